@@ -1,0 +1,470 @@
+"""Generate tests/golden/*.npz by RUNNING THE UPSTREAM REFERENCE (imported from /root/reference).
+
+TEST INFRASTRUCTURE.  Runs only in the build container (the reference never travels); the
+fixtures it writes are data: seeded/closed-form inputs and the reference's outputs for them.
+
+    python oracle/make_golden.py            # rewrites every fixture
+
+Fixture families: G1 grid_sample, G2 AdvBias, G3 AdvMorph, G4 AdvAffine,
+G5 consistency loss, G6 full solver traces (per-step dist / raw grads / params for the
+teacher-forced protocol), plus the RNG-free known-answer sums of SURVEY Appendix B.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle._import_reference import import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+CPU = torch.device("cpu")
+
+
+def smooth_data(n, c, dims, seed):
+    """Band-limited test images in [0,1]: linear upsample of a coarse random tensor."""
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.rand(n, c, *([6] * len(dims)), generator=g)
+    mode = "bilinear" if len(dims) == 2 else "trilinear"
+    return F.interpolate(coarse, size=tuple(dims), mode=mode, align_corners=True).clamp(0, 1).contiguous()
+
+
+def rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def make_model(spatial_dims, k=4):
+    """Conv(1,k,3,1,1) with closed-form weights."""
+    if spatial_dims == 2:
+        m = torch.nn.Conv2d(1, k, 3, 1, 1)
+        w = torch.zeros(k, 1, 3, 3)
+        for q in range(k):
+            for a in range(3):
+                for b in range(3):
+                    w[q, 0, a, b] = 0.1 * (q + 1) * ((a - 1) + 2 * (b - 1)) + 0.05
+    else:
+        m = torch.nn.Conv3d(1, k, 3, 1, 1)
+        w = torch.zeros(k, 1, 3, 3, 3)
+        for q in range(k):
+            for a in range(3):
+                for b in range(3):
+                    for c in range(3):
+                        w[q, 0, a, b, c] = 0.05 * (q + 1) * ((a - 1) + 2 * (b - 1) - (c - 1)) + 0.02
+    m.weight.data = w
+    m.bias.data = torch.tensor([0.01 * q for q in range(k)])
+    return m.eval()
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        elif isinstance(v, (dict, list, tuple)) and not isinstance(v, np.ndarray):
+            out[k] = np.array(json.dumps(v))
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **npify(d))
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_grid_sample():
+    out = {}
+    for tag, dims, C in (("2d", (9, 11), 3), ("3d", (6, 7, 5), 2)):
+        d = len(dims)
+        for pad in ("zeros", "border"):
+            inp = rand((2, C) + dims, 11 + d).requires_grad_(True)
+            # positions: mostly inside, some beyond [-1,1], some exactly on the border
+            grid = rand((2,) + dims + (d,), 13 + d, -1.25, 1.25)
+            grid.view(-1)[::17] = 1.0
+            grid.view(-1)[5::19] = -1.0
+            grid.requires_grad_(True)
+            w = rand((2, C) + dims, 17 + d)
+            o = F.grid_sample(inp, grid, mode="bilinear", padding_mode=pad, align_corners=True)
+            (o * w).sum().backward()
+            key = "%s_%s_" % (tag, pad)
+            out[key + "input"], out[key + "grid"], out[key + "w"] = inp, grid, w
+            out[key + "out"], out[key + "grad_input"], out[key + "grad_grid"] = o, inp.grad, grid.grad
+        inp = rand((2, C) + dims, 23)
+        grid = rand((2,) + dims + (d,), 29, -1.1, 1.1)
+        out[tag + "_nearest_input"], out[tag + "_nearest_grid"] = inp, grid
+        out[tag + "_nearest_out"] = F.grid_sample(inp, grid, mode="nearest", padding_mode="zeros",
+                                                  align_corners=True)
+    save("g1_grid_sample", out)
+
+
+# ----------------------------------------------------------------------------- G2
+def g2_bias(aug):
+    out = {}
+    cases = {
+        "2d_small": dict(spatial_dims=2, data_size=[2, 1, 32, 32], control_point_spacing=[16, 16], downscale=2),
+        "3d_small": dict(spatial_dims=3, data_size=[2, 1, 16, 16, 8], control_point_spacing=[8, 8, 4], downscale=2),
+        "2d_odd": dict(spatial_dims=2, data_size=[1, 2, 40, 28], control_point_spacing=[12, 10], downscale=2),
+        "3d_ds1": dict(spatial_dims=3, data_size=[1, 1, 12, 10, 8], control_point_spacing=[6, 4, 4], downscale=1),
+        "2d_cfg1": dict(spatial_dims=2, data_size=[1, 1, 192, 192], control_point_spacing=[96, 96], downscale=2),
+        "2d_cfg2": dict(spatial_dims=2, data_size=[1, 1, 256, 256], control_point_spacing=[128, 128], downscale=2),
+        "3d_cfg3": dict(spatial_dims=3, data_size=[1, 1, 128, 128, 64], control_point_spacing=[64, 64, 32], downscale=4),
+    }
+    meta = {}
+    for i, (tag, c) in enumerate(cases.items()):
+        for space in (("log", "linear") if tag.endswith("small") else ("log",)):
+            cfg = dict(epsilon=0.3, control_point_spacing=c["control_point_spacing"], downscale=c["downscale"],
+                       data_size=c["data_size"], interpolation_order=3, init_mode="random", space=space)
+            t = aug.AdvBias(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
+            torch.manual_seed(100 + i)
+            t.init_parameters()
+            p = (rand(tuple(t.param.shape), 200 + i) * 0.45).requires_grad_(True)  # beyond log(1.3): exercises the clip
+            t.param = p
+            data = smooth_data(*c["data_size"][:2], c["data_size"][2:], 300 + i)
+            w = rand(tuple(data.shape), 400 + i)
+            o = t.forward(data)
+            (o * w).sum().backward()
+            key = "%s_%s_" % (tag, space)
+            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, cp_grid=list(t.param.shape),
+                             crop_start=t._crop_start.tolist(), crop_end=t._crop_end.tolist(),
+                             stride=list(t._stride), padding=list(t._padding),
+                             kernel=list(t.interp_kernel.shape))
+            big = data.numel() > 30000
+            out[key + "param"], out[key + "grad_param"] = p.detach(), p.grad
+            if big:  # strided samples + sums keep the fixture small
+                sl = tuple([slice(None)] * 2 + [slice(None, None, 7)] * c["spatial_dims"])
+                out[key + "field_sample"] = t.bias_field.detach()[sl]
+                out[key + "field_sum"] = t.bias_field.detach().double().sum()
+                out[key + "data_seed"] = 300 + i
+                out[key + "w_seed"] = 400 + i
+            else:
+                out[key + "data"], out[key + "w"] = data, w
+                out[key + "field"], out[key + "out"] = t.bias_field.detach(), o.detach()
+    out["meta"] = meta
+    save("g2_bias", out)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3_morph(aug):
+    out, meta = {}, {}
+    cases = {
+        "2d": dict(spatial_dims=2, data_size=[2, 1, 32, 32], vector_size=[4, 4], epsilon=1.5, C=1),
+        "2d_k4": dict(spatial_dims=2, data_size=[2, 4, 24, 40], vector_size=[3, 5], epsilon=1.5, C=4),
+        "3d": dict(spatial_dims=3, data_size=[2, 1, 16, 16, 8], vector_size=[4, 4, 2], epsilon=1.5, C=1),
+        "3d_k4": dict(spatial_dims=3, data_size=[1, 4, 12, 10, 14], vector_size=[3, 2, 4], epsilon=1.5, C=4),
+        # big epsilon: ||u/2^8|| > 0.5 so the 3D exponentiation takes more than 8 squarings (Q2)
+        "3d_bigeps": dict(spatial_dims=3, data_size=[2, 1, 16, 16, 8], vector_size=[4, 4, 2], epsilon=400.0, C=1),
+    }
+    for i, (tag, c) in enumerate(cases.items()):
+        cfg = dict(epsilon=c["epsilon"], data_size=c["data_size"], vector_size=c["vector_size"])
+        t = aug.AdvMorph(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
+        torch.manual_seed(500 + i)
+        t.init_parameters()
+        p = t.unit_normalize(rand(tuple(t.param.shape), 600 + i)).detach().requires_grad_(True)
+        t.param = p
+        data = smooth_data(c["data_size"][0], c["C"], c["data_size"][2:], 700 + i)
+        w = rand(tuple(data.shape), 800 + i)
+        key = tag + "_"
+        dxy_f, _ = t.get_deformation_displacement_field(duv=t.epsilon * p)
+        dxy_b, _ = t.get_deformation_displacement_field(duv=-t.epsilon * p)
+        o = t.forward(data)
+        (o * w).sum().backward()
+        gf = p.grad.clone()
+        p.grad = None
+        ob = t.backward(data)
+        (ob * w).sum().backward()
+        gb = p.grad.clone()
+        p.grad = None
+        # round trip with a data gradient as well (prediction path: data requires grad)
+        dd = data.clone().requires_grad_(True)
+        rt = t.backward(t.forward(dd))
+        (rt * w).sum().backward()
+        meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, C=c["C"])
+        out.update({key + "param": p.detach(), key + "data": data, key + "w": w,
+                    key + "dxy_fwd": dxy_f.detach(), key + "dxy_bwd": dxy_b.detach(),
+                    key + "forward": o.detach(), key + "backward": ob.detach(),
+                    key + "grad_param_fwd": gf, key + "grad_param_bwd": gb,
+                    key + "roundtrip": rt.detach(), key + "roundtrip_grad_param": p.grad.clone(),
+                    key + "roundtrip_grad_data": dd.grad.clone()})
+        # border padding + nearest interpolation (label warping, §8 f3)
+        p.grad = None
+        out[key + "forward_border"] = t.forward(data, padding_mode="border").detach()
+        out[key + "forward_nearest"] = t.forward(data, interp="nearest").detach()
+    out["meta"] = meta
+    save("g3_morph", out)
+
+
+# ----------------------------------------------------------------------------- G4
+def g4_affine(aug):
+    out, meta = {}, {}
+    cfg2 = dict(rot=30.0 / 180.0, scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1)
+    cfg3 = dict(rot_x=10.0 / 180, rot_y=10.0 / 180, rot_z=10.0 / 180, scale_x=0.1, scale_y=0.1, scale_z=0.1,
+                shift_x=0.1, shift_y=0.1, shift_z=0.1)
+    cases = {
+        "2d": (2, [2, 1, 32, 32], cfg2, 1, torch.tensor([[0.5, -0.3, 0.8, 0.2, -0.6], [-0.9, 0.4, -0.1, 0.7, 0.3]])),
+        "2d_sat": (2, [2, 4, 24, 40], cfg2, 4, torch.tensor([[1.5, -0.3, -1.8, 0.2, 1.0], [-0.9, 2.4, -0.1, -1.0, 0.3]])),
+        "3d": (3, [2, 1, 16, 16, 8], cfg3, 1,
+               torch.tensor([[0.5, -0.3, 0.8, 0.2, -0.6, 0.1, -0.4, 0.9, -0.7],
+                             [-0.9, 0.4, -0.1, 0.7, 0.3, -0.5, 0.6, -0.2, 0.8]])),
+        "3d_k4": (3, [1, 4, 12, 10, 14], cfg3, 4,
+                  torch.tensor([[0.9, 1.3, -0.8, -0.2, 0.6, -1.1, 0.4, -0.9, 0.7]])),
+    }
+    for i, (tag, (sd, ds, cfg, C, param)) in enumerate(cases.items()):
+        cfg = dict(cfg, data_size=ds)
+        t = aug.AdvAffine(spatial_dims=sd, config_dict=cfg, use_gpu=False, device=CPU)
+        torch.manual_seed(900 + i)
+        t.init_parameters()
+        p = param.clone().requires_grad_(True)
+        t.param = p
+        data = smooth_data(ds[0], C, ds[2:], 1000 + i)
+        w = rand(tuple(data.shape), 1100 + i)
+        o = t.forward(data)
+        theta = t.affine_matrix.detach().clone()
+        (o * w).sum().backward()
+        gf = p.grad.clone()
+        p.grad = None
+        t.forward(data)
+        ob = t.backward(data)
+        theta_inv = t.get_inverse_matrix(t.affine_matrix).detach().clone()
+        (ob * w).sum().backward()
+        gb = p.grad.clone()
+        p.grad = None
+        dd = data.clone().requires_grad_(True)
+        rt = t.backward(t.forward(dd))
+        (rt * w).sum().backward()
+        key = tag + "_"
+        meta[key] = dict(spatial_dims=sd, config=cfg, C=C)
+        out.update({key + "param": p.detach(), key + "data": data, key + "w": w, key + "theta": theta,
+                    key + "theta_inv": theta_inv, key + "forward": o.detach(), key + "backward": ob.detach(),
+                    key + "grad_param_fwd": gf, key + "grad_param_bwd": gb, key + "roundtrip": rt.detach(),
+                    key + "roundtrip_grad_param": p.grad.clone(), key + "roundtrip_grad_data": dd.grad.clone()})
+    out["meta"] = meta
+    save("g4_affine", out)
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_loss():
+    import advchain.common.loss as L
+    out = {}
+    for tag, dims in (("2d", (20, 24)), ("3d", (10, 12, 8))):
+        pred = (rand((2, 4) + dims, 1200) * 2).requires_grad_(True)
+        ref = rand((2, 4) + dims, 1201) * 2
+        m1 = (rand((2, 1) + dims, 1202) > -0.6).float()
+        mask = m1.expand(2, 4, *dims).contiguous()
+        out[tag + "_pred"], out[tag + "_ref"], out[tag + "_mask"] = pred.detach(), ref, mask
+        for name, types, weights in (("mse", ["mse"], [1.0]), ("contour", ["contour"], [1.0]), ("kl", ["kl"], [1.0]),
+                                     ("mix", ["mse", "contour"], [1.0, 0.5])):
+            for mtag, mk in (("masked", mask), ("nomask", None)):
+                pred.grad = None
+                v = L.calc_segmentation_consistency(output=pred, reference=ref, divergence_types=types,
+                                                    divergence_weights=weights, scales=[0], mask=mk)
+                v.backward()
+                out["%s_%s_%s_value" % (tag, name, mtag)] = v.detach().double()
+                out["%s_%s_%s_grad" % (tag, name, mtag)] = pred.grad.clone()
+    save("g5_loss", out)
+
+
+# ----------------------------------------------------------------------------- G6
+def build_chain(aug, spatial_dims, data_size, names, pad_morph="zeros", pad_affine="zeros"):
+    dims = data_size[2:]
+    chain, spec = [], []
+    for nm in names:
+        if nm == "noise":
+            cfg = dict(epsilon=1.0, xi=1e-6, data_size=data_size)
+            t = aug.AdvNoise(spatial_dims=spatial_dims, config_dict=cfg, use_gpu=False, device=CPU)
+            kw = {}
+        elif nm == "bias":
+            cfg = dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims], downscale=2, data_size=data_size,
+                       interpolation_order=3, init_mode="random", space="log")
+            t = aug.AdvBias(spatial_dims=spatial_dims, config_dict=cfg, use_gpu=False, device=CPU)
+            kw = {}
+        elif nm == "morph":
+            vs = [max(2, s // 8) for s in dims] if spatial_dims == 2 else [max(2, s // 4) for s in dims]
+            cfg = dict(epsilon=1.5, data_size=data_size, vector_size=vs)
+            t = aug.AdvMorph(spatial_dims=spatial_dims, config_dict=cfg, use_gpu=False, device=CPU,
+                             image_padding_mode=pad_morph)
+            kw = dict(image_padding_mode=pad_morph)
+        else:
+            if spatial_dims == 2:
+                cfg = dict(rot=30.0 / 180.0, scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=data_size)
+            else:
+                cfg = dict(rot_x=10.0 / 180, rot_y=10.0 / 180, rot_z=10.0 / 180, scale_x=0.1, scale_y=0.1,
+                           scale_z=0.1, shift_x=0.1, shift_y=0.1, shift_z=0.1, data_size=data_size)
+            t = aug.AdvAffine(spatial_dims=spatial_dims, config_dict=cfg, use_gpu=False, device=CPU,
+                              image_padding_mode=pad_affine)
+            kw = dict(image_padding_mode=pad_affine)
+        chain.append(t)
+        spec.append(dict(name=nm, config=cfg, kwargs=kw))
+    return chain, spec
+
+
+def g6_solver(aug):
+    cases = {
+        "2d_full_n1": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=1),
+        "2d_full_n3": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=3),
+        "2d_full_n2_norm": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                                solver=dict(if_norm_image=True)),
+        "2d_smart_n2": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                            power_iteration="smart"),
+        "2d_power_n2": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                            power_iteration=True),
+        "2d_kl_n1": dict(sd=2, ds=[2, 1, 32, 32], names=["morph", "affine"], n_iter=1,
+                         solver=dict(divergence_types=["kl", "contour"], divergence_weights=[1.0, 0.5])),
+        "2d_photometric_n2": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias"], n_iter=2),
+        "2d_step_n2": dict(sd=2, ds=[3, 1, 24, 40], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                           step_sizes=[0.5, 0.2, 0.7, 0.1]),
+        "3d_bma_n2": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["bias", "morph", "affine"], n_iter=2),
+        "3d_full_n1": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["noise", "bias", "morph", "affine"], n_iter=1),
+        "3d_morph_anat_n2": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["morph"], n_iter=2, anatomy=True),
+        "2d_n0": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=0),
+    }
+    for ci, (tag, c) in enumerate(cases.items()):
+        sd, ds = c["sd"], c["ds"]
+        chain, spec = build_chain(aug, sd, ds, c["names"])
+        solver_kw = dict(divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
+        solver_kw.update(c.get("solver", {}))
+        solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
+                                                       **solver_kw)
+        model = make_model(sd)
+        data = smooth_data(ds[0], 1, ds[2:], 2000 + ci)
+        torch.manual_seed(3000 + ci)
+        init_params = []
+        for t in chain:
+            t.init_parameters()
+            init_params.append(t.param.detach().clone())
+        anatomy = None
+        if c.get("anatomy"):
+            axes = torch.meshgrid([torch.linspace(-1, 1, s) for s in ds[2:]], indexing="ij")
+            anatomy = (sum(a ** 2 for a in axes) <= 0.5 ** 2 * len(axes)).float()[None, None].repeat(ds[0], 1, 1, 1, 1)
+
+        # --- instrumentation: per-step records out of the reference's own loop
+        steps, losses, anat = [], [], []
+        for ti, t in enumerate(chain):
+            def wrap(t=t, ti=ti, orig=t.optimize_parameters):
+                def f(step_size=None):
+                    rec = dict(ti=ti, param_in=t.param.detach().clone(), grad=t.param.grad.detach().clone())
+                    r = orig(step_size=step_size)
+                    rec["param_out"] = t.param.detach().clone()
+                    steps.append(rec)
+                    return r
+                return f
+            t.optimize_parameters = wrap()
+        orig_loss = solver.loss_fn
+
+        def loss_rec(pred, reference, mask=None):
+            v = orig_loss(pred=pred, reference=reference, mask=mask)
+            losses.append(float(v.detach()))
+            return v
+        solver.loss_fn = loss_rec
+        orig_anat = solver.compute_anatomy_misoverlapping_loss
+
+        def anat_rec(anatomy_mask_images):
+            v = orig_anat(anatomy_mask_images)
+            anat.append(float(v.detach()))
+            return v
+        solver.compute_anatomy_misoverlapping_loss = anat_rec
+
+        kw = dict(n_iter=c["n_iter"], lazy_load=True, power_iteration=c.get("power_iteration", False),
+                  step_sizes=c.get("step_sizes", 1))
+        if anatomy is not None:
+            kw.update(anatomy_mask_images=anatomy, anatomy_reg_weight=50, volume_preserve_tolerance=5e-4)
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = solver.adversarial_training(data=data, model=model, **kw)
+        out = dict(meta=dict(spatial_dims=sd, data_size=ds, chain=spec, solver=solver_kw, train=kw if anatomy is None
+                             else {k: v for k, v in kw.items() if k != "anatomy_mask_images"},
+                             has_anatomy=anatomy is not None, n_transforms=len(solver.chain_of_transforms)),
+                   data=data, final_loss=loss.detach().double(), adv_data=solver.adv_data.detach(),
+                   adv_predict=solver.adv_predict.detach(), init_output=solver.init_output.detach(),
+                   warped_back=solver.warped_back_adv_output.detach(),
+                   loss_trace=np.array(losses, dtype=np.float64), anatomy_trace=np.array(anat, dtype=np.float64),
+                   n_updates=len(steps))
+        if anatomy is not None:
+            out["anatomy"] = anatomy
+        for i, p in enumerate(init_params):
+            out["init_param_%d" % i] = p
+        for i, t in enumerate(chain):
+            out["final_param_%d" % i] = t.param.detach()
+        for k, rec in enumerate(steps):
+            out["upd%02d_ti" % k] = rec["ti"]
+            out["upd%02d_param_in" % k] = rec["param_in"]
+            out["upd%02d_grad" % k] = rec["grad"]
+            out["upd%02d_param_out" % k] = rec["param_out"]
+        save("g6_" + tag, out)
+
+
+# ----------------------------------------------------------------------------- KATs
+def kat(aug):
+    """Re-derive the Appendix B scalars from the live reference so the fixture, not the prose, is the pin."""
+    out = {}
+    n, H = 2, 32
+    i = torch.arange(H).float().view(1, 1, H, 1)
+    j = torch.arange(H).float().view(1, 1, 1, H)
+    nn_ = torch.arange(n).float().view(n, 1, 1, 1)
+    data = 0.5 + 0.5 * torch.sin(0.37 * i + 0.11 * nn_) * torch.cos(0.23 * j)
+    ds = [n, 1, H, H]
+    chain, spec = build_chain(aug, 2, ds, ["noise", "bias", "morph", "affine"])
+    chain[0].epsilon = 0.1
+    chain[0].config_dict["epsilon"] = 0.1
+    chain[1].config_dict.update(control_point_spacing=[16, 16])
+    chain[2].config_dict.update(vector_size=[4, 4])
+    for t in chain:
+        t.init_config(t.config_dict)
+        t.init_parameters()
+    a = torch.arange(4).float()
+    noise_p = chain[0].unit_normalize(torch.cos(0.7 * i * j + nn_))
+    bias_p = 0.2 * torch.sin(1.3 * a.view(1, 1, 4, 1) + 0.7 * a.view(1, 1, 1, 4) + nn_)
+    c2 = torch.arange(2).float().view(1, 2, 1, 1)
+    morph_p = chain[2].unit_normalize(torch.sin(0.9 * a.view(1, 1, 4, 1) + 1.7 * a.view(1, 1, 1, 4) + 2.1 * c2 + 0.5 * nn_))
+    aff_p = torch.tensor([[0.5, -0.3, 0.8, 0.2, -0.6], [-0.9, 0.4, -0.1, 0.7, 0.3]])
+    for t, p in zip(chain, (noise_p, bias_p, morph_p, aff_p)):
+        t.set_parameters(p)
+    model = make_model(2)
+    solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
+                                                   divergence_weights=[1.0, 0.5], use_gpu=False, if_norm_image=True)
+    out["data"] = data
+    for k, p in zip(("noise", "bias", "morph", "affine"), (noise_p, bias_p, morph_p, aff_p)):
+        out["param_" + k] = p
+    out["noise_forward"] = chain[0].forward(data)
+    out["bias_forward"] = chain[1].forward(data)
+    out["morph_forward"] = chain[2].forward(data)
+    out["morph_backward"] = chain[2].backward(data)
+    out["affine_forward"] = chain[3].forward(data)
+    out["affine_backward"] = chain[3].backward(data)
+    out["solver_forward"] = solver.forward(data.clone())
+    l0 = solver.adversarial_training(data=data, model=model, n_iter=0, lazy_load=True)
+    out["loss_n0"] = l0.detach().double()
+    l2 = solver.adversarial_training(data=data, model=model, n_iter=2, lazy_load=True, step_sizes=1,
+                                     power_iteration=False)
+    out["loss_n2"] = l2.detach().double()
+    out["adv_data_n2"] = solver.adv_data.detach()
+    for k, t in zip(("noise", "bias", "morph", "affine"), chain):
+        out["final_" + k] = t.param.detach()
+    out["meta"] = dict(chain=spec)
+    save("kat_2d", out)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    aug = import_reference()
+    g1_grid_sample()
+    g2_bias(aug)
+    g3_morph(aug)
+    g4_affine(aug)
+    g5_loss()
+    g6_solver(aug)
+    kat(aug)
+
+
+if __name__ == "__main__":
+    main()
