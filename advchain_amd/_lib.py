@@ -1,0 +1,81 @@
+"""ctypes binding of ``libadvchain_hip.so`` (the C ABI declared in ``include/advchain_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  The product path never routes through PyTorch reference ops or the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadvchain_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes).  Must list every symbol of include/advchain_hip.h.
+PROTOTYPES = {
+    "advchain_version": (_I, []),
+    "advchain_last_error": (c_char_p, []),
+    "advchain_grid_sample_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P]),
+    "advchain_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P]),
+    "advchain_compose_self_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P]),
+    "advchain_compose_self_bwd": (_I, [_P, _P, _P, _L, _I, _P, _P]),
+    "advchain_affine_warp_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _I, _I, _P]),
+    "advchain_affine_warp_bwd_workspace": (_L, [_L, _I, _P]),
+    "advchain_affine_warp_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _P]),
+    "advchain_affine_theta_fwd": (_I, [_P, _P, _F, _P, _P, _L, _I, _P]),
+    "advchain_affine_theta_bwd": (_I, [_P, _P, _F, _P, _P, _P, _L, _I, _P]),
+    "advchain_tp_interp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _F, _P, _P]),
+    "advchain_band_reduce_axis": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _F, _P]),
+    "advchain_bias_field_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _F, _I, _F, _P]),
+    "advchain_bias_field_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _F, _I, _F, _P]),
+    "advchain_gauss_axis": (_I, [_P, _P, _P, _L, _L, _I, _P, _I, _P, _I, _I, _F, _P]),
+    "advchain_axpy": (_I, [_P, _P, _P, _F, _L, _P]),
+    "advchain_norm_workspace": (_L, [_L, _L]),
+    "advchain_norm_axpy": (_I, [_P, _P, _P, _P, _F, _L, _L, _P]),
+    "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _P]),
+    "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _I, _P, _I, _P]),
+}
+
+_lib = None
+
+
+class AdvchainHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdvchainHipError(
+            "libadvchain_hip.so not found at %s -- build it with `python -m advchain_amd.build` "
+            "(there is no CPU / PyTorch fallback for the advchain_amd kernels)" % LIB_PATH)
+    # make sure the HIP runtime PyTorch uses is the one already mapped (same SONAME libamdhip64.so.7)
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().advchain_last_error()
+        raise AdvchainHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def dims_array(dims):
+    return (c_int64 * len(dims))(*[int(d) for d in dims])
+
+
+def float_array(vals):
+    return (c_float * len(vals))(*[float(v) for v in vals])

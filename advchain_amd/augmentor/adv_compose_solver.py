@@ -1,0 +1,445 @@
+"""ComposeAdversarialTransformSolver: N gradient-ascent steps over a chain of adversarial transforms
+(reference: advchain/augmentor/adv_compose_solver.py:11-538; same public methods, arguments and control
+flow, including the reference's quirks -- see DESIGN.md "Quirks kept").
+
+What differs under the hood (results are unchanged, SURVEY §2.3 "Redundancy"):
+  * the validity mask of the forward o backward warp is computed on ONE channel, without autograd
+    (its gradient is exactly zero for 'mse'/'contour'), and re-uses the deformation fields of the data /
+    prediction path instead of recomputing two more DemonsCompose per step;
+  * no ``torch.cuda.empty_cache()`` inside the loop (5 allocator flushes per step in the reference);
+  * optional batch sharding over a ``torch.distributed`` process group (RCCL on ROCm): every rank owns a
+    contiguous slice of the batch; only scalars are exchanged (loss value / NaN guard, 3D step-count norm,
+    intensity range, anatomy check) and every normaliser uses the GLOBAL batch size.
+"""
+import logging
+
+import torch
+
+from ..common.loss import calc_segmentation_consistency
+from ..common.utils import _disable_tracking_bn_stats, _fix_dropout
+from .adv_affine import AdvAffine
+from .adv_bias import AdvBias
+from .adv_morph import AdvMorph
+from .adv_noise import AdvNoise
+
+_NATIVE = (AdvNoise, AdvBias, AdvMorph, AdvAffine)
+
+
+class ComposeAdversarialTransformSolver(object):
+    """apply a chain of transformation"""
+
+    def __init__(self, chain_of_transforms=[], divergence_types=['mse', 'contour'],
+                 divergence_weights=[1.0, 0.5], use_gpu=True, debug=False, if_norm_image=False,
+                 min_intensity=None, max_intensity=None, is_gt=False, process_group=None):
+        self.chain_of_transforms = chain_of_transforms
+        self.use_gpu = use_gpu
+        self.debug = debug
+        self.divergence_weights = divergence_weights
+        self.divergence_types = divergence_types
+        self.require_bi_loss = self.if_contains_geo_transform()
+        self.if_norm_image = if_norm_image
+        self.min_intensity = min_intensity
+        self.max_intensity = max_intensity
+        self.is_gt = is_gt
+        self.class_weights = None
+        self.process_group = process_group     # extension: batch-sharded replicas
+        self._global_batch = None
+
+    # ------------------------------------------------------------------------------- sharding helpers
+    def _dist(self):
+        if self.process_group is None:
+            return None
+        import torch.distributed as dist
+        return dist
+
+    def _all_reduce_(self, t, op="sum"):
+        dist = self._dist()
+        if dist is not None:
+            ops_ = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
+            dist.all_reduce(t, op=ops_[op], group=self.process_group)
+        return t
+
+    def _resolve_global_batch(self, n_local, device):
+        if self.process_group is None:
+            self._global_batch = None
+            return
+        t = torch.tensor([float(n_local)], device=device)
+        self._global_batch = int(self._all_reduce_(t).item())
+        for tr in self.chain_of_transforms:
+            if isinstance(tr, AdvMorph):
+                tr.process_group = self.process_group
+
+    def _global_value(self, local):
+        """Whole-batch value of a per-shard partial loss; keeps the autograd path of the local part."""
+        if self.process_group is None:
+            return local
+        total = self._all_reduce_(local.detach().clone())
+        return local + (total - local.detach())
+
+    # ------------------------------------------------------------------------------- public API
+    def adversarial_training(self, data, model, optimize_flags=None, init_output=None, lazy_load=False,
+                             power_iteration=False, n_iter=1, step_sizes=None, anatomy_mask_images=None,
+                             anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4):
+        """Optimise the chain against ``model`` on ``data`` and return the adversarial consistency loss
+        (adv_compose_solver.py:43-146)."""
+        n_t = len(self.chain_of_transforms)
+        if optimize_flags is not None:
+            assert n_t == len(optimize_flags), \
+                f'must specify each transform is learnable or not, expect {n_t} flags, but got {optimize_flags}'
+        else:
+            if n_iter == 0:
+                optimize_flags = [False] * n_t
+            elif n_iter > 0:
+                optimize_flags = [True] * n_t
+            else:
+                raise NotImplementedError
+        if isinstance(power_iteration, bool):
+            power_iterations = [power_iteration] * n_t
+        elif isinstance(power_iteration, list):
+            assert n_t == len(power_iteration), 'must specify each transform optimization mode'
+            power_iterations = power_iteration
+        elif isinstance(power_iteration, str):
+            if "smart" == power_iteration:
+                power_iterations = [t.get_name() == 'noise' for t in self.chain_of_transforms]
+            else:
+                raise NotImplementedError(power_iteration)
+        for i, pi in enumerate(power_iterations):
+            self.chain_of_transforms[i].power_iteration = pi
+        if step_sizes is None:
+            step_sizes = [1] * n_t
+        elif isinstance(step_sizes, (float, int)):
+            step_sizes = [step_sizes] * n_t
+        elif isinstance(step_sizes, list):
+            assert len(step_sizes) == n_t, 'specify step size for each transformation'
+        else:
+            raise ValueError('please use scalar or a  list of scalar to set step size')
+        self._resolve_global_batch(data.size(0), data.device)
+        if init_output is None:
+            init_output = self.get_init_output(data=data, model=model)
+        self.init_random_transformation(lazy_load, anatomy_mask_images=anatomy_mask_images,
+                                        volume_preserve_tolerance=volume_preserve_tolerance)
+        if n_iter >= 1:
+            self.chain_of_transforms = self.optimizing_transform(
+                data=data, model=model, init_output=init_output, n_iter=n_iter, optimize_flags=optimize_flags,
+                step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
+                anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
+        dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
+            data.detach().clone(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
+        self.init_output = init_output
+        self.warped_back_adv_output = warped_back_adv_output
+        self.origin_data = data
+        self.adv_data = adv_data
+        self.adv_predict = adv_output
+        if self.debug:
+            print('[outer loop] loss', dist.item())
+        return dist
+
+    @property
+    def diffs(self):
+        return [t.diff for t in self._last_chain]
+
+    def forward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
+        """Apply the chain in order (adv_compose_solver.py:148-176)."""
+        data.requires_grad = False
+        t_data = data.detach().clone()
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        self._last_chain = list(chain_of_transforms)
+        for transform in chain_of_transforms:
+            t_data = transform.forward(t_data, interp=interp, padding_mode=padding_mode)
+        if self.if_norm_image:
+            lo = self.min_intensity
+            hi = self.max_intensity
+            if lo is None:
+                lo = self._all_reduce_(torch.min(data).reshape(1), "min")[0]
+            if hi is None:
+                hi = self._all_reduce_(torch.max(data).reshape(1), "max")[0]
+            t_data = torch.clamp(t_data, lo, hi)
+        return t_data
+
+    def predict_forward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
+        # adv_compose_solver.py:184-197
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        self._last_chain = list(chain_of_transforms)
+        for transform in chain_of_transforms:
+            data = transform.predict_forward(data, interp=interp, padding_mode=padding_mode)
+        return data
+
+    def backward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
+        # adv_compose_solver.py:199-208
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        for transform in reversed(chain_of_transforms):
+            data = transform.backward(data, interp=interp, padding_mode=padding_mode)
+        return data
+
+    def predict_backward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
+        # adv_compose_solver.py:210-219
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        for transform in reversed(chain_of_transforms):
+            data = transform.predict_backward(data, interp=interp, padding_mode=padding_mode)
+        return data
+
+    def loss_fn(self, pred, reference, mask=None):
+        """Inconsistency of two predictions in the same coordinates (adv_compose_solver.py:221-234).  Under
+        batch sharding the returned tensor is this rank's partial (global normalisers): partials sum to the
+        whole-batch loss."""
+        if self.process_group is not None and self._global_batch is None:
+            self._resolve_global_batch(pred.size(0), pred.device)
+        return calc_segmentation_consistency(output=pred, reference=reference, divergence_types=self.divergence_types,
+                                             divergence_weights=self.divergence_weights, scales=[0], mask=mask,
+                                             class_weights=self.class_weights, is_gt=self.is_gt,
+                                             global_batch=self._global_batch)
+
+    # ------------------------------------------------------------------------------- masks
+    def _shared_fields(self, chain, on):
+        for t in chain:
+            hook = getattr(t, '_begin_shared_fields' if on else '_end_shared_fields', None)
+            if hook is not None:
+                hook()
+
+    def _validity_mask(self, init_output, chain):
+        """ones -> forward chain -> backward chain -> (x != 0)  (adv_compose_solver.py:262-268,321-325, Q12)."""
+        native = all(isinstance(t, _NATIVE) for t in chain)
+        zero_grad_ok = all(t in ('mse', 'contour') for t in self.divergence_types)
+        if native and zero_grad_ok:
+            with torch.no_grad():
+                ones = torch.ones((init_output.shape[0], 1) + tuple(init_output.shape[2:]), dtype=init_output.dtype,
+                                  device=init_output.device)
+                fb = self.predict_backward(self.predict_forward(ones, chain), chain)
+                m = (fb != 0).to(init_output.dtype)
+            return m.expand(init_output.shape)
+        masks = torch.ones_like(init_output, dtype=init_output.dtype, device=init_output.device, requires_grad=False)
+        fb = self.predict_backward(self.predict_forward(masks, chain), chain)
+        fb[fb != 0] = 1
+        return fb
+
+    def calc_adv_consistency_loss(self, data, model, init_output, chain_of_transforms=None):
+        """Consistency loss under the current (fixed) transforms (adv_compose_solver.py:236-279)."""
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        for tr in chain_of_transforms:
+            tr.eval()
+        self._shared_fields(chain_of_transforms, True)
+        try:
+            adv_data = self.forward(data, chain_of_transforms)
+            old_state = model.training
+            model.train()
+            with _fix_dropout(model):
+                adv_output = self.get_net_output(model, adv_data.detach().clone())
+            if self.if_contains_geo_transform(chain_of_transforms):
+                mask = self._validity_mask(init_output, chain_of_transforms)
+                warped_back_adv_output = self.predict_backward(adv_output, chain_of_transforms)
+                dist = self.loss_fn(pred=warped_back_adv_output, reference=init_output.detach(), mask=mask)
+            else:
+                warped_back_adv_output = adv_output
+                dist = self.loss_fn(pred=adv_output, reference=init_output.detach())
+            model.train(old_state)
+        finally:
+            self._shared_fields(chain_of_transforms, False)
+        return self._global_value(dist), adv_data, adv_output, warped_back_adv_output
+
+    def compute_anatomy_misoverlapping_loss(self, anatomy_mask_images):
+        """Round-trip warp of the anatomy mask, thresholded, MSE to the original (adv_compose_solver.py:281-287).
+        Value only: its gradient w.r.t. the transform parameters is exactly zero (Q18)."""
+        with torch.no_grad():
+            rec = self.predict_backward(self.predict_forward(anatomy_mask_images))
+            rec = (rec >= 0.5).to(anatomy_mask_images.dtype)
+            if self.process_group is None:
+                score = torch.nn.functional.mse_loss(rec, anatomy_mask_images)
+            else:
+                se = self._all_reduce_(((rec - anatomy_mask_images) ** 2).sum().reshape(1))[0]
+                per_sample = anatomy_mask_images.numel() // anatomy_mask_images.shape[0]
+                score = se / (float(self._global_batch) * per_sample)
+        if self.debug:
+            print('anatomy preserving error:', score)
+        return score
+
+    def optimizing_transform(self, model, data, init_output, optimize_flags, n_iter=1, step_sizes=None,
+                             anatomy_mask_images=None, anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4):
+        """The N-step ascent loop (adv_compose_solver.py:289-405)."""
+        stop_flag = False if n_iter > 0 else True
+        i_iter = 0
+        one_time_iter = n_iter
+        transforms = []
+        use_anatomy = anatomy_mask_images is not None and abs(anatomy_reg_weight) > 1e-32
+        while stop_flag is False:
+            model.zero_grad()
+            i_iter += 1
+            self.make_learnable_transformation(optimize_flags=optimize_flags,
+                                               chain_of_transforms=self.chain_of_transforms)
+            self._shared_fields(self.chain_of_transforms, True)
+            try:
+                augmented_data = self.forward(data.detach().clone())
+                with _disable_tracking_bn_stats(model):
+                    perturbed_output = self.get_net_output(model, augmented_data)
+                if self.if_contains_geo_transform(self.chain_of_transforms):
+                    warped_back_prediction = self.predict_backward(perturbed_output)
+                    mask = self._validity_mask(init_output, self.chain_of_transforms)
+                    dist = self.loss_fn(pred=warped_back_prediction, reference=init_output, mask=mask)
+                    if use_anatomy:
+                        assert anatomy_mask_images.size() == data.size(), \
+                            "gt mask should be of the same size as input image "
+                        reg_loss = anatomy_reg_weight * self.compute_anatomy_misoverlapping_loss(
+                            anatomy_mask_images=anatomy_mask_images)
+                        if self.debug:
+                            print("consistency loss", dist.item())
+                            print("reg_loss:", reg_loss.item())
+                        # constant w.r.t. every parameter (Q18); a rank-local share keeps the partials summable
+                        dist = dist + reg_loss / (1 if self.process_group is None else self._dist().get_world_size(self.process_group))
+                else:
+                    dist = self.loss_fn(pred=perturbed_output, reference=init_output.detach())
+                value = self._global_value(dist)
+                if self.debug:
+                    print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
+                self.last_inner_dist = value.detach()
+                if torch.isnan(value) or torch.isinf(value):
+                    dist = 0
+                else:
+                    dist.backward()
+                    i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
+                    #           is stepped with step_sizes[0]; kept for result parity
+                    for flag, transform in zip(optimize_flags, self.chain_of_transforms):
+                        if flag:
+                            if self.debug:
+                                print('update {} parameters'.format(transform.get_name()))
+                            try:
+                                step_size = step_sizes[i_tr]
+                            except Exception:
+                                step_size = transform.get_step_size()
+                                logging.warning(f'use default step size:{step_size}')
+                            transform.optimize_parameters(step_size=step_size)
+            finally:
+                self._shared_fields(self.chain_of_transforms, False)
+            model.zero_grad()
+
+            if i_iter == n_iter:
+                transforms = []
+                for flag, transform in zip(optimize_flags, self.chain_of_transforms):
+                    if flag:
+                        transform.rescale_parameters()
+                        transform.eval()
+                    transforms.append(transform)
+                if self.if_contains_geo_transform(transforms) and use_anatomy:
+                    print('activating volume preserving check')
+                    if abs(self.compute_anatomy_misoverlapping_loss(anatomy_mask_images)) <= volume_preserve_tolerance:
+                        print('Success! pass the volume preserving check')
+                        stop_flag = True
+                    else:
+                        if i_iter >= 3 * one_time_iter:
+                            stop_flag = True
+                            self.init_random_transformation(anatomy_mask_images=anatomy_mask_images,
+                                                            volume_preserve_tolerance=volume_preserve_tolerance)
+                        else:
+                            if i_iter == 2 * one_time_iter:
+                                self.init_random_transformation(anatomy_mask_images=anatomy_mask_images,
+                                                                volume_preserve_tolerance=volume_preserve_tolerance)
+                                n_iter += one_time_iter
+                                print('warning: the volume is not preserved, will continue search with a new initialization')
+                            else:
+                                n_iter += 1
+                                print('warning: the volume is not preserved, will continue search with one more step')
+                        for flag, transform in zip(optimize_flags, self.chain_of_transforms):
+                            if flag:
+                                transform.train()
+                        transforms.append(transform)  # reference quirk (line 399): last transform listed twice
+                else:
+                    stop_flag = True
+        return transforms
+
+    def rescale_intensity(self, data, new_min=0, new_max=1, eps=1e-20):
+        # adv_compose_solver.py:407-421
+        old_size = data.size()
+        flat = data.view(data.size(0), -1)
+        old_max = torch.max(flat, dim=1, keepdim=True).values
+        old_min = torch.min(flat, dim=1, keepdim=True).values
+        out = (flat - old_min + eps) / (old_max - old_min + eps) * (new_max - new_min) + new_min
+        return out.view(old_size)
+
+    def get_net_output(self, model, data):
+        """Override point (README: custom network outputs), adv_compose_solver.py:423-427."""
+        return model.forward(data)
+
+    def get_init_output(self, model, data):
+        # adv_compose_solver.py:429-433
+        with torch.no_grad():
+            with _disable_tracking_bn_stats(model):
+                reference_output = self.get_net_output(model, data)
+        return reference_output
+
+    def get_adv_data(self, data, model, init_output=None, n_iter=0, optimize_flags=None, step_sizes=None,
+                     anatomy_mask_images=None, anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4):
+        """Augmented input and the correspondingly warped reference (adv_compose_solver.py:435-463)."""
+        self._resolve_global_batch(data.size(0), data.device)
+        if init_output is None:
+            init_output = self.get_init_output(model, data)
+        if optimize_flags is None:
+            optimize_flags = [True] * len(self.chain_of_transforms)
+        if step_sizes is None:
+            step_sizes = [1] * len(self.chain_of_transforms)
+        self.init_random_transformation(lazy_load=False, anatomy_mask_images=anatomy_mask_images,
+                                        volume_preserve_tolerance=volume_preserve_tolerance)
+        origin_data = data.detach().clone()
+        if n_iter > 0:
+            optimized_transforms = self.optimizing_transform(
+                data=data, model=model, init_output=init_output, n_iter=n_iter, optimize_flags=optimize_flags,
+                step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
+                anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
+        else:
+            optimized_transforms = self.chain_of_transforms
+        augmented_data = self.forward(origin_data, optimized_transforms)
+        augmented_label = self.predict_forward(init_output, optimized_transforms)
+        return augmented_data, augmented_label
+
+    def if_contains_geo_transform(self, chain_of_transforms=None):
+        # adv_compose_solver.py:465-477
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        return sum(t.is_geometric() for t in chain_of_transforms) > 0
+
+    def init_random_transformation(self, lazy_load=False, anatomy_mask_images=None,
+                                   volume_preserve_tolerance=5 * 1e-4):
+        """(Re-)draw transform parameters; geometric ones are re-drawn up to 11 times until the anatomy mask
+        survives the round trip (adv_compose_solver.py:479-500)."""
+        for transform in self.chain_of_transforms:
+            if lazy_load:
+                if transform.param is None:
+                    transform.init_parameters()
+            else:
+                transform.init_parameters()
+            if transform.is_geometric() == 1 and anatomy_mask_images is not None:
+                i_iter = 0
+                while self.compute_anatomy_misoverlapping_loss(anatomy_mask_images) > volume_preserve_tolerance:
+                    transform.init_parameters()
+                    i_iter += 1
+                    if i_iter > 10:
+                        break
+
+    def reset_transformation(self, anatomy_mask_images=None, volume_preserve_tolerance=5 * 1e-4):
+        self.init_random_transformation(lazy_load=False, anatomy_mask_images=anatomy_mask_images,
+                                        volume_preserve_tolerance=volume_preserve_tolerance)
+
+    def set_transformation(self, parameter_list):
+        # adv_compose_solver.py:505-514
+        for i, param in enumerate(parameter_list):
+            self.chain_of_transforms[i].set_parameters(param)
+
+    def train(self):
+        if self.chain_of_transforms is not None:
+            for transform in self.chain_of_transforms:
+                transform.train()
+
+    def eval(self):
+        if self.chain_of_transforms is not None:
+            for transform in self.chain_of_transforms:
+                transform.eval()
+
+    def make_learnable_transformation(self, optimize_flags, chain_of_transforms=None):
+        # adv_compose_solver.py:525-538
+        if chain_of_transforms is None:
+            chain_of_transforms = self.chain_of_transforms
+        for flag, transform in zip(optimize_flags, chain_of_transforms):
+            if flag:
+                transform.train()

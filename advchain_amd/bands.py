@@ -1,0 +1,134 @@
+"""Host-side construction of band tables for the tensor-product interpolation kernels.
+
+A band table describes, per spatial axis, a small linear map (g coefficients -> S samples, at most
+8 contiguous non-zeros per sample).  Two maps are used on the hot path:
+
+* linear upsampling with ``align_corners=False`` (ATen ``UpSample.h:259-311``) -- the velocity
+  upsample of ``adv_morph.py:464`` and the last stage of the bias field (``adv_bias.py:316-327``);
+* the cubic B-spline synthesis ``conv_transpose(cp, kernel) -> crop`` of ``adv_bias.py:12-49,293-307``
+  in closed form, composed with the upsample into ONE per-axis matrix.
+
+This is geometry set-up (O(S) numbers per axis, done once per transform), not the data path.
+"""
+import numpy as np
+import torch
+
+BAND_MAX = 8
+
+
+def linear_upsample_matrix(in_size, out_size, scale_factor=None):
+    """(out_size, in_size) matrix of F.interpolate(mode=linear, align_corners=False), fp32 index
+    arithmetic exactly as ATen (area_pixel_compute_scale / compute_source_index / guard_index_and_lambda)."""
+    if scale_factor is not None and scale_factor > 0:
+        scale = np.float32(1.0 / float(scale_factor))
+    else:
+        scale = np.float32(in_size) / np.float32(out_size)
+    dst = np.arange(out_size, dtype=np.float32)
+    src = scale * (dst + np.float32(0.5)) - np.float32(0.5)
+    src = np.where(src < 0, np.float32(0), src).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), in_size - 1)
+    lam1 = np.clip(src - i0.astype(np.float32), 0, 1).astype(np.float32)
+    lam0 = (np.float32(1) - lam1).astype(np.float32)
+    i1 = i0 + (i0 < in_size - 1)
+    M = np.zeros((out_size, in_size), dtype=np.float64)
+    rows = np.arange(out_size)
+    np.add.at(M, (rows, i0), lam0.astype(np.float64))
+    np.add.at(M, (rows, i1), lam1.astype(np.float64))
+    return M
+
+
+def bspline_kernel_1d(spacing, order, variant):
+    """1-D factor of the reference's separable B-spline window (adv_bias.py:12-49).
+
+    variant '2d': round i pads by i*s (window ends up zero-padded to 10s+3 for order 3);
+    variant '3d': every round pads s-1 (length 4s-3).  Returned in float64."""
+    s = int(spacing)
+    k = np.ones(s, dtype=np.float64)
+    ones = np.ones(s, dtype=np.float64)
+    for i in range(1, order + 1):
+        pad = i * s if variant == "2d" else s - 1
+        k = np.convolve(np.pad(k, pad), ones, mode="valid") / s
+    return k
+
+
+def bspline_synthesis_matrix(n_cp, spacing, order, variant, crop_start, crop_end):
+    """(h, n_cp) matrix of conv_transpose(cp, kernel, stride=s, padding=(len-1)//2) followed by the crop
+    [s + crop_start : -s - crop_end]  (adv_bias.py:293-307, 370-371)."""
+    s = int(spacing)
+    k = bspline_kernel_1d(s, order, variant)
+    K = len(k)
+    pad = int((K - 1) / 2)
+    full_len = (n_cp - 1) * s - 2 * pad + K
+    full = np.zeros((full_len, n_cp), dtype=np.float64)
+    for i in range(n_cp):
+        for t in range(K):
+            o = i * s - pad + t
+            if 0 <= o < full_len:
+                full[o, i] += k[t]
+    lo = s + int(crop_start)
+    hi = full_len - s - int(crop_end)
+    return full[lo:hi]
+
+
+class BandTables(object):
+    """Device band tables for a tensor-product map (g0,g1[,g2]) -> (S0,S1[,S2])."""
+
+    def __init__(self, mats, device):
+        mats = [np.asarray(m, dtype=np.float64) for m in mats]
+        self.ndim = len(mats)
+        assert self.ndim in (2, 3)
+        if self.ndim == 2:  # trivial leading axis so the kernels always see 3 axes
+            mats = [np.ones((1, 1))] + mats
+        ints, floats = [], []
+        self.S, self.g, self.B = [], [], []
+        for M in mats:
+            S, g = M.shape
+            nz = M != 0
+            first = np.where(nz.any(1), nz.argmax(1), 0)
+            last = np.where(nz.any(1), g - 1 - nz[:, ::-1].argmax(1), 0)
+            B = int(max(1, (last - first + 1).max()))
+            if B > BAND_MAX:
+                raise NotImplementedError("interpolation band %d exceeds the kernel limit %d" % (B, BAND_MAX))
+            B = min(B, g)
+            start = np.clip(np.minimum(first, g - B), 0, None).astype(np.int32)
+            w = np.zeros((S, B), dtype=np.float32)
+            for j in range(B):
+                w[:, j] = M[np.arange(S), start + j]
+            lo = np.zeros(g, dtype=np.int32)
+            hi = np.zeros(g, dtype=np.int32)
+            for k in range(g):
+                touched = np.nonzero((start <= k) & (k < start + B))[0]
+                if len(touched):
+                    lo[k], hi[k] = touched[0], touched[-1] + 1
+            ints += [start, lo, hi]
+            floats.append(w.reshape(-1))
+            self.S.append(S)
+            self.g.append(g)
+            self.B.append(B)
+        self.itab = torch.from_numpy(np.concatenate(ints).astype(np.int32)).to(device)
+        self.ftab = torch.from_numpy(np.concatenate(floats).astype(np.float32)).to(device)
+        self.mats = mats  # kept on the host for tests / debugging
+
+    @property
+    def coef_dims(self):
+        return self.g[3 - self.ndim:]
+
+    @property
+    def full_dims(self):
+        return self.S[3 - self.ndim:]
+
+
+def upsample_tables(low_dims, full_dims, device, scale_factors=None):
+    mats = []
+    for a, (l, f) in enumerate(zip(low_dims, full_dims)):
+        sf = None if scale_factors is None else scale_factors[a]
+        mats.append(linear_upsample_matrix(l, f, sf))
+    return BandTables(mats, device)
+
+
+def gaussian_weights_1d(sigma=1.0):
+    """1-D factor of the normalised 9^d window of adv_morph.py:391-428 (sigma=1 -> 9 taps)."""
+    k = 2 * int(4 * sigma + 0.5) + 1
+    t = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
+    w = np.exp(-t * t / (2.0 * sigma * sigma))
+    return (w / w.sum()).tolist()

@@ -1,0 +1,175 @@
+// Shared device helpers for the advchain HIP kernels (gfx950 / CDNA4, wave64).
+//
+// Conventions used by every kernel in this directory
+//   * tensors are contiguous fp32, channels-first: (N, C, S0, S1, S2); 2D tensors use S0 = 1.
+//   * sampling grids are PLANAR channels-first (N, d, S0, S1, S2) -- the reference keeps them that
+//     way (adv_morph.py:14-55) and only permutes a strided view at the F.grid_sample call site; we
+//     never materialise the channels-last copy.  Grid channel 0 = x <-> S2 (fastest), 1 = y <-> S1,
+//     2 = z <-> S0, exactly F.grid_sample's convention.
+//   * align_corners=True everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace advchain {
+
+enum { INTERP_LINEAR = 0, INTERP_NEAREST = 1 };
+enum { PAD_ZEROS = 0, PAD_BORDER = 1, PAD_REFLECTION = 2 };
+
+constexpr int kBlock = 256;  // 4 waves of 64
+
+struct Dims {
+  int s0, s1, s2;  // s0 == 1 for 2D
+  __host__ __device__ int64_t voxels() const { return (int64_t)s0 * s1 * s2; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// torch.linspace(-1, 1, S)[i]  (ATen RangeFactories: symmetric two-sided formula).  The identity
+// sampling grid of adv_morph.py:14-55 and F.affine_grid's base grid are both built from it; we
+// evaluate it in registers instead of reading a materialised (N,d,...) base grid from HBM.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lin_coord(int i, int S) {
+  if (S <= 1) return S == 1 ? -1.f : 0.f;
+  const float step = 2.f / (float)(S - 1);
+  return (i < S / 2) ? (-1.f + step * (float)i) : (1.f - step * (float)(S - 1 - i));
+}
+// F.affine_grid's base grid differs only for S == 1 (it uses 0 there)
+__device__ __forceinline__ float affine_base_coord(int i, int S) {
+  if (S <= 1) return 0.f;
+  return lin_coord(i, S);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One axis of a (bi/tri)linear tap: ATen GridSampler.h:26-203 semantics.
+// ---------------------------------------------------------------------------------------------
+struct AxisTap {
+  int i0;       // lower corner index (may be out of range for zeros padding)
+  float w0;     // weight of corner i0      = (i0 + 1) - x
+  float w1;     // weight of corner i0 + 1  = x - i0
+  float mult;   // d(unnormalised, padded coordinate) / d(normalised grid value)
+  bool v0, v1;  // corner inside [0, S)
+};
+
+__device__ __forceinline__ float reflect_coord(float x, int twice_low, int twice_high, float& g) {
+  if (twice_low == twice_high) { g = 0.f; return 0.f; }
+  const float mn = (float)twice_low * 0.5f;
+  const float span = (float)(twice_high - twice_low) * 0.5f;
+  x -= mn;
+  float s = 1.f;
+  if (x < 0.f) { s = -1.f; x = -x; }
+  const float extra = fmodf(x, span);
+  const int flips = (int)floorf(x / span);
+  if ((flips & 1) == 0) { g = s; return extra + mn; }
+  g = -s;
+  return span - extra + mn;
+}
+
+template <int PAD>
+__device__ __forceinline__ float source_index(float coord, int S, float& mult) {
+  float x = ((coord + 1.f) * 0.5f) * (float)(S - 1);  // grid_sampler_unnormalize, align_corners
+  mult = 0.5f * (float)(S - 1);
+  if (PAD == PAD_BORDER) {
+    // clip_coordinates_set_grad: zero gradient AT and beyond the border (inclusive)
+    if (x <= 0.f) { x = 0.f; mult = 0.f; }
+    else if (x >= (float)(S - 1)) { x = (float)(S - 1); mult = 0.f; }
+  } else if (PAD == PAD_REFLECTION) {
+    float g;
+    x = reflect_coord(x, 0, 2 * (S - 1), g);
+    mult *= g;
+    if (x <= 0.f) { x = 0.f; mult = 0.f; }
+    else if (x >= (float)(S - 1)) { x = (float)(S - 1); mult = 0.f; }
+  }
+  return x;
+}
+
+template <int PAD>
+__device__ __forceinline__ AxisTap make_tap(float coord, int S) {
+  AxisTap t;
+  float x = source_index<PAD>(coord, S, t.mult);
+  if (!(x > -1.0e9f && x < 1.0e9f)) x = -16.f;  // NaN / huge: every corner out of range
+  const float f = floorf(x);
+  t.i0 = (int)f;
+  t.w1 = x - f;
+  t.w0 = (f + 1.f) - x;
+  t.v0 = (t.i0 >= 0) && (t.i0 < S);
+  t.v1 = (t.i0 + 1 >= 0) && (t.i0 + 1 < S);
+  return t;
+}
+
+// nearest: nearbyint (round-half-to-even) like ATen
+template <int PAD>
+__device__ __forceinline__ int nearest_index(float coord, int S, bool& valid) {
+  float m;
+  float x = source_index<PAD>(coord, S, m);
+  if (!(x > -1.0e9f && x < 1.0e9f)) x = -16.f;
+  const int i = (int)nearbyintf(x);
+  valid = (i >= 0) && (i < S);
+  return i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum NV values across a 256-thread block.  Result valid in thread 0.  `smem` >= 4*NV floats.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) smem[wave * NV + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += smem[w * NV + k];
+      v[k] = s;
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  // hardware global_atomic_add_f32 (no CAS loop); device memory only
+  unsafeAtomicAdd(p, v);
+}
+
+}  // namespace advchain
+
+// ---------------------------------------------------------------------------------------------
+// host-side helpers shared by the C-ABI translation units
+// ---------------------------------------------------------------------------------------------
+#define ADVCHAIN_OK 0
+#define ADVCHAIN_ERR_ARG (-1)
+#define ADVCHAIN_ERR_UNSUPPORTED (-2)
+#define ADVCHAIN_ERR_LAUNCH (-3)
+
+extern "C" void advchain_set_error_(const char* msg);
+
+#define ADVCHAIN_CHECK_ARG(cond, msg)      \
+  do {                                     \
+    if (!(cond)) {                         \
+      advchain_set_error_(msg);            \
+      return ADVCHAIN_ERR_ARG;             \
+    }                                      \
+  } while (0)
+
+#define ADVCHAIN_LAUNCH_CHECK()                          \
+  do {                                                   \
+    hipError_t e_ = hipGetLastError();                   \
+    if (e_ != hipSuccess) {                              \
+      advchain_set_error_(hipGetErrorString(e_));        \
+      return ADVCHAIN_ERR_LAUNCH;                        \
+    }                                                    \
+  } while (0)
+
+static inline int advchain_blocks(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }

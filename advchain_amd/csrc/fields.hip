@@ -1,0 +1,458 @@
+// Field-construction kernels for gfx950: separable Gaussian, banded tensor-product interpolation
+// (velocity upsample / B-spline bias field) and its adjoint, bias-field apply, per-sample
+// normalised updates, streaming elementwise ops.  All HBM-bound; no MFMA.
+//
+//   advchain_gauss_axis            <- depthwise 9^d Gaussian conv, adv_morph.py:377-452 (separable, Q3)
+//   advchain_tp_interp_fwd         <- F.interpolate(v, size=full, linear, align_corners=False) adv_morph.py:464
+//                                     (+ 'basegrid += dxy' adv_morph.py:111, + ||.|| of adv_morph.py:160)
+//   advchain_band_reduce_axis      <- autograd adjoint of the above / of conv_transpose+crop+Upsample
+//   advchain_bias_field_{fwd,bwd}  <- conv_transpose{2,3}d + crop + Upsample + exp + clip + multiply,
+//                                     adv_bias.py:279-356,186 (closed form of SURVEY Appendix E)
+//   advchain_axpy / advchain_scale <- adv_noise.py:81-84 and gradient scaling
+//   advchain_sumsq_partial / advchain_norm_axpy <- unit_normalize + ascent update,
+//                                     adv_transformation_base.py:151-155, adv_noise.py:56-63 etc.
+#include "common.h"
+
+namespace advchain {
+
+constexpr int kBandMax = 8;
+
+struct BandAxis {
+  const int* start;  // [S]   first coefficient index touched by output o
+  const float* w;    // [S*B] weights
+  const int* lo;     // [g]   adjoint: outputs [lo[k], hi[k]) may touch coefficient k
+  const int* hi;     // [g]
+  int S, g, B;
+};
+struct BandTables { BandAxis a[3]; };
+
+__device__ __forceinline__ void decode3(int v, const Dims& d, int& i0, int& i1, int& i2) {
+  i2 = v % d.s2;
+  const int r = v / d.s2;
+  i1 = r % d.s1;
+  i0 = r / d.s1;
+}
+
+// sum_{a,b,c} coef[s0+a, s1+b, s2+c] * w0[a] * w1[b] * w2[c]
+__device__ __forceinline__ float tp_eval(const float* __restrict__ coef, const BandTables& T, int i0, int i1, int i2) {
+  const BandAxis& A0 = T.a[0];
+  const BandAxis& A1 = T.a[1];
+  const BandAxis& A2 = T.a[2];
+  const int s0 = A0.start[i0], s1 = A1.start[i1], s2 = A2.start[i2];
+  const float* w0 = A0.w + i0 * A0.B;
+  const float* w1 = A1.w + i1 * A1.B;
+  const float* w2 = A2.w + i2 * A2.B;
+  float acc = 0.f;
+  for (int a = 0; a < A0.B; ++a) {
+    float acc1 = 0.f;
+    for (int b = 0; b < A1.B; ++b) {
+      const float* row = coef + ((int64_t)(s0 + a) * A1.g + (s1 + b)) * A2.g + s2;
+      float acc2 = 0.f;
+      for (int c = 0; c < A2.B; ++c) acc2 += row[c] * w2[c];
+      acc1 += acc2 * w1[b];
+    }
+    acc += acc1 * w0[a];
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[plane][v] = (add_identity ? identity_coord(channel) : 0) + scale * tp_eval ; optional sum of
+// tp_eval^2 over the whole launch (for the 3D step-count rule).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTables T, Dims full, int C, int ndim,
+                int add_identity, float scale, float* __restrict__ sumsq) {
+  __shared__ float smem[4];
+  const int plane = blockIdx.y;
+  const int V = (int)full.voxels();
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  float sq[1] = {0.f};
+  if (v < V) {
+    int i0, i1, i2;
+    decode3(v, full, i0, i1, i2);
+    const int64_t G = (int64_t)T.a[0].g * T.a[1].g * T.a[2].g;
+    const float val = tp_eval(coef + (int64_t)plane * G, T, i0, i1, i2);
+    sq[0] = val * val;
+    if (out) {
+      float base = 0.f;
+      if (add_identity) {
+        const int c = plane % C;  // channel 0 = x <-> s2, 1 = y <-> s1, 2 = z <-> s0
+        base = c == 0 ? lin_coord(i2, full.s2) : (c == 1 ? lin_coord(i1, full.s1) : lin_coord(i0, full.s0));
+      }
+      out[(int64_t)plane * V + v] = base + scale * val;
+    }
+  }
+  if (sumsq) {
+    block_sum<1>(sq, smem);
+    if (threadIdx.x == 0) atomic_add_f32(sumsq, sq[0]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint along one axis:  out[o][k][i] = sum_s val(in[o][s][i]) * w[s][k - start[s]]
+//   val = (in - in2) * scale  when in2 != null, else in * scale
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_band_reduce_axis(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int64_t outer,
+                   int inner, BandAxis A, float scale) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total = outer * A.g * inner;
+  if (t >= total) return;
+  const int i = (int)(t % inner);
+  const int64_t r = t / inner;
+  const int k = (int)(r % A.g);
+  const int64_t o = r / A.g;
+  const int lo = A.lo[k], hi = A.hi[k];
+  const float* p = in + (o * A.S) * inner + i;
+  const float* p2 = in2 ? in2 + (o * A.S) * inner + i : nullptr;
+  float acc = 0.f;
+  for (int s = lo; s < hi; ++s) {
+    const int b = k - A.start[s];
+    if (b >= 0 && b < A.B) {
+      float x = p[(int64_t)s * inner];
+      if (p2) x -= p2[(int64_t)s * inner];
+      acc += x * A.w[s * A.B + b];
+    }
+  }
+  out[t] = acc * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias field
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bias_value(float L, int use_log, float eps, float& e, bool& pass) {
+  e = use_log ? expf(L) : 1.f + L;
+  const float b = e - 1.f;
+  pass = (b >= -eps) && (b <= eps);          // torch.clamp: gradient on the closed interval
+  return 1.f + fminf(fmaxf(b, -eps), eps);   // adv_bias.py:352-353
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_bias_fwd(const float* __restrict__ cp, const float* __restrict__ data, float* __restrict__ out,
+           float* __restrict__ field, BandTables T, Dims full, int C, float eps, int use_log, float cp_scale) {
+  const int n = blockIdx.y;
+  const int V = (int)full.voxels();
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  int i0, i1, i2;
+  decode3(v, full, i0, i1, i2);
+  const int64_t G = (int64_t)T.a[0].g * T.a[1].g * T.a[2].g;
+  const float L = cp_scale * tp_eval(cp + (int64_t)n * G, T, i0, i1, i2);
+  float e;
+  bool pass;
+  const float b = bias_value(L, use_log, eps, e, pass);
+  field[(int64_t)n * V + v] = b;
+  if (data) {
+    for (int c = 0; c < C; ++c) {
+      const int64_t o = ((int64_t)n * C + c) * V + v;
+      out[o] = b * data[o];
+    }
+  }
+}
+
+// gL = dLoss/dL (full res, one channel); gdata optional
+__global__ void __launch_bounds__(kBlock)
+k_bias_bwd(const float* __restrict__ cp, const float* __restrict__ data, const float* __restrict__ gout,
+           float* __restrict__ gL, float* __restrict__ gdata, BandTables T, Dims full, int C, float eps, int use_log,
+           float cp_scale) {
+  const int n = blockIdx.y;
+  const int V = (int)full.voxels();
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  int i0, i1, i2;
+  decode3(v, full, i0, i1, i2);
+  const int64_t G = (int64_t)T.a[0].g * T.a[1].g * T.a[2].g;
+  const float L = cp_scale * tp_eval(cp + (int64_t)n * G, T, i0, i1, i2);
+  float e;
+  bool pass;
+  const float b = bias_value(L, use_log, eps, e, pass);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int64_t o = ((int64_t)n * C + c) * V + v;
+    const float go = gout[o];
+    s += go * data[o];
+    if (gdata) gdata[o] = go * b;
+  }
+  if (gL) gL[(int64_t)n * V + v] = pass ? s * (use_log ? e : 1.f) * cp_scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// separable Gaussian, one axis per launch (zero padding), with fused prologue / epilogue
+//   PRE : 0 none | 1 x*scale | 2 border-identity(x) - identity   (x = sampling position, adv_morph.py:473-487)
+//   POST: 0 none | 1 + identity (adv_morph.py:489) | 2 * slope(aux) (adjoint of PRE 2; aux = positions)
+// channel c of plane p = p % C addresses axis (x <-> s2, y <-> s1, z <-> s0).
+// ---------------------------------------------------------------------------------------------
+struct GaussW { float w[9]; };
+
+// value and slope of F.grid_sample(identity_grid, pos, border, align_corners=True) along one axis
+__device__ __forceinline__ float border_identity(float pos, int S, float& slope) {
+  float mult;
+  const float x = source_index<PAD_BORDER>(pos, S, mult);
+  const float f = floorf(x);
+  const int i0 = (int)f;
+  const int i1 = min(i0 + 1, S - 1);
+  const float a = lin_coord(i0, S), b = lin_coord(i1, S);
+  slope = mult * (b - a);
+  return ((f + 1.f) - x) * a + (x - f) * b;
+}
+
+template <int PRE, int POST>
+__global__ void __launch_bounds__(kBlock)
+k_gauss_axis(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, int64_t total,
+             Dims d, int C, int axis, GaussW gw, float scale) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= total) return;
+  const int V = (int)d.voxels();
+  const int plane = (int)(t / V);
+  const int v = (int)(t - (int64_t)plane * V);
+  int idx[3];
+  decode3(v, d, idx[0], idx[1], idx[2]);
+  const int S[3] = {d.s0, d.s1, d.s2};
+  const int stride = axis == 2 ? 1 : (axis == 1 ? d.s2 : d.s1 * d.s2);
+  const int c = plane % C;
+  const int caxis = 2 - c;  // the axis this channel's coordinate runs along
+  const int ia = idx[axis];
+  float acc = 0.f;
+#pragma unroll
+  for (int k = -4; k <= 4; ++k) {
+    const int j = ia + k;
+    if (j >= 0 && j < S[axis]) {
+      float x = in[t + (int64_t)k * stride];
+      if (PRE == 1) x *= scale;
+      if (PRE == 2) {
+        const int ci = (caxis == axis) ? j : idx[caxis];
+        float slope;
+        x = border_identity(x, S[caxis], slope) - lin_coord(ci, S[caxis]);
+      }
+      acc += gw.w[k + 4] * x;
+    }
+  }
+  if (POST == 1) acc += lin_coord(idx[caxis], S[caxis]);
+  if (POST == 2) {
+    float slope;
+    border_identity(aux[t], S[caxis], slope);
+    acc *= slope;
+  }
+  out[t] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming elementwise
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_axpy(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, float a, int64_t n4,
+       int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n4) {
+    const float4 p = reinterpret_cast<const float4*>(y)[i];
+    float4 q = x ? reinterpret_cast<const float4*>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q.x += a * p.x; q.y += a * p.y; q.z += a * p.z; q.w += a * p.w;
+    reinterpret_cast<float4*>(out)[i] = q;
+  }
+  const int64_t j = n4 * 4 + i;  // scalar tail (everything when the buffers are not 16-byte aligned)
+  if (j < n) out[j] = (x ? x[j] : 0.f) + a * y[j];
+}
+
+// partial[n][b] = sum over chunk b of x[n][:]^2
+__global__ void __launch_bounds__(kBlock)
+k_sumsq_partial(const float* __restrict__ x, float* __restrict__ partial, int64_t M, int chunk) {
+  __shared__ float smem[4];
+  const int n = blockIdx.y, b = blockIdx.x;
+  const float* xn = x + (int64_t)n * M;
+  const int64_t lo = (int64_t)b * chunk, hi = min(lo + chunk, M);
+  float s[1] = {0.f};
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) { const float q = xn[i]; s[0] += q * q; }
+  block_sum<1>(s, smem);
+  if (threadIdx.x == 0) partial[(int64_t)n * gridDim.x + b] = s[0];
+}
+
+// out[n][:] = (base ? base[n][:] : 0) + step * x[n][:] / (sqrt(sum partial[n][:]) + 1e-20)
+__global__ void __launch_bounds__(kBlock)
+k_norm_axpy(const float* __restrict__ base, const float* __restrict__ x, const float* __restrict__ partial,
+            int nb, float step, float* __restrict__ out, int64_t M, int chunk) {
+  __shared__ float smem[4];
+  __shared__ float inv_s;
+  const int n = blockIdx.y, b = blockIdx.x;
+  float s[1] = {0.f};
+  for (int i = threadIdx.x; i < nb; i += kBlock) s[0] += partial[(int64_t)n * nb + i];
+  block_sum<1>(s, smem);
+  if (threadIdx.x == 0) inv_s = step / (sqrtf(s[0]) + 1e-20f);
+  __syncthreads();
+  const float inv = inv_s;
+  const int64_t lo = (int64_t)b * chunk, hi = min(lo + chunk, M);
+  const int64_t off = (int64_t)n * M;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+static inline bool fdims_ok(int ndim, const int64_t* s) {
+  if (ndim != 2 && ndim != 3) return false;
+  for (int i = 0; i < ndim; ++i)
+    if (s[i] < 1 || s[i] > (1 << 24)) return false;
+  return true;
+}
+static inline Dims fmake_dims(int ndim, const int64_t* s) {
+  Dims d;
+  if (ndim == 3) { d.s0 = (int)s[0]; d.s1 = (int)s[1]; d.s2 = (int)s[2]; }
+  else { d.s0 = 1; d.s1 = (int)s[0]; d.s2 = (int)s[1]; }
+  return d;
+}
+
+// Band-table buffers (device), built by the host (advchain_amd/bands.py):
+//   itab: for each axis a (3 axes; 2D passes a trivial leading axis):  start[S_a] | lo[g_a] | hi[g_a]
+//   ftab: for each axis a: w[S_a * B_a]
+static bool unpack_tables(const int32_t* itab, const float* ftab, const int64_t* S, const int64_t* g, const int64_t* B,
+                          BandTables& T) {
+  const int32_t* ip = itab;
+  const float* fp = ftab;
+  for (int a = 0; a < 3; ++a) {
+    if (S[a] < 1 || g[a] < 1 || B[a] < 1 || B[a] > kBandMax || B[a] > g[a]) return false;
+    T.a[a].S = (int)S[a]; T.a[a].g = (int)g[a]; T.a[a].B = (int)B[a];
+    T.a[a].start = ip; ip += S[a];
+    T.a[a].lo = ip; ip += g[a];
+    T.a[a].hi = ip; ip += g[a];
+    T.a[a].w = fp; fp += S[a] * B[a];
+  }
+  return true;
+}
+
+extern "C" {
+
+int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
+                           const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
+                           float scale, float* sumsq, void* stream) {
+  ADVCHAIN_CHECK_ARG(coef && itab && ftab && (out || sumsq), "tp_interp_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(planes >= 0 && planes < 65536 && C >= 1, "tp_interp_fwd: bad planes/C");
+  BandTables T;
+  ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "tp_interp_fwd: bad band tables");
+  if (planes == 0) return ADVCHAIN_OK;
+  Dims full{(int)S[0], (int)S[1], (int)S[2]};
+  ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "tp_interp_fwd: volume too large");
+  dim3 grid(advchain_blocks(full.voxels(), kBlock), (unsigned)planes);
+  hipLaunchKernelGGL(k_tp_interp_fwd, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C, ndim,
+                     add_identity, scale, sumsq);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// One adjoint pass along `axis` (0..2 of the padded 3-axis view).  in: (outer, S_axis, inner) -> out: (outer, g_axis, inner)
+int advchain_band_reduce_axis(const float* in, const float* in2, float* out, const int32_t* itab, const float* ftab,
+                              const int64_t* S, const int64_t* g, const int64_t* B, int axis, int64_t outer,
+                              int64_t inner, float scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && itab && ftab, "band_reduce_axis: null pointer");
+  ADVCHAIN_CHECK_ARG(axis >= 0 && axis < 3 && outer >= 0 && inner >= 1 && inner < (1ll << 31), "band_reduce_axis: bad axis/outer/inner");
+  BandTables T;
+  ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "band_reduce_axis: bad band tables");
+  const int64_t total = outer * T.a[axis].g * inner;
+  if (total == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_band_reduce_axis, dim3(advchain_blocks(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, in,
+                     in2, out, outer, (int)inner, T.a[axis], scale);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_bias_field_fwd(const float* cp, const float* data, float* out, float* field, const int32_t* itab,
+                            const float* ftab, const int64_t* S, const int64_t* g, const int64_t* B, int64_t N,
+                            int64_t C, float eps, int use_log, float cp_scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(cp && field && itab && ftab && (!data || out), "bias_field_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "bias_field_fwd: bad N/C");
+  BandTables T;
+  ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "bias_field_fwd: bad band tables");
+  if (N == 0) return ADVCHAIN_OK;
+  Dims full{(int)S[0], (int)S[1], (int)S[2]};
+  ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "bias_field_fwd: volume too large");
+  dim3 grid(advchain_blocks(full.voxels(), kBlock), (unsigned)N);
+  hipLaunchKernelGGL(k_bias_fwd, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, out, field, T, full, (int)C, eps,
+                     use_log, cp_scale);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_bias_field_bwd(const float* cp, const float* data, const float* grad_out, float* grad_L, float* grad_data,
+                            const int32_t* itab, const float* ftab, const int64_t* S, const int64_t* g,
+                            const int64_t* B, int64_t N, int64_t C, float eps, int use_log, float cp_scale,
+                            void* stream) {
+  ADVCHAIN_CHECK_ARG(cp && data && grad_out && itab && ftab && (grad_L || grad_data), "bias_field_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "bias_field_bwd: bad N/C");
+  BandTables T;
+  ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "bias_field_bwd: bad band tables");
+  if (N == 0) return ADVCHAIN_OK;
+  Dims full{(int)S[0], (int)S[1], (int)S[2]};
+  ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "bias_field_bwd: volume too large");
+  dim3 grid(advchain_blocks(full.voxels(), kBlock), (unsigned)N);
+  hipLaunchKernelGGL(k_bias_bwd, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, grad_out, grad_L, grad_data, T,
+                     full, (int)C, eps, use_log, cp_scale);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// weights: 9 taps (sigma = 1 -> radius 4).  axis is 0..2 of the (s0,s1,s2) view (2D: s0 == 1).
+int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim,
+                        const int64_t* dims, int axis, const float* weights9, int pre, int post, float scale,
+                        void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && in != out && weights9, "gauss_axis: null/aliased pointer");
+  ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_axis: bad dims");
+  ADVCHAIN_CHECK_ARG(axis >= 0 && axis < 3 && C >= 1 && C <= 3, "gauss_axis: bad axis/C");
+  ADVCHAIN_CHECK_ARG(pre >= 0 && pre <= 2 && post >= 0 && post <= 2 && (post != 2 || aux), "gauss_axis: bad pre/post");
+  const Dims d = fmake_dims(ndim, dims);
+  const int64_t total = planes * d.voxels();
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "gauss_axis: volume too large");
+  if (total == 0) return ADVCHAIN_OK;
+  GaussW gw;
+  for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
+  dim3 grid(advchain_blocks(total, kBlock)), blk(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define GA(PRE, POST) hipLaunchKernelGGL((k_gauss_axis<PRE, POST>), grid, blk, 0, st, in, out, aux, total, d, (int)C, axis, gw, scale)
+  switch (pre * 3 + post) {
+    case 0: GA(0, 0); break;
+    case 1: GA(0, 1); break;
+    case 2: GA(0, 2); break;
+    case 3: GA(1, 0); break;
+    case 4: GA(1, 1); break;
+    case 5: GA(1, 2); break;
+    case 6: GA(2, 0); break;
+    case 7: GA(2, 1); break;
+    default: GA(2, 2); break;
+  }
+#undef GA
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// out = (x ? x : 0) + a * y
+int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n, void* stream) {
+  ADVCHAIN_CHECK_ARG(y && out && n >= 0, "axpy: null pointer");
+  if (n == 0) return ADVCHAIN_OK;
+  const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  const int64_t n4 = al ? n / 4 : 0;
+  const int64_t threads = n4 > (n - 4 * n4) ? n4 : (n - 4 * n4);
+  hipLaunchKernelGGL(k_axpy, dim3(advchain_blocks(threads, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, y, out, a, n4, n);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int64_t advchain_norm_workspace(int64_t N, int64_t M) {
+  const int64_t chunk = 16384;
+  return N * ((M + chunk - 1) / chunk);  // floats
+}
+
+// out[n] = (base ? base[n] : 0) + step * x[n] / (||x[n]||_2 + 1e-20)       x: (N, M)
+int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
+                       int64_t M, void* stream) {
+  ADVCHAIN_CHECK_ARG(x && out && workspace, "norm_axpy: null pointer");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && M >= 0, "norm_axpy: bad N/M");
+  if (N == 0 || M == 0) return ADVCHAIN_OK;
+  const int chunk = 16384;
+  const int nb = (int)((M + chunk - 1) / chunk);
+  dim3 grid(nb, (unsigned)N), blk(kBlock);
+  hipLaunchKernelGGL(k_sumsq_partial, grid, blk, 0, (hipStream_t)stream, x, workspace, M, chunk);
+  hipLaunchKernelGGL(k_norm_axpy, grid, blk, 0, (hipStream_t)stream, base, x, workspace, nb, step, out, M, chunk);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Fused segmentation-consistency loss ('mse' + 'contour' terms) for gfx950.
+//
+//   advchain_consistency_fwd/bwd <- calc_segmentation_consistency + contour_loss,
+//                                   advchain/common/loss.py:8-87,102-220 (Q13, Q14)
+//
+// forward : P = softmax(pred), T = softmax(ref) (or ref itself when it is already a probability
+//           map), D = P - T;   sums[0] = sum_k ((P_k m_k) - (T_k m_k))^2
+//           edge stencils A, B on D (classes 1..K-1), masked by m_0:
+//             2D: A = Sobel-x, B = Sobel-y;  3D (Q14): A = h (x) hp (x) h  (used for BOTH conv_x and
+//             conv_y in the reference), B = h (x) h (x) hp;  sums[1] = sum (A*D m)^2, sums[2] = sum (B*D m)^2
+//           R = 2 m^2 (A*D), 2 m^2 (B*D)   (kept for the backward)
+// backward: grad_pred = softmax'(P) [ gs * ( c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B ) ]
+// The caller owns the normalisers (global N under batch sharding).
+// Streaming + 3^d stencil: HBM-bound, no MFMA.
+#include "common.h"
+
+namespace advchain {
+
+constexpr int kMaxK = 16;
+
+__device__ __forceinline__ float hsm(int i) { return i == 1 ? 2.f : 1.f; }        // [1, 2, 1]
+__device__ __forceinline__ float hdf(int i) { return i == 0 ? 1.f : (i == 1 ? 0.f : -1.f); }  // [1, 0, -1]
+
+// stencil weights at tap (a0,a1,a2) in {0,1,2}^3 (a0 unused in 2D)
+template <int DIM>
+__device__ __forceinline__ void stencil_w(int a0, int a1, int a2, float& wa, float& wb) {
+  if (DIM == 2) {
+    // conv2d cross-correlation, kernel[a1][a2]: Sobel-x = h[a1]*hp[a2], Sobel-y = hp[a1]*h[a2]
+    wa = hsm(a1) * hdf(a2);
+    wb = hdf(a1) * hsm(a2);
+  } else {
+    wa = hsm(a0) * hdf(a1) * hsm(a2);
+    wb = hsm(a0) * hsm(a1) * hdf(a2);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
+               float* __restrict__ P, float* __restrict__ D, float* __restrict__ sums, int K, int V, int mask_ch,
+               int ref_is_prob) {
+  __shared__ float smem[4];
+  const int n = blockIdx.y;
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  float acc[1] = {0.f};
+  if (v < V) {
+    const float* pn = pred + (int64_t)n * K * V + v;
+    const float* rn = ref + (int64_t)n * K * V + v;
+    float mp = -INFINITY, mr = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      mp = fmaxf(mp, pn[(int64_t)k * V]);
+      mr = fmaxf(mr, rn[(int64_t)k * V]);
+    }
+    float sp = 0.f, sr = 0.f;
+    for (int k = 0; k < K; ++k) {
+      sp += expf(pn[(int64_t)k * V] - mp);
+      sr += expf(rn[(int64_t)k * V] - mr);
+    }
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(pn[(int64_t)k * V] - mp) / sp;
+      const float t = ref_is_prob ? rn[(int64_t)k * V] : expf(rn[(int64_t)k * V] - mr) / sr;
+      const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
+      const int64_t o = ((int64_t)n * K + k) * V + v;
+      P[o] = p;
+      D[o] = p - t;
+      const float e = p * m - t * m;
+      acc[0] += e * e;
+    }
+  }
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) atomic_add_f32(sums, acc[0]);
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(kBlock)
+k_edge_fwd(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ R,
+           float* __restrict__ sums, int K, Dims d, int mask_ch) {
+  __shared__ float smem[8];
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  float acc[2] = {0.f, 0.f};
+  if (v < V) {
+    const int i2 = v % d.s2;
+    const int r = v / d.s2;
+    const int i1 = r % d.s1;
+    const int i0 = r / d.s1;
+    const float m = mask ? mask[(int64_t)n * mask_ch * V + v] : 1.f;
+    for (int k = 1; k < K; ++k) {
+      const float* Dk = D + ((int64_t)n * K + k) * V;
+      float ga = 0.f, gb = 0.f;
+#pragma unroll
+      for (int a0 = (DIM == 3 ? 0 : 1); a0 < (DIM == 3 ? 3 : 2); ++a0)
+#pragma unroll
+        for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+          for (int a2 = 0; a2 < 3; ++a2) {
+            const int j0 = i0 + a0 - 1, j1 = i1 + a1 - 1, j2 = i2 + a2 - 1;
+            if (j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2) {
+              float wa, wb;
+              stencil_w<DIM>(a0, a1, a2, wa, wb);
+              const float x = Dk[(j0 * d.s1 + j1) * d.s2 + j2];
+              ga += wa * x;
+              gb += wb * x;
+            }
+          }
+      const float ea = ga * m, eb = gb * m;
+      acc[0] += ea * ea;
+      acc[1] += eb * eb;
+      if (R) {
+        R[((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v] = 2.f * m * m * ga;
+        R[((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v] = 2.f * m * m * gb;
+      }
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + 1, acc[0]);
+    atomic_add_f32(sums + 2, acc[1]);
+  }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(kBlock)
+k_consistency_bwd(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
+                  const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
+                  float c_mse, float c_a, float c_b, int K, Dims d, int mask_ch) {
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  const int v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const int i2 = v % d.s2;
+  const int r = v / d.s2;
+  const int i1 = r % d.s1;
+  const int i0 = r / d.s1;
+  const float gs = gscale ? gscale[0] : 1.f;
+  float gp[kMaxK];
+  float dot = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t o = ((int64_t)n * K + k) * V + v;
+    const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
+    float g = c_mse * 2.f * m * m * D[o];
+    if (k >= 1 && R) {
+      const float* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
+      const float* Rb = Ra + V;
+      float s = 0.f;
+#pragma unroll
+      for (int a0 = (DIM == 3 ? 0 : 1); a0 < (DIM == 3 ? 3 : 2); ++a0)
+#pragma unroll
+        for (int a1 = 0; a1 < 3; ++a1)
+#pragma unroll
+          for (int a2 = 0; a2 < 3; ++a2) {
+            // adjoint: contribution of output voxel u - delta, delta = a - 1
+            const int j0 = i0 - (a0 - 1), j1 = i1 - (a1 - 1), j2 = i2 - (a2 - 1);
+            if (j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2) {
+              float wa, wb;
+              stencil_w<DIM>(a0, a1, a2, wa, wb);
+              const int q = (j0 * d.s1 + j1) * d.s2 + j2;
+              s += c_a * wa * Ra[q] + c_b * wb * Rb[q];
+            }
+          }
+      g += s;
+    }
+    g *= gs;
+    gp[k] = g;
+    dot += g * P[o];
+  }
+  for (int k = 0; k < K; ++k) {
+    const int64_t o = ((int64_t)n * K + k) * V + v;
+    gpred[o] = P[o] * (gp[k] - dot);
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+static inline bool ldims_ok(int ndim, const int64_t* s) {
+  if (ndim != 2 && ndim != 3) return false;
+  for (int i = 0; i < ndim; ++i)
+    if (s[i] < 1 || s[i] > (1 << 24)) return false;
+  return true;
+}
+static inline Dims lmake_dims(int ndim, const int64_t* s) {
+  Dims d;
+  if (ndim == 3) { d.s0 = (int)s[0]; d.s1 = (int)s[1]; d.s2 = (int)s[2]; }
+  else { d.s0 = 1; d.s1 = (int)s[0]; d.s2 = (int)s[1]; }
+  return d;
+}
+
+extern "C" {
+
+int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
+                             float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                             int ref_is_prob, int want_edges, void* stream) {
+  ADVCHAIN_CHECK_ARG(pred && ref && P && D && sums, "consistency_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_fwd: bad N/K (K <= 16)");
+  ADVCHAIN_CHECK_ARG(!mask || mask_channels == 1 || mask_channels == K, "consistency_fwd: mask must have 1 or K channels");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = lmake_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "consistency_fwd: volume too large");
+  const int V = (int)d.voxels();
+  dim3 g(advchain_blocks(V, kBlock), (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_softmax_diff, g, b, 0, st, pred, ref, mask, P, D, sums, (int)K, V, mask_channels, ref_is_prob);
+  if (want_edges && K > 1) {
+    if (ndim == 3) hipLaunchKernelGGL(k_edge_fwd<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
+    else hipLaunchKernelGGL(k_edge_fwd<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
+  }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_consistency_bwd(const float* P, const float* D, const float* R, const float* mask,
+                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
+                             int64_t K, int ndim, const int64_t* dims, int mask_channels, void* stream) {
+  ADVCHAIN_CHECK_ARG(P && D && grad_pred, "consistency_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_bwd: bad N/K (K <= 16)");
+  ADVCHAIN_CHECK_ARG(!mask || mask_channels == 1 || mask_channels == K, "consistency_bwd: mask must have 1 or K channels");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = lmake_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "consistency_bwd: volume too large");
+  dim3 g(advchain_blocks(d.voxels(), kBlock), (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (ndim == 3) hipLaunchKernelGGL(k_consistency_bwd<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+  else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,700 @@
+// (bi/tri)linear + nearest samplers, forward and backward, for gfx950.
+//
+//   advchain_grid_sample_{fwd,bwd}   <- F.grid_sample(data, grid, mode, padding, align_corners=True)
+//                                       reference adv_morph.py:546-557 (dense-field image / prediction warp)
+//   advchain_compose_self_{fwd,bwd}  <- F.grid_sample(phi, phi^T, 'border', align_corners=True)
+//                                       reference adv_morph.py:179-202 (scaling-and-squaring step, input == grid)
+//   advchain_affine_warp_{fwd,bwd}   <- F.affine_grid + F.grid_sample, reference adv_affine.py:289-314
+//                                       (grid evaluated in registers, never materialised)
+//
+// All are HBM-bound gather/scatter kernels: one thread owns VEC consecutive output voxels along the
+// fastest axis (16-byte loads/stores when VEC == 4), gathers its 2^d corners through L1/L2 (near-
+// identity warps keep them in the same or neighbouring cache lines) and, in backward, scatters with
+// hardware fp32 atomics.  No MFMA: there is no contraction here.
+#include "common.h"
+
+namespace advchain {
+
+template <int DIM, int PAD>
+struct Taps {
+  AxisTap x, y, z;
+  __device__ __forceinline__ void build(float gx, float gy, float gz, const Dims& d) {
+    x = make_tap<PAD>(gx, d.s2);
+    y = make_tap<PAD>(gy, d.s1);
+    if (DIM == 3) z = make_tap<PAD>(gz, d.s0);
+    else { z.i0 = 0; z.w0 = 1.f; z.w1 = 0.f; z.mult = 0.f; z.v0 = true; z.v1 = false; }
+  }
+  __device__ __forceinline__ bool ok(int cz, int cy, int cx) const {
+    return (cx ? x.v1 : x.v0) && (cy ? y.v1 : y.v0) && (DIM == 3 ? (cz ? z.v1 : z.v0) : true);
+  }
+  __device__ __forceinline__ int off(int cz, int cy, int cx, const Dims& d) const {
+    return ((z.i0 + cz) * d.s1 + (y.i0 + cy)) * d.s2 + (x.i0 + cx);
+  }
+  __device__ __forceinline__ float wx(int c) const { return c ? x.w1 : x.w0; }
+  __device__ __forceinline__ float wy(int c) const { return c ? y.w1 : y.w0; }
+  __device__ __forceinline__ float wz(int c) const { return c ? z.w1 : z.w0; }
+  __device__ __forceinline__ float w(int cz, int cy, int cx) const {
+    float r = wx(cx) * wy(cy);
+    if (DIM == 3) r *= wz(cz);
+    return r;
+  }
+};
+
+template <int DIM, int PAD>
+__device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
+  float acc = 0.f;
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        if (t.ok(cz, cy, cx)) acc += in[t.off(cz, cy, cx, d)] * t.w(cz, cy, cx);
+      }
+  return acc;
+}
+
+// scatter go*w into gin and accumulate d(out)/d(unnormalised coordinate) * go into (ax, ay, az)
+template <int DIM, int PAD, bool NEED_GIN, bool NEED_GGRID>
+__device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, float* __restrict__ gin, float go,
+                                                  const Taps<DIM, PAD>& t, const Dims& d, float& ax, float& ay,
+                                                  float& az) {
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        if (t.ok(cz, cy, cx)) {
+          const int o = t.off(cz, cy, cx, d);
+          if (NEED_GIN) atomic_add_f32(gin + o, t.w(cz, cy, cx) * go);
+          if (NEED_GGRID) {
+            const float val = in[o];
+            if (DIM == 3) {
+              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
+              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
+              az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
+            } else {
+              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
+              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
+            }
+          }
+        }
+      }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r[k] = p[k];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] = r[k];
+  }
+}
+
+__device__ __forceinline__ float clamp_unit(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+// =============================================================================================
+// generic grid_sample with a planar grid
+// =============================================================================================
+template <int DIM, int INTERP, int PAD, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out, int C,
+                  Dims id, Dims od, int clamp_grid) {
+  const int64_t IV = id.voxels(), OV = od.voxels();
+  const int n = blockIdx.y;
+  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (v >= OV) return;
+  const float* g = grid + (int64_t)n * DIM * OV + v;
+  float gx[VEC], gy[VEC], gz[VEC];
+  load_vec<VEC>(g, gx);
+  load_vec<VEC>(g + OV, gy);
+  if (DIM == 3) load_vec<VEC>(g + 2 * OV, gz);
+  const float* inn = in + (int64_t)n * C * IV;
+  float* outn = out + (int64_t)n * C * OV + v;
+  if (INTERP == INTERP_LINEAR) {
+    Taps<DIM, PAD> t[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (clamp_grid) { gx[k] = clamp_unit(gx[k]); gy[k] = clamp_unit(gy[k]); if (DIM == 3) gz[k] = clamp_unit(gz[k]); }
+      t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, id);
+    }
+    for (int c = 0; c < C; ++c) {
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD>(inn + (int64_t)c * IV, t[k], id);
+      store_vec<VEC>(outn + (int64_t)c * OV, r);
+    }
+  } else {
+    int off[VEC];
+    bool ok[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (clamp_grid) { gx[k] = clamp_unit(gx[k]); gy[k] = clamp_unit(gy[k]); if (DIM == 3) gz[k] = clamp_unit(gz[k]); }
+      bool vx, vy, vz = true;
+      const int ix = nearest_index<PAD>(gx[k], id.s2, vx);
+      const int iy = nearest_index<PAD>(gy[k], id.s1, vy);
+      const int iz = DIM == 3 ? nearest_index<PAD>(gz[k], id.s0, vz) : 0;
+      ok[k] = vx && vy && vz;
+      off[k] = (iz * id.s1 + iy) * id.s2 + ix;
+    }
+    for (int c = 0; c < C; ++c) {
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r[k] = ok[k] ? inn[(int64_t)c * IV + off[k]] : 0.f;
+      store_vec<VEC>(outn + (int64_t)c * OV, r);
+    }
+  }
+}
+
+template <int DIM, int INTERP, int PAD, int VEC, bool NEED_GIN, bool NEED_GGRID>
+__global__ void __launch_bounds__(kBlock)
+k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                  float* __restrict__ gin, float* __restrict__ ggrid, int C, Dims id, Dims od, int clamp_grid) {
+  const int64_t IV = id.voxels(), OV = od.voxels();
+  const int n = blockIdx.y;
+  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (v >= OV) return;
+  const float* g = grid + (int64_t)n * DIM * OV + v;
+  float gx[VEC], gy[VEC], gz[VEC];
+  load_vec<VEC>(g, gx);
+  load_vec<VEC>(g + OV, gy);
+  if (DIM == 3) load_vec<VEC>(g + 2 * OV, gz);
+  const float* inn = in + (int64_t)n * C * IV;
+  float* ginn = NEED_GIN ? gin + (int64_t)n * C * IV : nullptr;
+  const float* gon = gout + (int64_t)n * C * OV + v;
+  if (INTERP == INTERP_LINEAR) {
+    Taps<DIM, PAD> t[VEC];
+    float ax[VEC], ay[VEC], az[VEC];
+    bool pass_x[VEC], pass_y[VEC], pass_z[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      pass_x[k] = pass_y[k] = pass_z[k] = true;
+      if (clamp_grid) {  // torch.clamp passes gradient on the closed interval [-1, 1]
+        pass_x[k] = (gx[k] >= -1.f) && (gx[k] <= 1.f);
+        pass_y[k] = (gy[k] >= -1.f) && (gy[k] <= 1.f);
+        gx[k] = clamp_unit(gx[k]); gy[k] = clamp_unit(gy[k]);
+        if (DIM == 3) { pass_z[k] = (gz[k] >= -1.f) && (gz[k] <= 1.f); gz[k] = clamp_unit(gz[k]); }
+      }
+      t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, id);
+      ax[k] = ay[k] = az[k] = 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+      float go[VEC];
+      load_vec<VEC>(gon + (int64_t)c * OV, go);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GGRID>(inn + (int64_t)c * IV, NEED_GIN ? ginn + (int64_t)c * IV : nullptr,
+                                                          go[k], t[k], id, ax[k], ay[k], az[k]);
+    }
+    if (NEED_GGRID) {
+      float* gg = ggrid + (int64_t)n * DIM * OV + v;
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r[k] = pass_x[k] ? t[k].x.mult * ax[k] : 0.f;
+      store_vec<VEC>(gg, r);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r[k] = pass_y[k] ? t[k].y.mult * ay[k] : 0.f;
+      store_vec<VEC>(gg + OV, r);
+      if (DIM == 3) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = pass_z[k] ? t[k].z.mult * az[k] : 0.f;
+        store_vec<VEC>(gg + 2 * OV, r);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (clamp_grid) { gx[k] = clamp_unit(gx[k]); gy[k] = clamp_unit(gy[k]); if (DIM == 3) gz[k] = clamp_unit(gz[k]); }
+      bool vx, vy, vz = true;
+      const int ix = nearest_index<PAD>(gx[k], id.s2, vx);
+      const int iy = nearest_index<PAD>(gy[k], id.s1, vy);
+      const int iz = DIM == 3 ? nearest_index<PAD>(gz[k], id.s0, vz) : 0;
+      if (NEED_GIN && vx && vy && vz) {
+        const int off = (iz * id.s1 + iy) * id.s2 + ix;
+        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * IV + off, gon[(int64_t)c * OV + k]);
+      }
+    }
+    if (NEED_GGRID) {  // nearest has zero gradient w.r.t. the grid (ATen does the same)
+      float* gg = ggrid + (int64_t)n * DIM * OV + v;
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) r[k] = 0.f;
+      for (int a = 0; a < DIM; ++a) store_vec<VEC>(gg + (int64_t)a * OV, r);
+    }
+  }
+}
+
+// =============================================================================================
+// self-composition  phi <- phi o phi  (input == grid, DIM channels, border padding)
+//   final_mode: 0  out = sample
+//               1  out = (sample - phi0) + identity   (last squaring: emits the sampling positions
+//                  'integrated_offsets + base_grid' of adv_morph.py:143,176 + 474,483; Q1 aliasing)
+// =============================================================================================
+template <int DIM, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
+                   Dims d, int final_mode) {
+  const int64_t V = d.voxels();
+  const int n = blockIdx.y;
+  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (v >= V) return;
+  const float* pn = phi + (int64_t)n * DIM * V;
+  float gx[VEC], gy[VEC], gz[VEC];
+  load_vec<VEC>(pn + v, gx);
+  load_vec<VEC>(pn + V + v, gy);
+  if (DIM == 3) load_vec<VEC>(pn + 2 * V + v, gz);
+  Taps<DIM, PAD_BORDER> t[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
+  float* on = out + (int64_t)n * DIM * V + v;
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) {
+    float r[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD_BORDER>(pn + (int64_t)c * V, t[k], d);
+    if (final_mode == 1) {
+      float p0[VEC];
+      load_vec<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, p0);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const int64_t vv = v + k;
+        int idx;
+        int S;
+        if (c == 0) { idx = (int)(vv % d.s2); S = d.s2; }
+        else if (c == 1) { idx = (int)((vv / d.s2) % d.s1); S = d.s1; }
+        else { idx = (int)(vv / ((int64_t)d.s2 * d.s1)); S = d.s0; }
+        r[k] = (r[k] - p0[k]) + lin_coord(idx, S);
+      }
+    }
+    store_vec<VEC>(on + (int64_t)c * V, r);
+  }
+}
+
+// gphi must be zero-initialised by the caller (scatter target).
+template <int DIM, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d) {
+  const int64_t V = d.voxels();
+  const int n = blockIdx.y;
+  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  if (v >= V) return;
+  const float* pn = phi + (int64_t)n * DIM * V;
+  float* gpn = gphi + (int64_t)n * DIM * V;
+  const float* gon = gout + (int64_t)n * DIM * V + v;
+  float gx[VEC], gy[VEC], gz[VEC];
+  load_vec<VEC>(pn + v, gx);
+  load_vec<VEC>(pn + V + v, gy);
+  if (DIM == 3) load_vec<VEC>(pn + 2 * V + v, gz);
+  Taps<DIM, PAD_BORDER> t[VEC];
+  float ax[VEC], ay[VEC], az[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
+    ax[k] = ay[k] = az[k] = 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) {
+    float go[VEC];
+    load_vec<VEC>(gon + (int64_t)c * V, go);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      sample_linear_bwd<DIM, PAD_BORDER, true, true>(pn + (int64_t)c * V, gpn + (int64_t)c * V, go[k], t[k], d, ax[k],
+                                                     ay[k], az[k]);
+  }
+  // the coordinate path lands on the same tensor (input == grid)
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    if (t[k].x.mult != 0.f) atomic_add_f32(gpn + v + k, t[k].x.mult * ax[k]);
+    if (t[k].y.mult != 0.f) atomic_add_f32(gpn + V + v + k, t[k].y.mult * ay[k]);
+    if (DIM == 3 && t[k].z.mult != 0.f) atomic_add_f32(gpn + 2 * V + v + k, t[k].z.mult * az[k]);
+  }
+}
+
+// =============================================================================================
+// affine warp: grid = theta_n * (x, y[, z], 1) evaluated in registers
+// =============================================================================================
+template <int DIM>
+struct Theta { float m[DIM][DIM + 1]; };
+
+template <int DIM>
+__device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v, const Dims& d, float& bx, float& by,
+                                                float& bz, float& gx, float& gy, float& gz) {
+  const int ix = (int)(v % d.s2);
+  const int iy = (int)((v / d.s2) % d.s1);
+  bx = affine_base_coord(ix, d.s2);
+  by = affine_base_coord(iy, d.s1);
+  if constexpr (DIM == 3) {
+    const int iz = (int)(v / ((int64_t)d.s2 * d.s1));
+    bz = affine_base_coord(iz, d.s0);
+    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2] * bz + th.m[0][3];
+    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2] * bz + th.m[1][3];
+    gz = th.m[DIM - 1][0] * bx + th.m[DIM - 1][1] * by + th.m[DIM - 1][2] * bz + th.m[DIM - 1][DIM];
+  } else {
+    bz = 0.f; gz = 0.f;
+    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2];
+    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2];
+  }
+}
+
+template <int DIM, int INTERP, int PAD>
+__global__ void __launch_bounds__(kBlock)
+k_affine_warp_fwd(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, int C,
+                  Dims d) {
+  const int64_t V = d.voxels();
+  const int n = blockIdx.y;
+  Theta<DIM> th;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * DIM * (DIM + 1) + r * (DIM + 1) + c];
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  float bx, by, bz, gx, gy, gz;
+  affine_position<DIM>(th, v, d, bx, by, bz, gx, gy, gz);
+  const float* inn = in + (int64_t)n * C * V;
+  float* on = out + (int64_t)n * C * V + v;
+  if (INTERP == INTERP_LINEAR) {
+    Taps<DIM, PAD> t;
+    t.build(gx, gy, gz, d);
+    for (int c = 0; c < C; ++c) on[(int64_t)c * V] = sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
+  } else {
+    bool vx, vy, vz = true;
+    const int ix = nearest_index<PAD>(gx, d.s2, vx);
+    const int iy = nearest_index<PAD>(gy, d.s1, vy);
+    const int iz = DIM == 3 ? nearest_index<PAD>(gz, d.s0, vz) : 0;
+    const bool ok = vx && vy && vz;
+    const int off = (iz * d.s1 + iy) * d.s2 + ix;
+    for (int c = 0; c < C; ++c) on[(int64_t)c * V] = ok ? inn[(int64_t)c * V + off] : 0.f;
+  }
+}
+
+// gtheta_partial: (N, gridDim.x, DIM*(DIM+1)) block partial sums, reduced by k_reduce_partials.
+template <int DIM, int INTERP, int PAD, bool NEED_GIN, bool NEED_GTHETA>
+__global__ void __launch_bounds__(kBlock)
+k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
+                  float* __restrict__ gin, float* __restrict__ gtheta_partial, int C, Dims d) {
+  constexpr int NT = DIM * (DIM + 1);
+  __shared__ float smem[4 * NT];
+  const int64_t V = d.voxels();
+  const int n = blockIdx.y;
+  Theta<DIM> th;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * NT + r * (DIM + 1) + c];
+  const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  float acc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) acc[k] = 0.f;
+  if (v < V) {
+    float bx, by, bz, gx, gy, gz;
+    affine_position<DIM>(th, v, d, bx, by, bz, gx, gy, gz);
+    const float* inn = in + (int64_t)n * C * V;
+    float* ginn = NEED_GIN ? gin + (int64_t)n * C * V : nullptr;
+    const float* gon = gout + (int64_t)n * C * V + v;
+    if (INTERP == INTERP_LINEAR) {
+      Taps<DIM, PAD> t;
+      t.build(gx, gy, gz, d);
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int c = 0; c < C; ++c)
+        sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GTHETA>(inn + (int64_t)c * V, NEED_GIN ? ginn + (int64_t)c * V : nullptr,
+                                                           gon[(int64_t)c * V], t, d, ax, ay, az);
+      if (NEED_GTHETA) {
+        const float ggx = t.x.mult * ax, ggy = t.y.mult * ay, ggz = DIM == 3 ? t.z.mult * az : 0.f;
+        const float base[4] = {bx, by, DIM == 3 ? bz : 1.f, 1.f};
+#pragma unroll
+        for (int c = 0; c < DIM + 1; ++c) {
+          acc[0 * (DIM + 1) + c] = ggx * base[c];
+          acc[1 * (DIM + 1) + c] = ggy * base[c];
+          if constexpr (DIM == 3) acc[2 * (DIM + 1) + c] = ggz * base[c];
+        }
+      }
+    } else if (NEED_GIN) {
+      bool vx, vy, vz = true;
+      const int ix = nearest_index<PAD>(gx, d.s2, vx);
+      const int iy = nearest_index<PAD>(gy, d.s1, vy);
+      const int iz = DIM == 3 ? nearest_index<PAD>(gz, d.s0, vz) : 0;
+      if (vx && vy && vz) {
+        const int off = (iz * d.s1 + iy) * d.s2 + ix;
+        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * V + off, gon[(int64_t)c * V]);
+      }
+    }
+  }
+  if (NEED_GTHETA) {
+    block_sum<NT>(acc, smem);
+    if (threadIdx.x == 0) {
+      float* dst = gtheta_partial + ((int64_t)n * gridDim.x + blockIdx.x) * NT;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) dst[k] = acc[k];
+    }
+  }
+}
+
+// out[row][k] = sum_b partial[row][b][k]      (deterministic second stage)
+__global__ void k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int nb, int K) {
+  const int row = blockIdx.x;
+  const int k = blockIdx.y;
+  __shared__ float smem[4];
+  float s[1] = {0.f};
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s[0] += partial[((int64_t)row * nb + b) * K + k];
+  block_sum<1>(s, smem);
+  if (threadIdx.x == 0) out[(int64_t)row * K + k] = s[0];
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+// ---------------------------------------------------------------------------------------------
+// dispatch helpers
+// ---------------------------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define DISPATCH_PAD(PADV, ...)                                            \
+  switch (PADV) {                                                          \
+    case PAD_ZEROS: { constexpr int PAD = PAD_ZEROS; __VA_ARGS__; } break; \
+    case PAD_BORDER: { constexpr int PAD = PAD_BORDER; __VA_ARGS__; } break; \
+    default: { constexpr int PAD = PAD_REFLECTION; __VA_ARGS__; } break;   \
+  }
+
+template <int DIM>
+static int launch_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, Dims id, Dims od,
+                                  int interp, int padding, int clamp_grid, hipStream_t st) {
+  const int64_t OV = od.voxels();
+  const bool vec4 = (OV % 4 == 0) && aligned16(grid) && aligned16(out);
+  const int vec = vec4 ? 4 : 1;
+  dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
+  DISPATCH_PAD(padding, {
+    if (interp == INTERP_LINEAR) {
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+    } else {
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+    }
+  });
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+template <int DIM, int INTERP, int PAD, int VEC>
+static void launch_gs_bwd_flags(dim3 g, dim3 b, hipStream_t st, const float* gout, const float* in, const float* grid,
+                                float* gin, float* ggrid, int C, Dims id, Dims od, int clamp_grid) {
+  if (gin && ggrid) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, true>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
+  else if (gin) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, false>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
+  else hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, false, true>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
+}
+
+template <int DIM>
+static int launch_grid_sample_bwd(const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                  int64_t N, int64_t C, Dims id, Dims od, int interp, int padding, int clamp_grid,
+                                  hipStream_t st) {
+  const int64_t OV = od.voxels();
+  const bool vec4 = (OV % 4 == 0) && aligned16(grid) && aligned16(gout) && (!ggrid || aligned16(ggrid));
+  const int vec = vec4 ? 4 : 1;
+  dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
+  DISPATCH_PAD(padding, {
+    if (interp == INTERP_LINEAR) {
+      if (vec4) launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+      else launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+    } else {
+      if (vec4) launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+      else launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+    }
+  });
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+static inline bool dims_ok(int ndim, const int64_t* s) {
+  if (ndim != 2 && ndim != 3) return false;
+  for (int i = 0; i < ndim; ++i)
+    if (s[i] < 1 || s[i] > (1 << 24)) return false;
+  return true;
+}
+static inline Dims make_dims(int ndim, const int64_t* s) {
+  Dims d;
+  if (ndim == 3) { d.s0 = (int)s[0]; d.s1 = (int)s[1]; d.s2 = (int)s[2]; }
+  else { d.s0 = 1; d.s1 = (int)s[0]; d.s2 = (int)s[1]; }
+  return d;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+template <int DIM, int INTERP, int PAD>
+static void launch_affine_bwd(dim3 g, dim3 b, hipStream_t st, const float* gout, const float* in, const float* theta,
+                              float* gin, float* gpart, int C, Dims d) {
+  if (gin && gpart) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
+  else if (gin) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, false>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
+  else hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, false, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
+}
+
+extern "C" {
+
+int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
+                             const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
+                             void* stream) {
+  ADVCHAIN_CHECK_ARG(in && grid && out, "grid_sample_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "grid_sample_fwd: bad N/C");
+  ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "grid_sample_fwd: interp must be 0 (linear) or 1 (nearest)");
+  ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "grid_sample_fwd: padding must be 0/1/2");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
+  ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_fwd: per-sample volume too large");
+  return ndim == 3 ? launch_grid_sample_fwd<3>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
+                   : launch_grid_sample_fwd<2>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
+}
+
+int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
+                             float* grad_grid, int64_t N, int64_t C, int ndim, const int64_t* in_dims,
+                             const int64_t* out_dims, int interp, int padding, int clamp_grid, void* stream) {
+  ADVCHAIN_CHECK_ARG(grad_out && in && grid, "grid_sample_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(grad_in || grad_grid, "grid_sample_bwd: nothing to compute");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "grid_sample_bwd: bad N/C");
+  ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "grid_sample_bwd: interp");
+  ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "grid_sample_bwd: padding");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
+  ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_bwd: per-sample volume too large");
+  return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
+                   : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
+}
+
+int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
+                              const int64_t* dims, int final_mode, void* stream) {
+  ADVCHAIN_CHECK_ARG(phi && out && phi != out, "compose_self_fwd: null/aliased pointer");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(final_mode == 0 || (final_mode == 1 && phi0), "compose_self_fwd: final_mode 1 needs phi0");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_fwd: bad N");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = make_dims(ndim, dims);
+  const int64_t V = d.voxels();
+  ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
+  const bool vec4 = (V % 4 == 0) && aligned16(phi) && aligned16(out) && (!phi0 || aligned16(phi0));
+  dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (ndim == 3) {
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<3, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    else hipLaunchKernelGGL((k_compose_self_fwd<3, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
+  } else {
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<2, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    else hipLaunchKernelGGL((k_compose_self_fwd<2, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
+  }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int64_t N, int ndim,
+                              const int64_t* dims, void* stream) {
+  ADVCHAIN_CHECK_ARG(grad_out && phi && grad_phi, "compose_self_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_bwd: bad N");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = make_dims(ndim, dims);
+  const int64_t V = d.voxels();
+  ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
+  const bool vec4 = (V % 4 == 0) && aligned16(phi) && aligned16(grad_out);
+  dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (ndim == 3) {
+    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<3, 4>), g, b, 0, st, grad_out, phi, grad_phi, d);
+    else hipLaunchKernelGGL((k_compose_self_bwd<3, 1>), g, b, 0, st, grad_out, phi, grad_phi, d);
+  } else {
+    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<2, 4>), g, b, 0, st, grad_out, phi, grad_phi, d);
+    else hipLaunchKernelGGL((k_compose_self_bwd<2, 1>), g, b, 0, st, grad_out, phi, grad_phi, d);
+  }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim,
+                             const int64_t* dims, int interp, int padding, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && theta && out, "affine_warp_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "affine_warp_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "affine_warp_fwd: bad N/C");
+  ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "affine_warp_fwd: interp");
+  ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "affine_warp_fwd: padding");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = make_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "affine_warp_fwd: per-sample volume too large");
+  dim3 g(advchain_blocks(d.voxels(), kBlock), (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_PAD(padding, {
+    if (ndim == 3) {
+      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+      else hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+    } else {
+      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+      else hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+    }
+  });
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims) {
+  if (!dims_ok(ndim, dims)) return -1;
+  const Dims d = make_dims(ndim, dims);
+  return N * (int64_t)advchain_blocks(d.voxels(), kBlock) * ndim * (ndim + 1);  // floats
+}
+
+int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
+                             float* grad_theta, float* workspace, int64_t N, int64_t C, int ndim,
+                             const int64_t* dims, int interp, int padding, void* stream) {
+  ADVCHAIN_CHECK_ARG(grad_out && in && theta, "affine_warp_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(grad_in || grad_theta, "affine_warp_bwd: nothing to compute");
+  ADVCHAIN_CHECK_ARG(!grad_theta || workspace, "affine_warp_bwd: grad_theta needs a workspace");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "affine_warp_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "affine_warp_bwd: bad N/C");
+  ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "affine_warp_bwd: interp");
+  ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "affine_warp_bwd: padding");
+  if (N == 0) return ADVCHAIN_OK;
+  const Dims d = make_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "affine_warp_bwd: per-sample volume too large");
+  const int nb = advchain_blocks(d.voxels(), kBlock);
+  dim3 g(nb, (unsigned)N), b(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  float* gpart = grad_theta ? workspace : nullptr;
+  if (interp == INTERP_NEAREST && !grad_in) {
+    // nearest: zero gradient w.r.t. theta
+    (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
+    return ADVCHAIN_OK;
+  }
+  DISPATCH_PAD(padding, {
+    if (ndim == 3) {
+      if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d);
+      else launch_affine_bwd<3, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d);
+    } else {
+      if (interp == INTERP_LINEAR) launch_affine_bwd<2, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d);
+      else launch_affine_bwd<2, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d);
+    }
+  });
+  ADVCHAIN_LAUNCH_CHECK();
+  if (grad_theta) {
+    if (interp == INTERP_NEAREST) {
+      (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
+    } else {
+      const int K = ndim * (ndim + 1);
+      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)N, K), dim3(kBlock), 0, st, gpart, grad_theta, nb, K);
+      ADVCHAIN_LAUNCH_CHECK();
+    }
+  }
+  return ADVCHAIN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+"""Autograd-composable operators backed by the HIP kernels (C ABI via ctypes).
+
+Every operator requires CUDA(ROCm) fp32 tensors and the built ``libadvchain_hip.so``; there is no
+PyTorch / CPU fallback -- a CPU tensor or a missing library raises.  PyTorch is used for device
+memory (``torch.empty``), the current stream and the autograd tape only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .bands import gaussian_weights_1d
+
+_INTERP = {"bilinear": 0, "trilinear": 0, "linear": 0, "nearest": 1}
+_PAD = {"zeros": 0, "border": 1, "reflection": 2}
+_GAUSS9 = _lib.float_array(gaussian_weights_1d(1.0))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.AdvchainHipError("%s must be a CUDA/ROCm tensor: the advchain_amd kernels have no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise _lib.AdvchainHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def interp_code(interp):
+    if interp not in _INTERP:
+        raise NotImplementedError("interpolation mode %r is not implemented by the HIP sampler "
+                                  "(supported: bilinear/trilinear, nearest)" % (interp,))
+    return _INTERP[interp]
+
+
+def pad_code(padding_mode):
+    if padding_mode not in _PAD:
+        raise NotImplementedError("padding_mode %r" % (padding_mode,))
+    return _PAD[padding_mode]
+
+
+# ------------------------------------------------------------------------------------------------
+# raw (non-autograd) wrappers: one C-ABI call each
+# ------------------------------------------------------------------------------------------------
+def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
+    N, C = inp.shape[:2]
+    nd = inp.dim() - 2
+    odims = grid.shape[2:]
+    out = torch.empty((N, C) + tuple(odims), device=inp.device, dtype=torch.float32)
+    _lib.check(_lib.load().advchain_grid_sample_fwd(_ptr(inp), _ptr(grid), _ptr(out), N, C, nd,
+                                                    _lib.dims_array(inp.shape[2:]), _lib.dims_array(odims),
+                                                    interp, padding, int(clamp_grid), _stream()), "grid_sample_fwd")
+    return out
+
+
+def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, need_ggrid):
+    N, C = inp.shape[:2]
+    nd = inp.dim() - 2
+    gin = torch.zeros_like(inp) if need_gin else None
+    ggrid = torch.empty_like(grid) if need_ggrid else None
+    _lib.check(_lib.load().advchain_grid_sample_bwd(_ptr(gout), _ptr(inp), _ptr(grid), _ptr(gin), _ptr(ggrid), N, C, nd,
+                                                    _lib.dims_array(inp.shape[2:]), _lib.dims_array(grid.shape[2:]),
+                                                    interp, padding, int(clamp_grid), _stream()), "grid_sample_bwd")
+    return gin, ggrid
+
+
+def raw_compose_self_fwd(phi, phi0=None, final_mode=0):
+    N = phi.shape[0]
+    nd = phi.dim() - 2
+    out = torch.empty_like(phi)
+    _lib.check(_lib.load().advchain_compose_self_fwd(_ptr(phi), _ptr(out), _ptr(phi0), N, nd,
+                                                     _lib.dims_array(phi.shape[2:]), final_mode, _stream()),
+               "compose_self_fwd")
+    return out
+
+
+def raw_compose_self_bwd(gout, phi):
+    N = phi.shape[0]
+    nd = phi.dim() - 2
+    gphi = torch.zeros_like(phi)
+    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), N, nd,
+                                                     _lib.dims_array(phi.shape[2:]), _stream()), "compose_self_bwd")
+    return gphi
+
+
+def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
+    """Separable 9-tap Gaussian over all spatial axes of x (planes = x.shape[0]*x.shape[1])."""
+    nd = x.dim() - 2
+    planes = x.shape[0] * x.shape[1]
+    dims = _lib.dims_array(x.shape[2:])
+    axes = [2, 1, 0][:nd]  # innermost first (padded 3-axis numbering)
+    lib = _lib.load()
+    cur = x
+    for i, ax in enumerate(axes):
+        out = torch.empty_like(x)
+        p = pre if i == 0 else 0
+        q = post if i == len(axes) - 1 else 0
+        _lib.check(lib.advchain_gauss_axis(_ptr(cur), _ptr(out), _ptr(aux) if q == 2 else None, planes, C, nd, dims, ax,
+                                           _GAUSS9, p, q, float(scale) if p == 1 else 1.0, _stream()), "gauss_axis")
+        cur = out
+    return cur
+
+
+def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True, sumsq=None):
+    planes = coef.shape[0] * coef.shape[1]
+    out = None
+    if want_out:
+        out = torch.empty((coef.shape[0], coef.shape[1]) + tuple(tables.full_dims), device=coef.device,
+                          dtype=torch.float32)
+    _lib.check(_lib.load().advchain_tp_interp_fwd(_ptr(coef), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
+                                                  _lib.dims_array(tables.S), _lib.dims_array(tables.g),
+                                                  _lib.dims_array(tables.B), planes, C, tables.ndim,
+                                                  int(add_identity), float(scale), _ptr(sumsq), _stream()),
+               "tp_interp_fwd")
+    return out
+
+
+def raw_tp_adjoint(gfull, tables, gfull2=None, scale=1.0):
+    """W^T applied along every axis: (N,C,S...) -> (N,C,g...).  First pass may fuse (a - b) * scale."""
+    lib = _lib.load()
+    N, C = gfull.shape[:2]
+    S, g, B = list(tables.S), list(tables.g), list(tables.B)
+    Sa, ga, Ba = _lib.dims_array(S), _lib.dims_array(g), _lib.dims_array(B)
+    cur, cur2 = gfull, gfull2
+    shape = list(S)
+    first = True
+    for ax in (2, 1, 0):
+        if S[ax] == 1 and g[ax] == 1:
+            continue
+        outer = N * C
+        for a in range(ax):
+            outer *= shape[a]
+        inner = 1
+        for a in range(ax + 1, 3):
+            inner *= shape[a]
+        shape[ax] = g[ax]
+        out = torch.empty((N, C) + tuple(shape[3 - tables.ndim:]), device=gfull.device, dtype=torch.float32)
+        _lib.check(lib.advchain_band_reduce_axis(_ptr(cur), _ptr(cur2), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
+                                                 Sa, ga, Ba, ax, outer, inner, float(scale) if first else 1.0,
+                                                 _stream()), "band_reduce_axis")
+        cur, cur2, first = out, None, False
+    if first:  # degenerate: nothing to reduce
+        cur = (gfull - gfull2 if gfull2 is not None else gfull) * scale
+    return cur
+
+
+def raw_axpy(x, y, a):
+    out = torch.empty_like(y)
+    _lib.check(_lib.load().advchain_axpy(_ptr(x), _ptr(y), _ptr(out), float(a), y.numel(), _stream()), "axpy")
+    return out
+
+
+def normalized_axpy(base, x, step=1.0):
+    """base + step * x / (||x||_2 per sample + 1e-20); base may be None.  No autograd (parameter updates)."""
+    x = _dev(x.detach(), "x")
+    base = None if base is None else _dev(base.detach(), "base")
+    N = x.shape[0]
+    M = x.numel() // max(N, 1)
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.advchain_norm_workspace(N, M)), device=x.device, dtype=torch.float32)
+    out = torch.empty_like(x)
+    _lib.check(lib.advchain_norm_axpy(_ptr(base), _ptr(x), _ptr(out), _ptr(ws), float(step), N, M, _stream()),
+               "norm_axpy")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, grid, interp, padding, clamp_grid):
+        inp, grid = _dev(inp, "input"), _dev(grid, "grid")
+        ctx.save_for_backward(inp, grid)
+        ctx.cfg = (interp, padding, clamp_grid)
+        return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid)
+
+    @staticmethod
+    def backward(ctx, gout):
+        inp, grid = ctx.saved_tensors
+        interp, padding, clamp_grid = ctx.cfg
+        need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_in or need_grid):
+            return None, None, None, None, None
+        gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid)
+        return gin, ggrid, None, None, None
+
+
+def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
+    """F.grid_sample(inp, grid^T, mode, padding_mode, align_corners=True) with a PLANAR grid (N,d,...)."""
+    return _GridSample.apply(inp, grid, interp_code(interp), pad_code(padding_mode), bool(clamp_grid))
+
+
+class _AffineWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, theta, interp, padding):
+        inp, theta = _dev(inp, "input"), _dev(theta, "theta")
+        N, C = inp.shape[:2]
+        nd = inp.dim() - 2
+        out = torch.empty_like(inp)
+        _lib.check(_lib.load().advchain_affine_warp_fwd(_ptr(inp), _ptr(theta), _ptr(out), N, C, nd,
+                                                        _lib.dims_array(inp.shape[2:]), interp, padding, _stream()),
+                   "affine_warp_fwd")
+        ctx.save_for_backward(inp, theta)
+        ctx.cfg = (interp, padding)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        inp, theta = ctx.saved_tensors
+        interp, padding = ctx.cfg
+        need_in, need_th = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_in or need_th):
+            return None, None, None, None
+        lib = _lib.load()
+        N, C = inp.shape[:2]
+        nd = inp.dim() - 2
+        dims = _lib.dims_array(inp.shape[2:])
+        gin = torch.zeros_like(inp) if need_in else None
+        gth = torch.empty_like(theta) if need_th else None
+        ws = None
+        if need_th:
+            ws = torch.empty(max(1, lib.advchain_affine_warp_bwd_workspace(N, nd, dims)), device=inp.device,
+                             dtype=torch.float32)
+        _lib.check(lib.advchain_affine_warp_bwd(_ptr(_dev(gout, "grad")), _ptr(inp), _ptr(theta), _ptr(gin), _ptr(gth),
+                                                _ptr(ws), N, C, nd, dims, interp, padding, _stream()), "affine_warp_bwd")
+        return gin, gth, None, None
+
+
+def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
+    """F.grid_sample(inp, F.affine_grid(theta, inp.size(), align_corners=True), ..., align_corners=True)."""
+    return _AffineWarp.apply(inp, theta, interp_code(interp), pad_code(padding_mode))
+
+
+class _AffineTheta(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, param, cfg, param_scale, nd):
+        param = _dev(param, "param")
+        N = param.shape[0]
+        theta = torch.empty((N, nd, nd + 1), device=param.device, dtype=torch.float32)
+        theta_inv = torch.empty_like(theta)
+        cfg_arr = _lib.float_array(cfg)
+        _lib.check(_lib.load().advchain_affine_theta_fwd(_ptr(param), cfg_arr, float(param_scale), _ptr(theta),
+                                                         _ptr(theta_inv), N, nd, _stream()), "affine_theta_fwd")
+        ctx.save_for_backward(param)
+        ctx.cfg = (cfg_arr, float(param_scale), nd)
+        return theta, theta_inv
+
+    @staticmethod
+    def backward(ctx, gtheta, gtheta_inv):
+        (param,) = ctx.saved_tensors
+        cfg_arr, scale, nd = ctx.cfg
+        gparam = torch.empty_like(param)
+        gtheta = None if gtheta is None else _dev(gtheta, "grad_theta")
+        gtheta_inv = None if gtheta_inv is None else _dev(gtheta_inv, "grad_theta_inv")
+        _lib.check(_lib.load().advchain_affine_theta_bwd(_ptr(param), cfg_arr, scale, _ptr(gtheta), _ptr(gtheta_inv),
+                                                         _ptr(gparam), param.shape[0], nd, _stream()),
+                   "affine_theta_bwd")
+        return gparam, None, None, None
+
+
+def affine_theta(param, cfg, param_scale, nd):
+    """(N,5|9) bounded parameters -> (theta, theta^-1), each (N, nd, nd+1)."""
+    return _AffineTheta.apply(param, tuple(float(c) for c in cfg), float(param_scale), int(nd))
+
+
+class _Axpy(torch.autograd.Function):
+    """out = x + a * y  (AdvNoise.forward, adv_noise.py:81-84)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a):
+        ctx.a = a
+        return raw_axpy(_dev(x, "x"), _dev(y, "y"), a)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        gx = g if ctx.needs_input_grad[0] else None
+        gy = raw_axpy(None, g, ctx.a) if ctx.needs_input_grad[1] else None
+        return gx, gy, None
+
+
+def axpy(x, y, a):
+    return _Axpy.apply(x, y, float(a))
+
+
+class _BiasApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cp, data, tables, eps, use_log, cp_scale):
+        cp, data = _dev(cp, "control points"), _dev(data, "data")
+        N, C = data.shape[:2]
+        out = torch.empty_like(data)
+        field = torch.empty((N, 1) + tuple(data.shape[2:]), device=data.device, dtype=torch.float32)
+        _lib.check(_lib.load().advchain_bias_field_fwd(_ptr(cp), _ptr(data), _ptr(out), _ptr(field), _ptr(tables.itab),
+                                                       _ptr(tables.ftab), _lib.dims_array(tables.S),
+                                                       _lib.dims_array(tables.g), _lib.dims_array(tables.B), N, C,
+                                                       float(eps), int(use_log), float(cp_scale), _stream()),
+                   "bias_field_fwd")
+        ctx.save_for_backward(cp, data)
+        ctx.cfg = (tables, float(eps), int(use_log), float(cp_scale))
+        ctx.mark_non_differentiable(field)
+        return out, field
+
+    @staticmethod
+    def backward(ctx, gout, _gfield):
+        cp, data = ctx.saved_tensors
+        tables, eps, use_log, cp_scale = ctx.cfg
+        need_cp, need_data = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_cp or need_data):
+            return None, None, None, None, None, None
+        N, C = data.shape[:2]
+        gL = torch.empty((N, 1) + tuple(data.shape[2:]), device=data.device, dtype=torch.float32) if need_cp else None
+        gdata = torch.empty_like(data) if need_data else None
+        _lib.check(_lib.load().advchain_bias_field_bwd(_ptr(cp), _ptr(data), _ptr(_dev(gout, "grad")), _ptr(gL),
+                                                       _ptr(gdata), _ptr(tables.itab), _ptr(tables.ftab),
+                                                       _lib.dims_array(tables.S), _lib.dims_array(tables.g),
+                                                       _lib.dims_array(tables.B), N, C, eps, use_log, cp_scale,
+                                                       _stream()), "bias_field_bwd")
+        gcp = raw_tp_adjoint(gL, tables).reshape(cp.shape) if need_cp else None
+        return gcp, gdata, None, None, None, None
+
+
+def bias_apply(cp, data, tables, eps, use_log=True, cp_scale=1.0):
+    """(data * clipped_bias_field(cp), clipped_bias_field)."""
+    return _BiasApply.apply(cp, data, tables, eps, use_log, cp_scale)
+
+
+def bias_field_only(cp, tables, eps, use_log=True, cp_scale=1.0):
+    cp = _dev(cp.detach(), "control points")
+    N = cp.shape[0]
+    field = torch.empty((N, 1) + tuple(tables.full_dims), device=cp.device, dtype=torch.float32)
+    _lib.check(_lib.load().advchain_bias_field_fwd(_ptr(cp), None, None, _ptr(field), _ptr(tables.itab),
+                                                   _ptr(tables.ftab), _lib.dims_array(tables.S),
+                                                   _lib.dims_array(tables.g), _lib.dims_array(tables.B), N, 1,
+                                                   float(eps), int(use_log), float(cp_scale), _stream()),
+               "bias_field_fwd")
+    return field
+
+
+class _DemonsField(torch.autograd.Function):
+    """Low-res velocity -> un-clamped sampling grid (DemonsCompose, adv_morph.py:454-491).
+
+    forward:  gauss(scale*v) -> linear upsample -> phi0 = id + u/2^n -> n x (phi <- phi o phi)
+              -> pos = (phi_n - phi0) + id -> gauss(border_identity(pos) - id) + id
+    The final clamp(-1,1) (adv_morph.py:490, 304-305) is applied by the sampler on load.
+    backward: the hand-written adjoint of the same chain (saved: phi_0..phi_{n-1}, pos)."""
+
+    @staticmethod
+    def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq):
+        vel = _dev(vel, "velocity")
+        N, d = vel.shape[:2]
+        s1 = raw_gauss(vel, d, pre=1, scale=scale)
+        n = 8
+        if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
+            ss = torch.zeros(1, device=vel.device, dtype=torch.float32)
+            raw_tp_interp(s1, tables, d, want_out=False, sumsq=ss)
+            if reduce_sumsq is not None:
+                ss = reduce_sumsq(ss)
+            norm = float(ss.sqrt().item())
+            while norm / (2.0 ** n) > 0.5:
+                n += 1
+        inv = 1.0 / (2.0 ** n)
+        phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv)]
+        for i in range(n - 1):
+            phis.append(raw_compose_self_fwd(phis[-1]))
+        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1)
+        q = raw_gauss(pos, d, pre=2, post=1)
+        ctx.save_for_backward(pos, *phis)
+        ctx.cfg = (scale, tables, inv, d)
+        ctx.nsteps = n
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        pos = ctx.saved_tensors[0]
+        phis = ctx.saved_tensors[1:]
+        scale, tables, inv, d = ctx.cfg
+        gq = _dev(gq, "grad")
+        gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
+        g = gpos                                          # d/d phi_n
+        for phi in reversed(phis):
+            g = raw_compose_self_bwd(g, phi)
+        # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
+        gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
+        gvel = raw_gauss(gs1, d, pre=1, scale=scale)
+        return gvel, None, None, None, None
+
+
+def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+    return _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq)
+
+
+class _Consistency(torch.autograd.Function):
+    """c_mse * S0 + c_a * SA + c_b * SB  with  S0 = sum((P m - T m)^2), SA/SB = masked edge energies
+    (advchain/common/loss.py:55-79,102-220).  Differentiable w.r.t. the prediction logits only."""
+
+    @staticmethod
+    def forward(ctx, pred, ref, mask, coef, ref_is_prob, want_edges):
+        pred, ref = _dev(pred, "pred"), _dev(ref, "reference")
+        mask = None if mask is None else _dev(mask, "mask")
+        N, K = pred.shape[:2]
+        nd = pred.dim() - 2
+        dims = _lib.dims_array(pred.shape[2:])
+        mch = 1 if mask is None else mask.shape[1]
+        P = torch.empty_like(pred)
+        D = torch.empty_like(pred)
+        need_grad = ctx.needs_input_grad[0]
+        R = None
+        if need_grad and want_edges and K > 1:
+            R = torch.empty((N, 2 * (K - 1)) + tuple(pred.shape[2:]), device=pred.device, dtype=torch.float32)
+        sums = torch.zeros(3, device=pred.device, dtype=torch.float32)
+        _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
+                                                        _ptr(sums), N, K, nd, dims, mch, int(ref_is_prob),
+                                                        int(want_edges), _stream()), "consistency_fwd")
+        if need_grad:
+            ctx.save_for_backward(P, D, R, mask)
+        ctx.cfg = (coef, mch)
+        ctx.mark_non_differentiable(sums)
+        cvec = torch.tensor(coef, device=pred.device, dtype=torch.float32)
+        return torch.dot(sums, cvec), sums
+
+    @staticmethod
+    def backward(ctx, gloss, _gsums):
+        P, D, R, mask = ctx.saved_tensors
+        coef, mch = ctx.cfg
+        N, K = P.shape[:2]
+        nd = P.dim() - 2
+        gs = _dev(gloss.reshape(1), "grad")
+        gpred = torch.empty_like(P)
+        _lib.check(_lib.load().advchain_consistency_bwd(_ptr(P), _ptr(D), _ptr(R), _ptr(mask), _ptr(gs), _ptr(gpred),
+                                                        float(coef[0]), float(coef[1]), float(coef[2]), N, K, nd,
+                                                        _lib.dims_array(P.shape[2:]), mch, _stream()), "consistency_bwd")
+        return gpred, None, None, None, None, None
+
+
+def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
+    """Returns (coef . sums, sums) with sums = [S_mse, S_edgeA, S_edgeB] (device tensor, raw sums)."""
+    return _Consistency.apply(pred, ref, mask, tuple(float(c) for c in coef), bool(ref_is_prob), bool(want_edges))

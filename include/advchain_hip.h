@@ -1,0 +1,174 @@
+/* advchain_hip.h -- C ABI of libadvchain_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of cherise215/advchain: the adversarial-augmentation
+ * inner loop (ComposeAdversarialTransformSolver over AdvNoise / AdvBias / AdvMorph / AdvAffine).
+ * The reference has no native layer of its own: its arithmetic is a set of PyTorch ATen call
+ * sites.  Each entry point below replaces one (or a fused run) of those call sites; the
+ * "replaces" line cites the reference file:line (paths relative to the upstream repo root).
+ *
+ * Contract (all entry points)
+ *   - extern "C", plain pointers and sizes, no torch types.  Pointers are DEVICE pointers to
+ *     contiguous fp32 (int32 for index tables) owned by the caller; nothing is allocated or
+ *     freed inside; outputs / workspaces are caller-allocated.
+ *   - layout: channels-first (N, C, S0, S1[, S2]); `ndim` = 2 or 3 spatial dims, `dims` has
+ *     `ndim` entries in tensor order (slowest first).  Sampling grids are PLANAR (N, ndim, ...)
+ *     with channel 0 = x <-> last spatial dim, 1 = y, 2 = z (F.grid_sample convention).
+ *   - align_corners=True everywhere (the reference never uses False for samplers).
+ *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); kernels are
+ *     enqueued asynchronously on it; the call never synchronises.
+ *   - returns 0 on success, <0 on error (ADVCHAIN_ERR_*); advchain_last_error() gives the
+ *     message (thread-local).  No exceptions cross the ABI.  Thread-safe for distinct
+ *     streams/buffers.
+ *   - backward entry points whose targets are scatter destinations (grad_in / grad_phi) require
+ *     the caller to zero them first; they accumulate with hardware fp32 atomics.
+ */
+#ifndef ADVCHAIN_HIP_H_
+#define ADVCHAIN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVCHAIN_INTERP_LINEAR 0  /* 'bilinear' (4-D) / trilinear (5-D) */
+#define ADVCHAIN_INTERP_NEAREST 1
+#define ADVCHAIN_PAD_ZEROS 0
+#define ADVCHAIN_PAD_BORDER 1
+#define ADVCHAIN_PAD_REFLECTION 2
+
+int advchain_version(void);
+const char* advchain_last_error(void);
+
+/* ---- dense-field warp ------------------------------------------------------------------
+ * replaces: F.grid_sample(data, grid.permute(..), mode, padding_mode, align_corners=True)
+ *           advchain/augmentor/adv_morph.py:546-557 (AdvMorph.transform), and the final
+ *           torch.clamp(dxy,-1,1) of adv_morph.py:304-305,490 when clamp_grid != 0 (the
+ *           clamp and its sub-gradient mask are applied to the grid on load).
+ * in (N,C,in_dims), grid (N,ndim,out_dims) planar, out (N,C,out_dims).                      */
+int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
+                             const int64_t* in_dims, const int64_t* out_dims, int interp, int padding,
+                             int clamp_grid, void* stream);
+/* replaces: autograd grid_sampler_{2,3}d_backward for the call above.
+ * grad_in (N,C,in_dims) must be pre-zeroed (scatter-add); grad_grid (N,ndim,out_dims) is
+ * overwritten.  Either may be NULL.                                                         */
+int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
+                             float* grad_grid, int64_t N, int64_t C, int ndim, const int64_t* in_dims,
+                             const int64_t* out_dims, int interp, int padding, int clamp_grid, void* stream);
+
+/* ---- scaling-and-squaring step ---------------------------------------------------------
+ * replaces: applyComposition{2,3}D(phi, phi) = F.grid_sample(phi, phi^T, 'border',
+ *           align_corners=True), adv_morph.py:179-202, called 8+ times from
+ *           vectorFieldExponentiation{2,3}D adv_morph.py:132-135,165-168.
+ * final_mode 1 additionally emits (sample - phi0) + identity, i.e. 'phi - grid_wh' (with the
+ * in-place aliasing of adv_morph.py:111,143,176) plus '+ self.base_grid' of :474,483.
+ * phi, out, phi0: (N, ndim, dims).                                                          */
+int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
+                              const int64_t* dims, int final_mode, void* stream);
+/* grad_phi (pre-zeroed) receives both the value path (scatter) and the coordinate path.      */
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int64_t N, int ndim,
+                              const int64_t* dims, void* stream);
+
+/* ---- affine warp -----------------------------------------------------------------------
+ * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),
+ *           adv_affine.py:297-313.  theta (N, ndim, ndim+1); the grid is never materialised.    */
+int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim,
+                             const int64_t* dims, int interp, int padding, void* stream);
+int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims); /* floats */
+/* grad_in pre-zeroed or NULL; grad_theta (N, ndim, ndim+1) overwritten (deterministic two-stage
+ * reduction through `workspace`) or NULL.                                                     */
+int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
+                             float* grad_theta, float* workspace, int64_t N, int64_t C, int ndim,
+                             const int64_t* dims, int interp, int padding, void* stream);
+
+/* ---- affine parameters -> matrices -----------------------------------------------------
+ * replaces: AdvAffine.gen_batch_affine_matrix adv_affine.py:210-273 (Hardtanh, Euler z-y'-x''
+ *           rotation, scale, translation) and get_inverse_matrix adv_affine.py:316-324.
+ * param (N, 5|9); cfg = 2D {rot, scale_x, scale_y, shift_x, shift_y}
+ *                       3D {rot_x,rot_y,rot_z, scale_x,scale_y,scale_z, shift_x,shift_y,shift_z};
+ * theta, theta_inv (N, ndim, ndim+1).                                                         */
+int advchain_affine_theta_fwd(const float* param, const float* cfg_host, float param_scale, float* theta,
+                              float* theta_inv, int64_t N, int ndim, void* stream);
+int advchain_affine_theta_bwd(const float* param, const float* cfg_host, float param_scale, const float* grad_theta,
+                              const float* grad_theta_inv, float* grad_param, int64_t N, int ndim, void* stream);
+
+/* ---- banded tensor-product interpolation -----------------------------------------------
+ * Band tables (see advchain_amd/bands.py) describe, per axis a of the padded 3-axis view
+ * (2D passes a trivial leading axis), a linear map from g_a coefficients to S_a samples with at
+ * most B_a (<= 8) contiguous non-zeros per sample:
+ *   itab = for a in 0..2: start[S_a] | lo[g_a] | hi[g_a]      (int32)
+ *   ftab = for a in 0..2: w[S_a * B_a]                        (fp32)
+ * replaces: F.interpolate(duv, size=full, 'bilinear'|'trilinear', align_corners=False)
+ *           adv_morph.py:464, fused with 'basegrid += duv/2^n' (adv_morph.py:111,129-130) when
+ *           add_identity != 0, and with torch.norm(duv_interval) (adv_morph.py:160) when
+ *           sumsq != NULL (adds sum(interp^2) over the launch; caller zeroes it).
+ * coef (planes, g0,g1,g2) -> out (planes, S0,S1,S2) = identity? + scale * interp.               */
+int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
+                           const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
+                           float scale, float* sumsq, void* stream);
+/* adjoint along one axis: in (outer, S_axis, inner) -> out (outer, g_axis, inner),
+ * out = W_axis^T ((in - in2) * scale); in2 may be NULL.
+ * replaces: upsample_{bi,tri}linear backward / conv_transpose backward w.r.t. its input.        */
+int advchain_band_reduce_axis(const float* in, const float* in2, float* out, const int32_t* itab, const float* ftab,
+                              const int64_t* S, const int64_t* g, const int64_t* B, int axis, int64_t outer,
+                              int64_t inner, float scale, void* stream);
+
+/* ---- bias field ------------------------------------------------------------------------
+ * replaces: AdvBias.compute_smoothed_bias + clip_bias + multiply, adv_bias.py:279-356,186:
+ *           conv_transpose{2,3}d(cp, bspline) -> crop -> Upsample(linear, align_corners=False)
+ *           -> exp (log space) or 1+x -> 1+clamp(b-1,-eps,eps) -> data*b, evaluated in closed
+ *           form from the control points (band tables = upsample o B-spline, per axis).
+ * cp (N,1,g...), data/out (N,C,S...), field (N,1,S...) = clipped bias.  data may be NULL.        */
+int advchain_bias_field_fwd(const float* cp, const float* data, float* out, float* field, const int32_t* itab,
+                            const float* ftab, const int64_t* S, const int64_t* g, const int64_t* B, int64_t N,
+                            int64_t C, float eps, int use_log, float cp_scale, void* stream);
+/* grad_L (N,1,S...) = dLoss/d(log-field) at full resolution (reduce to control points with
+ * advchain_band_reduce_axis); grad_data (N,C,S...) = grad_out * field.  Either may be NULL.     */
+int advchain_bias_field_bwd(const float* cp, const float* data, const float* grad_out, float* grad_L, float* grad_data,
+                            const int32_t* itab, const float* ftab, const int64_t* S, const int64_t* g,
+                            const int64_t* B, int64_t N, int64_t C, float eps, int use_log, float cp_scale,
+                            void* stream);
+
+/* ---- separable Gaussian ----------------------------------------------------------------
+ * replaces: depthwise nn.Conv{2,3}d with the normalised 9^d Gaussian (sigma=1), zero padding,
+ *           adv_morph.py:377-452; one axis per call (self-adjoint: same entry for backward).
+ * pre : 0 none | 1 x*scale | 2 F.grid_sample(base_grid, x, 'border') - base_grid  (adv_morph.py:473-487)
+ * post: 0 none | 1 + base_grid (adv_morph.py:489)   | 2 * d(pre 2)/dx at aux      (backward of pre 2)
+ * in/out/aux (planes, dims); plane p carries grid channel p % C.  host pointer weights9[9].     */
+int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim,
+                        const int64_t* dims, int axis, const float* weights9_host, int pre, int post, float scale,
+                        void* stream);
+
+/* ---- streaming / per-sample normalisation ----------------------------------------------
+ * replaces: data + eps*param adv_noise.py:81-84 (x may be NULL: out = a*y).                     */
+int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n, void* stream);
+int64_t advchain_norm_workspace(int64_t N, int64_t M); /* floats */
+/* replaces: unit_normalize (adv_transformation_base.py:151-155) fused with the ascent update
+ *           param + step*g/(||g||+1e-20) (adv_noise.py:56-63, adv_bias.py:144-147,
+ *           adv_morph.py:511-513).  base may be NULL (pure normalisation).  x (N, M).           */
+int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
+                       int64_t M, void* stream);
+
+/* ---- consistency loss ------------------------------------------------------------------
+ * replaces: calc_segmentation_consistency / contour_loss, advchain/common/loss.py:8-87,102-220
+ *           ('mse' and 'contour' terms: softmax over K, mask, 3^d edge stencils, Q13/Q14).
+ * pred/ref (N,K,dims) logits (ref already a probability map when ref_is_prob), mask
+ * (N, mask_channels in {1,K}, dims) or NULL.  Outputs: P = softmax(pred), D = P - T (N,K,dims);
+ * R (N, 2(K-1), dims) = 2 m^2 (A*D), 2 m^2 (B*D) per class 1..K-1 (NULL when no backward is
+ * needed); sums[0] += sum ((P m)-(T m))^2, sums[1] += sum (A*D m)^2, sums[2] += sum (B*D m)^2
+ * (caller zeroes `sums` (3 floats) and applies the GLOBAL normalisers -- required for batch
+ * sharding).  2D: A = Sobel-x, B = Sobel-y.  3D: A = h(x)hp(x)h (the
+ * reference uses it for conv_x AND conv_y), B = h(x)h(x)hp.                                      */
+int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
+                             float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                             int ref_is_prob, int want_edges, void* stream);
+/* grad_pred (N,K,dims) = softmax'(P)[ gs (c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B) ], gs = *grad_scale
+ * (device scalar, NULL = 1).                                                                    */
+int advchain_consistency_bwd(const float* P, const float* D, const float* R, const float* mask,
+                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
+                             int64_t K, int ndim, const int64_t* dims, int mask_channels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVCHAIN_HIP_H_ */

@@ -33,11 +33,14 @@ def import_reference():
     # reference's one wins inside this process.
     for k in [k for k in sys.modules if k == "advchain" or k.startswith("advchain.")]:
         del sys.modules[k]
-    sys.path.insert(0, REFERENCE_ROOT)
-    try:
-        import advchain.augmentor as aug  # noqa
-        import advchain.common.loss as loss  # noqa
-        import advchain.common.utils as utils  # noqa
-    finally:
-        sys.path.remove(REFERENCE_ROOT)
+    # the reference's top-level ``advchain`` directory has no __init__.py (namespace package), so a regular
+    # package of the same name on sys.path (our alias) would shadow it: bind the name explicitly.
+    pkg = types.ModuleType("advchain")
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "advchain")]
+    sys.modules["advchain"] = pkg
+    import importlib
+    aug = importlib.import_module("advchain.augmentor")
+    importlib.import_module("advchain.common.loss")
+    importlib.import_module("advchain.common.utils")
+    assert aug.__file__.startswith(REFERENCE_ROOT), aug.__file__
     return aug

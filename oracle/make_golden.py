@@ -126,7 +126,16 @@ def g2_bias(aug):
             t = aug.AdvBias(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
             torch.manual_seed(100 + i)
             t.init_parameters()
-            p = (rand(tuple(t.param.shape), 200 + i) * 0.45).requires_grad_(True)  # beyond log(1.3): exercises the clip
+            # beyond log(1.3): exercises the clip.  The clip's sub-gradient is discontinuous, so pick a seed
+            # whose field keeps a margin to the threshold (SURVEY §7 "pick seeds with margins")
+            for attempt in range(50):
+                p = (rand(tuple(t.param.shape), 200 + i + 1000 * attempt) * 0.45)
+                fld = t.compute_smoothed_bias(p)
+                if int((((fld - 1).abs() - 0.3).abs() < 3e-5).sum()) == 0:
+                    break
+            else:
+                raise RuntimeError("no margin seed for " + tag)
+            p = p.requires_grad_(True)
             t.param = p
             data = smooth_data(*c["data_size"][:2], c["data_size"][2:], 300 + i)
             w = rand(tuple(data.shape), 400 + i)

@@ -1,0 +1,355 @@
+"""Kernel-level parity (GPU): every C-ABI entry point vs the CPU oracle / the ATen op it replaces,
+on seeded inputs and on the committed golden vectors.  fp32, tolerance stated per test (contract 1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import Fixture, maxdiff, rand, smooth_data
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-5
+
+
+def _ops():
+    from advchain_amd import ops
+    return ops
+
+
+def to_planar(grid_last):
+    d = grid_last.shape[-1]
+    return grid_last.permute(0, d + 1, *range(1, d + 1)).contiguous()
+
+
+def rel(a, b):
+    return maxdiff(a, b) / max(1e-6, float(b.abs().max()))
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_grid_sample_golden(tag, pad):
+    """G1: ATen CPU outputs stored in tests/golden/g1_grid_sample.npz."""
+    ops = _ops()
+    fx = Fixture("g1_grid_sample")
+    k = "%s_%s_" % (tag, pad)
+    inp = fx.t(k + "input", DEV).requires_grad_(True)
+    grid = to_planar(fx.t(k + "grid", DEV)).requires_grad_(True)
+    w = fx.t(k + "w", DEV)
+    out = ops.grid_sample(inp, grid, "bilinear", pad)
+    (out * w).sum().backward()
+    assert maxdiff(out.cpu(), fx.t(k + "out")) < TOL
+    assert maxdiff(inp.grad.cpu(), fx.t(k + "grad_input")) < TOL
+    assert maxdiff(grid.grad.cpu(), to_planar(fx.t(k + "grad_grid"))) < 5e-5
+    n = ops.grid_sample(fx.t(tag + "_nearest_input", DEV), to_planar(fx.t(tag + "_nearest_grid", DEV)), "nearest", "zeros")
+    assert maxdiff(n.cpu(), fx.t(tag + "_nearest_out")) == 0.0
+
+
+@pytest.mark.parametrize("dims,C", [((17, 23), 3), ((16, 24), 1), ((7, 9, 11), 2), ((8, 12, 16), 4)])
+@pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
+@pytest.mark.parametrize("interp", ["bilinear", "nearest"])
+def test_grid_sample_vs_aten_cpu(dims, C, pad, interp):
+    """Seeded inputs incl. out-of-range and on-border coordinates; both the float4 and the scalar kernels."""
+    ops = _ops()
+    d = len(dims)
+    inp = rand((2, C) + dims, 1)
+    grid = rand((2,) + dims + (d,), 2, -1.3, 1.3)
+    grid.view(-1)[::13] = 1.0
+    grid.view(-1)[3::17] = -1.0
+    w = rand((2, C) + dims, 3)
+    a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    ref = F.grid_sample(a, g, mode=interp, padding_mode=pad, align_corners=True)
+    (ref * w).sum().backward()
+    a2 = inp.to(DEV).requires_grad_(True)
+    g2 = to_planar(grid).to(DEV).requires_grad_(True)
+    out = ops.grid_sample(a2, g2, interp, pad)
+    (out * w.to(DEV)).sum().backward()
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(a2.grad.cpu(), a.grad) < TOL
+    if interp == "bilinear":
+        assert maxdiff(g2.grad.cpu(), to_planar(g.grad)) < 5e-5
+    else:
+        assert float(g2.grad.abs().max()) == 0.0
+
+
+def test_grid_sample_clamp_grid_and_resample():
+    """clamp_grid == torch.clamp(grid,-1,1) before sampling (value and sub-gradient); in/out sizes may differ."""
+    ops = _ops()
+    inp = rand((2, 2, 9, 10, 12), 5)
+    grid = rand((2, 6, 7, 8, 3), 6, -1.4, 1.4)
+    w = rand((2, 2, 6, 7, 8), 7)
+    a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    ref = F.grid_sample(a, torch.clamp(g, -1, 1), padding_mode="zeros", align_corners=True)
+    (ref * w).sum().backward()
+    a2, g2 = inp.to(DEV).requires_grad_(True), to_planar(grid).to(DEV).requires_grad_(True)
+    out = ops.grid_sample(a2, g2, "bilinear", "zeros", clamp_grid=True)
+    (out * w.to(DEV)).sum().backward()
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(a2.grad.cpu(), a.grad) < TOL
+    assert maxdiff(g2.grad.cpu(), to_planar(g.grad)) < 5e-5
+
+
+@pytest.mark.parametrize("dims", [(20, 28), (19, 21), (8, 12, 16), (7, 9, 5)])
+def test_compose_self(dims):
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    phi = (O.identity_grid(2, dims) + 0.15 * rand((2, d) + dims, 11)).contiguous()
+    w = rand((2, d) + dims, 12)
+    p = phi.clone().requires_grad_(True)
+    ref = O.compose_fields(p, p)
+    (ref * w).sum().backward()
+    pd = phi.to(DEV)
+    out = ops.raw_compose_self_fwd(pd)
+    gphi = ops.raw_compose_self_bwd(w.to(DEV), pd)
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(gphi.cpu(), p.grad) < 5e-5
+    # final mode: (sample - phi0) + identity
+    phi0 = (O.identity_grid(2, dims) + 0.01 * rand((2, d) + dims, 13)).contiguous()
+    fin = ops.raw_compose_self_fwd(pd, phi0=phi0.to(DEV), final_mode=1)
+    assert maxdiff(fin.cpu(), (ref.detach() - phi0) + O.identity_grid(2, dims)) < TOL
+
+
+@pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4)])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_affine_warp(dims, C, pad):
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    theta = (torch.eye(d, d + 1).repeat(2, 1, 1) + 0.2 * rand((2, d, d + 1), 21)).contiguous()
+    inp = rand((2, C) + dims, 22)
+    w = rand((2, C) + dims, 23)
+    a, t = inp.clone().requires_grad_(True), theta.clone().requires_grad_(True)
+    ref = O.affine_warp(a, t, "bilinear", pad)
+    (ref * w).sum().backward()
+    a2, t2 = inp.to(DEV).requires_grad_(True), theta.to(DEV).requires_grad_(True)
+    out = ops.affine_warp(a2, t2, "bilinear", pad)
+    (out * w.to(DEV)).sum().backward()
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(a2.grad.cpu(), a.grad) < TOL
+    assert rel(t2.grad.cpu(), t.grad) < 2e-5
+    n_ref = O.affine_warp(inp, theta, "nearest", pad)
+    n_out = ops.affine_warp(inp.to(DEV), theta.to(DEV), "nearest", pad)
+    assert float((n_out.cpu() != n_ref).float().mean()) < 2e-3  # rounding ties at .5 may differ by fp order
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_affine_theta(nd):
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    if nd == 2:
+        cfg = dict(rot=30.0 / 180, scale_x=0.2, scale_y=0.15, shift_x=0.1, shift_y=0.05)
+        order = ["rot", "scale_x", "scale_y", "shift_x", "shift_y"]
+        p = torch.tensor([[0.5, -0.3, 0.8, 0.2, -0.6], [-0.9, 0.4, -0.1, 0.7, 0.3], [1.5, -2.0, 0.99, -1.0, 1.0]])
+    else:
+        cfg = dict(rot_x=10.0 / 180, rot_y=20.0 / 180, rot_z=15.0 / 180, scale_x=0.1, scale_y=0.2, scale_z=0.15,
+                   shift_x=0.1, shift_y=0.05, shift_z=0.2)
+        order = ["rot_x", "rot_y", "rot_z", "scale_x", "scale_y", "scale_z", "shift_x", "shift_y", "shift_z"]
+        p = torch.tensor([[0.5, -0.3, 0.8, 0.2, -0.6, 0.1, -0.4, 0.9, -0.7],
+                          [-0.9, 0.4, -0.1, 0.7, 0.3, -0.5, 0.6, -0.2, 0.8],
+                          [1.5, 0.4, -1.1, 0.7, 2.3, -0.5, 0.6, -1.0, 1.0]])
+    w1, w2 = rand((3, nd, nd + 1), 31), rand((3, nd, nd + 1), 32)
+    a = p.clone().requires_grad_(True)
+    th = O.affine_theta(a, cfg, nd)
+    thi = O.affine_inverse(th)
+    ((th * w1).sum() + (thi * w2).sum()).backward()
+    b = p.to(DEV).requires_grad_(True)
+    th2, thi2 = ops.affine_theta(b, [cfg[k] for k in order], 1.0, nd)
+    ((th2 * w1.to(DEV)).sum() + (thi2 * w2.to(DEV)).sum()).backward()
+    assert maxdiff(th2.cpu(), th) < 1e-6
+    assert maxdiff(thi2.cpu(), thi) < 2e-6
+    assert maxdiff(b.grad.cpu(), a.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 12, 12), (2, 2, 40, 33), (2, 3, 8, 8, 32), (1, 3, 13, 11, 10)])
+def test_gauss_separable_vs_dense(shape):
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    x = rand(shape, 41)
+    ref = O.gaussian_smooth(x)
+    out = ops.raw_gauss(x.to(DEV), shape[1])
+    assert maxdiff(out.cpu(), ref) < 2e-6
+    out2 = ops.raw_gauss(x.to(DEV), shape[1], pre=1, scale=-1.5)
+    assert maxdiff(out2.cpu(), O.gaussian_smooth(-1.5 * x)) < 3e-6
+
+
+@pytest.mark.parametrize("low,full", [((12, 12), (192, 192)), ((3, 5), (24, 40)), ((8, 8, 32), (128, 128, 64)),
+                                        ((4, 4, 2), (16, 16, 8)), ((3, 2, 4), (12, 10, 14))])
+def test_tp_interp_upsample_and_adjoint(low, full):
+    from advchain_amd import bands
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(low)
+    n = 1 if np.prod(full) > 500000 else 2
+    v = rand((n, d) + low, 51)
+    mode = "bilinear" if d == 2 else "trilinear"
+    a = v.clone().requires_grad_(True)
+    ref = F.interpolate(a, size=full, mode=mode, align_corners=False)
+    w = rand((n, d) + full, 52)
+    w2 = rand((n, d) + full, 53)
+    ((ref * (w - w2)).sum() * 0.25).backward()
+    tabs = bands.upsample_tables(low, full, DEV)
+    out = ops.raw_tp_interp(v.to(DEV), tabs, d)
+    assert maxdiff(out.cpu(), ref) < 2e-6
+    # identity + scale, and sum of squares
+    ss = torch.zeros(1, device=DEV)
+    out2 = ops.raw_tp_interp(v.to(DEV), tabs, d, add_identity=True, scale=0.125, sumsq=ss)
+    assert maxdiff(out2.cpu(), O.identity_grid(n, full) + ref.detach() * 0.125) < 2e-6
+    assert abs(float(ss) - float((ref.detach().double() ** 2).sum())) < 1e-4 * float((ref.detach().double() ** 2).sum())
+    adj = ops.raw_tp_adjoint(w.to(DEV), tabs, gfull2=w2.to(DEV), scale=0.25)
+    assert rel(adj.cpu(), a.grad) < 2e-5
+
+
+def test_bias_golden():
+    """G2: AdvBias field / forward / control-point gradient against the reference's outputs."""
+    from advchain_amd.augmentor import AdvBias
+    fx = Fixture("g2_bias")
+    for key, m in fx.json().items():
+        cfg = m["config"]
+        t = AdvBias(spatial_dims=m["spatial_dims"], config_dict=cfg, device=torch.device(DEV))
+        t.init_parameters()
+        assert list(t.param.shape) == m["cp_grid"], key
+        p = fx.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        if key + "data" in fx:
+            data, w = fx.t(key + "data", DEV), fx.t(key + "w", DEV)
+        else:
+            ds = cfg["data_size"]
+            data = smooth_data(ds[0], ds[1], ds[2:], int(fx.arr(key + "data_seed"))).to(DEV)
+            w = rand(tuple(data.shape), int(fx.arr(key + "w_seed"))).to(DEV)
+        o = t.forward(data)
+        (o * w).sum().backward()
+        if key + "field" in fx:
+            assert maxdiff(t.bias_field.cpu(), fx.t(key + "field")) < 5e-6, key
+            assert maxdiff(o.cpu(), fx.t(key + "out")) < 5e-6, key
+        else:
+            sl = tuple([slice(None)] * 2 + [slice(None, None, 7)] * m["spatial_dims"])
+            assert maxdiff(t.bias_field[sl].cpu(), fx.t(key + "field_sample")) < 5e-6, key
+        g = fx.t(key + "grad_param")
+        assert maxdiff(p.grad.cpu(), g) < 2e-5 * max(1.0, float(g.abs().max())), key
+
+
+def test_bias_data_gradient():
+    from advchain_amd.augmentor import AdvBias
+    from oracle import advchain_oracle as O
+    cfg = dict(epsilon=0.3, control_point_spacing=[16, 16], downscale=2, data_size=[2, 3, 32, 32],
+               interpolation_order=3, init_mode="random", space="log")
+    t = AdvBias(spatial_dims=2, config_dict=cfg, device=torch.device(DEV))
+    t.init_parameters()
+    o = O.OracleBias(2, cfg)
+    o.init_parameters()
+    o.param = t.param.detach().cpu().clone()
+    data = rand((2, 3, 32, 32), 61, 0, 1)
+    w = rand((2, 3, 32, 32), 62)
+    a = data.clone().requires_grad_(True)
+    (o.forward(a) * w).sum().backward()
+    b = data.to(DEV).requires_grad_(True)
+    (t.forward(b) * w.to(DEV)).sum().backward()
+    assert maxdiff(b.grad.cpu(), a.grad) < 1e-5
+
+
+def test_demons_field_golden():
+    """G3: DemonsCompose grid (+/- velocity), warps, and raw velocity gradients vs the reference."""
+    from advchain_amd.augmentor import AdvMorph
+    fx = Fixture("g3_morph")
+    for key, m in fx.json().items():
+        t = AdvMorph(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
+        t.init_parameters()
+        p = fx.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        data, w = fx.t(key + "data", DEV), fx.t(key + "w", DEV)
+        dxy_f, _ = t.get_deformation_displacement_field(duv=t.epsilon * p)
+        dxy_b, _ = t.get_deformation_displacement_field(duv=-t.epsilon * p)
+        assert maxdiff(dxy_f.cpu(), fx.t(key + "dxy_fwd")) < TOL, key
+        assert maxdiff(dxy_b.cpu(), fx.t(key + "dxy_bwd")) < TOL, key
+        o = t.forward(data)
+        (o * w).sum().backward()
+        assert maxdiff(o.cpu(), fx.t(key + "forward")) < TOL, key
+        g = fx.t(key + "grad_param_fwd")
+        assert maxdiff(p.grad.cpu(), g) < 1e-4 * max(1.0, float(g.abs().max())), key
+        p.grad = None
+        ob = t.backward(data)
+        (ob * w).sum().backward()
+        assert maxdiff(ob.cpu(), fx.t(key + "backward")) < TOL, key
+        g = fx.t(key + "grad_param_bwd")
+        assert maxdiff(p.grad.cpu(), g) < 1e-4 * max(1.0, float(g.abs().max())), key
+        p.grad = None
+        dd = data.clone().requires_grad_(True)
+        rt = t.backward(t.forward(dd))
+        (rt * w).sum().backward()
+        assert maxdiff(rt.cpu(), fx.t(key + "roundtrip")) < TOL, key
+        assert maxdiff(dd.grad.cpu(), fx.t(key + "roundtrip_grad_data")) < TOL, key
+        g = fx.t(key + "roundtrip_grad_param")
+        assert maxdiff(p.grad.cpu(), g) < 1e-4 * max(1.0, float(g.abs().max())), key
+        assert maxdiff(t.forward(data, padding_mode="border").cpu(), fx.t(key + "forward_border")) < TOL
+        nn_out = t.forward(data, interp="nearest").cpu()
+        assert float((nn_out - fx.t(key + "forward_nearest")).abs().gt(1e-6).float().mean()) < 5e-3
+
+
+def test_affine_golden():
+    from advchain_amd.augmentor import AdvAffine
+    fx = Fixture("g4_affine")
+    for key, m in fx.json().items():
+        t = AdvAffine(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
+        t.init_parameters()
+        p = fx.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        data, w = fx.t(key + "data", DEV), fx.t(key + "w", DEV)
+        o = t.forward(data)
+        assert maxdiff(t.affine_matrix.cpu(), fx.t(key + "theta")) < 1e-6
+        assert maxdiff(t.get_inverse_matrix(t.affine_matrix).cpu(), fx.t(key + "theta_inv")) < 2e-6
+        (o * w).sum().backward()
+        assert maxdiff(o.cpu(), fx.t(key + "forward")) < TOL
+        g = fx.t(key + "grad_param_fwd")
+        assert maxdiff(p.grad.cpu(), g) < 2e-5 * max(1.0, float(g.abs().max())), key
+        p.grad = None
+        t.forward(data)
+        ob = t.backward(data)
+        (ob * w).sum().backward()
+        assert maxdiff(ob.cpu(), fx.t(key + "backward")) < TOL
+        g = fx.t(key + "grad_param_bwd")
+        assert maxdiff(p.grad.cpu(), g) < 2e-5 * max(1.0, float(g.abs().max())), key
+        p.grad = None
+        dd = data.clone().requires_grad_(True)
+        rt = t.backward(t.forward(dd))
+        (rt * w).sum().backward()
+        assert maxdiff(rt.cpu(), fx.t(key + "roundtrip")) < TOL
+        assert maxdiff(dd.grad.cpu(), fx.t(key + "roundtrip_grad_data")) < TOL
+        g = fx.t(key + "roundtrip_grad_param")
+        assert maxdiff(p.grad.cpu(), g) < 2e-5 * max(1.0, float(g.abs().max())), key
+
+
+def test_axpy_and_normalized_update():
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    for shape in [(3, 1, 33, 17), (2, 3, 8, 8, 32), (4, 64), (2, 1, 128, 128, 9)]:
+        x, y = rand(shape, 71), rand(shape, 72)
+        assert maxdiff(ops.raw_axpy(x.to(DEV), y.to(DEV), 0.3).cpu(), x + 0.3 * y) < 1e-6
+        assert maxdiff(ops.raw_axpy(None, y.to(DEV), -2.0).cpu(), -2.0 * y) < 1e-6
+        ref = x + 0.7 * O.unit_normalize(y)
+        assert maxdiff(ops.normalized_axpy(x.to(DEV), y.to(DEV), 0.7).cpu(), ref) < 1e-6
+        assert maxdiff(ops.normalized_axpy(None, y.to(DEV), 1.0).cpu(), O.unit_normalize(y)) < 1e-6
+    a = rand((2, 1, 9, 9), 73).to(DEV).requires_grad_(True)
+    b = rand((2, 1, 9, 9), 74).to(DEV).requires_grad_(True)
+    ops.axpy(a, b, 0.5).sum().backward()
+    assert float((a.grad - 1).abs().max()) == 0 and float((b.grad - 0.5).abs().max()) == 0
+
+
+def test_consistency_loss_golden():
+    """G5: 'mse' / 'contour' / mixed consistency values and logits gradients vs the reference (2D and 3D)."""
+    from advchain_amd.common.loss import calc_segmentation_consistency
+    fx = Fixture("g5_loss")
+    for tag in ("2d", "3d"):
+        ref, mask = fx.t(tag + "_ref", DEV), fx.t(tag + "_mask", DEV)
+        for name, types, weights in (("mse", ["mse"], [1.0]), ("contour", ["contour"], [1.0]), ("kl", ["kl"], [1.0]),
+                                     ("mix", ["mse", "contour"], [1.0, 0.5])):
+            for mtag, mk in (("masked", mask), ("nomask", None)):
+                pred = fx.t(tag + "_pred", DEV).requires_grad_(True)
+                v = calc_segmentation_consistency(output=pred, reference=ref, divergence_types=types,
+                                                  divergence_weights=weights, scales=[0], mask=mk)
+                v.backward()
+                k = "%s_%s_%s_" % (tag, name, mtag)
+                assert abs(float(v) - fx.f(k + "value")) < 1e-7 + 2e-5 * abs(fx.f(k + "value")), k
+                g = fx.t(k + "grad")
+                assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, k

@@ -1,0 +1,232 @@
+"""Solver-level parity (GPU) against the reference's own runs stored in tests/golden/g6_*.npz.
+
+Protocol: the N-step ascent map is chaotic in fp32, so the 1e-4 contract is checked PER STEP
+with teacher forcing -- the reference's parameters theta_k are injected, and dist_k, the raw gradients and
+theta_{k+1} are compared -- plus free-running runs for short horizons on the band-limited fixtures."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import Fixture, make_model, maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+TOL = 1e-4  # the north-star contract (fp32)
+
+
+def build_chain(spec):
+    from advchain_amd.augmentor import AdvAffine, AdvBias, AdvMorph, AdvNoise
+    cls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
+    chain = []
+    for s in spec:
+        sd = len(s["config"]["data_size"]) - 2
+        chain.append(cls[s["name"]](spatial_dims=sd, config_dict=s["config"], device=DEV, **s.get("kwargs", {})))
+    return chain
+
+
+def make_solver(fx):
+    from advchain_amd.augmentor import ComposeAdversarialTransformSolver
+    meta = fx.json()
+    chain = build_chain(meta["chain"])
+    for i, t in enumerate(chain):
+        t.init_parameters()
+        t.set_parameters(fx.t("init_param_%d" % i, DEV))
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, **meta["solver"])
+    return solver, chain, meta, make_model(meta["spatial_dims"], device=DEV)
+
+
+G6_CASES = ["2d_full_n1", "2d_full_n3", "2d_full_n2_norm", "2d_smart_n2", "2d_power_n2", "2d_kl_n1",
+            "2d_photometric_n2", "2d_step_n2", "3d_bma_n2", "3d_full_n1", "3d_morph_anat_n2", "2d_n0"]
+
+
+def _kwargs(fx, meta):
+    kw = dict(meta["train"])
+    if meta["has_anatomy"]:
+        kw["anatomy_mask_images"] = fx.t("anatomy", DEV)
+    return kw
+
+
+@pytest.mark.parametrize("case", G6_CASES)
+def test_free_running(case):
+    """Whole adversarial_training call vs the reference (horizons <= 3 steps on smooth data)."""
+    fx = Fixture("g6_" + case)
+    solver, chain, meta, model = make_solver(fx)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = solver.adversarial_training(data=fx.t("data", DEV), model=model, **_kwargs(fx, meta))
+    ref = fx.f("final_loss")
+    assert abs(float(loss) - ref) < 1e-6 + 2e-4 * abs(ref), (float(loss), ref)
+    assert maxdiff(solver.init_output.cpu(), fx.t("init_output")) < 1e-5
+    tol = TOL if meta["train"]["n_iter"] <= 1 else 5 * TOL   # amplification of rounding over >1 step
+    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data")) < tol
+    assert maxdiff(solver.warped_back_adv_output.cpu(), fx.t("warped_back")) < tol * 3
+    for i, t in enumerate(solver.chain_of_transforms[:len(chain)]):
+        ref_p = fx.t("final_param_%d" % i)
+        assert maxdiff(t.param.cpu(), ref_p) < tol * max(1.0, float(ref_p.abs().max())), (case, i)
+
+
+@pytest.mark.parametrize("case", [c for c in G6_CASES if c not in ("2d_n0",)])
+def test_teacher_forced_steps(case):
+    """Per-step: inject the reference's theta_k, compare dist_k, raw gradients and theta_{k+1} (<= 1e-4)."""
+    fx = Fixture("g6_" + case)
+    solver, chain, meta, model = make_solver(fx)
+    data = fx.t("data", DEV)
+    kw = _kwargs(fx, meta)
+    n_updates = int(fx.arr("n_updates"))
+    n_t = len(chain)
+    n_steps = n_updates // n_t
+    pis = kw.get("power_iteration", False)
+    if pis == "smart":
+        pis = [t.get_name() == "noise" for t in chain]
+    elif isinstance(pis, bool):
+        pis = [pis] * n_t
+    for t, pi in zip(chain, pis):
+        t.power_iteration = pi
+    step_sizes = kw.get("step_sizes", 1)
+    step_sizes = [step_sizes] * n_t if isinstance(step_sizes, (int, float)) else step_sizes
+    init_output = solver.get_init_output(model, data)
+    anatomy = kw.get("anatomy_mask_images")
+    loss_trace = fx.arr("loss_trace")
+    anat_trace = fx.arr("anatomy_trace")
+    for k in range(n_steps):
+        # teacher forcing: parameters the reference had at the start of step k (train() re-normalises for
+        # power iteration exactly like the reference does)
+        for ti, t in enumerate(chain):
+            t.eval()
+            p_in = fx.t("upd%02d_param_in" % (k * n_t + ti), DEV)
+            t.param = p_in.clone()
+        captured = {}
+        for ti, t in enumerate(chain):
+            def wrap(t=t, ti=ti, orig=t.optimize_parameters):
+                def f(step_size=None):
+                    captured[ti] = t.param.grad.detach().clone()
+                    return orig(step_size=step_size)
+                return f
+            t._orig_opt = t.optimize_parameters
+            t.optimize_parameters = wrap()
+        # run exactly one ascent iteration through the product's own loop (no rescale: i_iter != n_iter)
+        with contextlib.redirect_stdout(io.StringIO()):
+            _run_one_step(solver, model, data, init_output, step_sizes, anatomy, kw)
+        for t in chain:
+            t.optimize_parameters = t._orig_opt
+        expected = loss_trace[k]
+        if meta["has_anatomy"]:
+            expected = expected + 50 * anat_trace[1 + k]
+        assert abs(float(solver.last_inner_dist) - expected) < 1e-7 + 1e-4 * abs(expected), (case, k)
+        for ti, t in enumerate(chain):
+            g_ref = fx.t("upd%02d_grad" % (k * n_t + ti))
+            scale = max(1e-12, float(g_ref.abs().max()))
+            assert maxdiff(captured[ti].cpu(), g_ref) < TOL * scale, (case, k, ti, "grad")
+            p_ref = fx.t("upd%02d_param_out" % (k * n_t + ti))
+            if t.get_name() == "affine":
+                # sign(grad) is discontinuous at 0: only compare where the reference gradient is clearly non-zero
+                sel = g_ref.abs() > 1e-3 * scale
+                assert maxdiff(t.param.cpu()[sel], p_ref[sel]) < TOL, (case, k, ti, "param")
+            else:
+                assert maxdiff(t.param.cpu(), p_ref) < TOL * max(1.0, float(p_ref.abs().max())), (case, k, ti, "param")
+
+
+def _run_one_step(solver, model, data, init_output, step_sizes, anatomy, kw):
+    """One iteration of optimizing_transform: n_iter is chosen so that the end-of-loop branch is not taken."""
+    orig = solver.optimizing_transform
+
+    class _Stop(Exception):
+        pass
+
+    # run the product loop with n_iter=2 and abort after the first iteration's updates
+    calls = {"n": 0}
+    orig_make = solver.make_learnable_transformation
+
+    def make(optimize_flags, chain_of_transforms=None):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise _Stop()
+        return orig_make(optimize_flags=optimize_flags, chain_of_transforms=chain_of_transforms)
+    solver.make_learnable_transformation = make
+    try:
+        orig(model=model, data=data, init_output=init_output, optimize_flags=[True] * len(solver.chain_of_transforms),
+             n_iter=2, step_sizes=step_sizes, anatomy_mask_images=anatomy,
+             anatomy_reg_weight=kw.get("anatomy_reg_weight", 50),
+             volume_preserve_tolerance=kw.get("volume_preserve_tolerance", 5e-4))
+    except _Stop:
+        pass
+    finally:
+        solver.make_learnable_transformation = orig_make
+
+
+def test_kat_appendix_b():
+    """RNG-free known answers of SURVEY Appendix B (values re-derived from the live reference)."""
+    from advchain_amd.augmentor import ComposeAdversarialTransformSolver
+    fx = Fixture("kat_2d")
+    chain = build_chain(fx.json()["chain"])
+    chain[0].epsilon = 0.1
+    for t, k in zip(chain, ("noise", "bias", "morph", "affine")):
+        t.init_parameters()
+        t.set_parameters(fx.t("param_" + k, DEV))
+    data = fx.t("data", DEV)
+    assert maxdiff(chain[0].forward(data).cpu(), fx.t("noise_forward")) < 1e-6
+    assert maxdiff(chain[1].forward(data).cpu(), fx.t("bias_forward")) < 5e-6
+    assert maxdiff(chain[2].forward(data).cpu(), fx.t("morph_forward")) < 2e-5
+    assert maxdiff(chain[2].backward(data).cpu(), fx.t("morph_backward")) < 2e-5
+    assert maxdiff(chain[3].forward(data).cpu(), fx.t("affine_forward")) < 2e-5
+    assert maxdiff(chain[3].backward(data).cpu(), fx.t("affine_backward")) < 2e-5
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=['mse', 'contour'],
+                                               divergence_weights=[1.0, 0.5], if_norm_image=True)
+    assert maxdiff(solver.forward(data.clone()).cpu(), fx.t("solver_forward")) < 2e-5
+    model = make_model(2, device=DEV)
+    l0 = solver.adversarial_training(data=data, model=model, n_iter=0, lazy_load=True)
+    assert abs(float(l0) - 2.503928030e-03) < 2e-7
+    l2 = solver.adversarial_training(data=data, model=model, n_iter=2, lazy_load=True, step_sizes=1)
+    assert abs(float(l2) - 3.633607877e-03) < 1e-6
+    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data_n2")) < 5e-4
+
+
+def test_cpu_tensor_is_rejected():
+    """No CPU fallback: the product raises on CPU tensors."""
+    from advchain_amd import _lib, ops
+    with pytest.raises(_lib.AdvchainHipError):
+        ops.grid_sample(torch.rand(1, 1, 4, 4), torch.rand(1, 2, 4, 4))
+
+
+def test_third_party_transform_plugin():
+    """A user subclass of AdvTransformBase written with plain torch ops works inside the solver."""
+    from advchain_amd.augmentor import AdvTransformBase, ComposeAdversarialTransformSolver
+
+    class Gamma(AdvTransformBase):
+        def init_config(self, config_dict):
+            self.epsilon = config_dict["epsilon"]
+            self.data_size = config_dict["data_size"]
+
+        def init_parameters(self):
+            self.param = torch.zeros(self.data_size[0], 1, device=self.device)
+            return self.param
+
+        def forward(self, data, **kw):
+            g = torch.exp(self.epsilon * torch.tanh(self.param)).view(-1, 1, 1, 1)
+            out = data.clamp_min(1e-6) ** g
+            self.diff = out - data
+            return out
+
+        def backward(self, data, **kw):
+            return data
+        predict_forward = predict_backward = backward
+
+        def optimize_parameters(self, step_size=None):
+            self.param = (self.param + step_size * self.param.grad.sign()).detach()
+            return self.param
+
+        def rescale_parameters(self):
+            return self.param
+
+        def get_name(self):
+            return "gamma"
+
+    ds = [2, 1, 32, 32]
+    t = Gamma(spatial_dims=2, config_dict=dict(epsilon=0.3, data_size=ds), device=DEV)
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=[t])
+    model = make_model(2, device=DEV)
+    data = torch.rand(*ds, device=DEV)
+    loss = solver.adversarial_training(data=data, model=model, n_iter=2)
+    assert torch.isfinite(loss) and float(t.param.abs().max()) > 0
