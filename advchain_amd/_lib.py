@@ -44,6 +44,51 @@ class AdvchainHipError(RuntimeError):
     pass
 
 
+class _Lib(object):
+    """Thin proxy over the ctypes library.  ``timed`` (bench / profiling only) wraps selected entry points with
+    a pair of events on the current stream -- the stream the kernels are launched on -- and records
+    (name, args, start_event, end_event); everything else is a direct ctypes call."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._raw = {}
+        self.records = []
+
+    def _bind(self, name, res, args):
+        fn = getattr(self._cdll, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+        self._raw[name] = fn
+        setattr(self, name, fn)
+
+    def timed(self, names=None):
+        import contextlib
+        import torch
+
+        @contextlib.contextmanager
+        def ctx():
+            chosen = [n for n in self._raw if (names is None or n in names) and self._raw[n].restype is c_int
+                      and len(self._raw[n].argtypes) > 0]
+            for n in chosen:
+                raw = self._raw[n]
+
+                def wrapped(*a, _raw=raw, _n=n):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = _raw(*a)
+                    e1.record()
+                    self.records.append((_n, a, e0, e1))
+                    return rc
+                setattr(self, n, wrapped)
+            try:
+                yield self
+            finally:
+                for n in chosen:
+                    setattr(self, n, self._raw[n])
+        return ctx()
+
+
 def load():
     """Loads the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -58,11 +103,9 @@ def load():
     tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     if os.path.exists(tl):
         ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = _Lib(ctypes.CDLL(LIB_PATH))
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
-        fn.restype = res
-        fn.argtypes = args
+        lib._bind(name, res, args)
     _lib = lib
     return lib
 

@@ -1,0 +1,336 @@
+#!/usr/bin/env python
+"""Benchmark of the AdvChain adversarial-augmentation inner loop on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2]
+
+One "step" = one ``solver.adversarial_training(data, model, n_iter=...)`` call on one synthetic batch (all
+ascent steps + the final consistency-loss pass), data already resident in HBM.  Prints ONE JSON line:
+metric / value (whole-job augmented images per second) / roofline of the dominant kernel (HIP events on the
+launch stream, over the timed region) / cpu_baseline (the CPU oracle, bounded sample, rank 0 at N=1 only).
+
+Multi-GPU (``torch.distributed.run``): one process per GPU, the batch is sharded (weak scaling: the
+per-GPU batch is the workload's batch), RCCL all-reduces carry scalars only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
+
+# BASELINE.json configs.  batch = per-GPU batch (weak scaling).
+WORKLOADS = {
+    "cfg1": dict(dims=(192, 192), batch=4, chain=["noise", "bias", "morph", "affine"], n_iter=1,
+                 desc="2D 4x1x192x192, chain=[noise,bias,morph,affine], 1 adv step"),
+    "cfg2": dict(dims=(256, 256), batch=32, chain=["noise", "bias", "morph", "affine"], n_iter=5,
+                 desc="2D 32x1x256x256, chain=[noise,bias,morph,affine], 5 adv steps"),
+    "cfg3": dict(dims=(128, 128, 64), batch=4, chain=["bias", "morph", "affine"], n_iter=3,
+                 desc="3D 4x1x128x128x64, chain=[bias,morph,affine], 3 adv steps"),
+    "cfg4": dict(dims=(128, 128, 64), batch=8, chain=["noise", "bias", "morph", "affine"], n_iter=5,
+                 desc="3D 8x1x128x128x64 per GPU (64 over 8 GPUs), full chain, 5 adv steps"),
+    "cfg5": dict(dims=(160, 160, 80), batch=4, chain=["morph"], n_iter=10, anatomy=True,
+                 desc="3D 4x1x160x160x80 per GPU (8 over 2 GPUs), morph only (vector h/8), 10 adv steps, anatomy mask"),
+}
+
+
+def transform_configs(dims, batch, names, morph_div8=False):
+    """Notebook conventions."""
+    sd = len(dims)
+    ds = [batch, 1] + list(dims)
+    out = []
+    for nm in names:
+        if nm == "noise":
+            out.append((nm, dict(epsilon=1.0, xi=1e-6, data_size=ds)))
+        elif nm == "bias":
+            out.append((nm, dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims],
+                                 downscale=2 if sd == 2 else 4, data_size=ds, interpolation_order=3,
+                                 init_mode="random", space="log")))
+        elif nm == "morph":
+            if morph_div8:
+                vs = [s // 8 for s in dims]
+            elif sd == 2:
+                vs = [s // 16 for s in dims]
+            else:
+                vs = [dims[0] // 16, dims[1] // 16, dims[2] // 2]
+            out.append((nm, dict(epsilon=1.5, data_size=ds, vector_size=vs)))
+        else:
+            if sd == 2:
+                out.append((nm, dict(rot=30.0 / 180, scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1,
+                                     data_size=ds)))
+            else:
+                out.append((nm, dict(rot_x=10.0 / 180, rot_y=10.0 / 180, rot_z=10.0 / 180, scale_x=0.1,
+                                     scale_y=0.1, scale_z=0.1, shift_x=0.1, shift_y=0.1, shift_z=0.1,
+                                     data_size=ds)))
+    return out
+
+
+def make_model(sd):
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d if sd == 2 else torch.nn.Conv3d
+    return conv(1, 4, 3, 1, 1).eval()
+
+
+def ellipsoid(batch, dims):
+    axes = torch.meshgrid([torch.linspace(-1, 1, s) for s in dims], indexing="ij")
+    return (sum(a ** 2 for a in axes) <= 0.25 * 1.0).float()[None, None].repeat(batch, 1, *([1] * len(dims)))
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic bytes per launch (fp32) of each C-ABI entry point, from its arguments
+# ------------------------------------------------------------------------------------------------
+def _arr(a, n):
+    return [int(a[i]) for i in range(n)]
+
+
+def _prod(x):
+    p = 1
+    for v in x:
+        p *= v
+    return p
+
+
+def algorithmic_bytes(name, a):
+    """Compulsory HBM traffic of one launch: bytes that must be read + written once."""
+    if name == "advchain_compose_self_fwd":
+        N, nd = a[3], a[4]
+        V = _prod(_arr(a[5], nd))
+        extra = 4 * nd * N * V if a[6] == 1 else 0          # final mode also reads phi0
+        return 8 * nd * N * V + extra                        # read phi (d ch) + write out (d ch)
+    if name == "advchain_compose_self_bwd":
+        N, nd = a[3], a[4]
+        V = _prod(_arr(a[5], nd))
+        return 12 * nd * N * V                               # read grad_out, phi; write grad_phi (atomics)
+    if name == "advchain_grid_sample_fwd":
+        N, C, nd = a[3], a[4], a[5]
+        return 4 * N * (C * _prod(_arr(a[6], nd)) + (C + nd) * _prod(_arr(a[7], nd)))
+    if name == "advchain_grid_sample_bwd":
+        N, C, nd = a[5], a[6], a[7]
+        IV, OV = _prod(_arr(a[8], nd)), _prod(_arr(a[9], nd))
+        b = 4 * N * (C * OV + nd * OV + C * IV)              # grad_out, grid, in
+        if a[3]:
+            b += 4 * N * C * IV                              # grad_in
+        if a[4]:
+            b += 4 * N * nd * OV                             # grad_grid
+        return b
+    if name == "advchain_affine_warp_fwd":
+        N, C, nd = a[3], a[4], a[5]
+        return 8 * N * C * _prod(_arr(a[6], nd))
+    if name == "advchain_affine_warp_bwd":
+        N, C, nd = a[6], a[7], a[8]
+        V = _prod(_arr(a[9], nd))
+        return 4 * N * C * V * (2 + (1 if a[3] else 0))
+    if name == "advchain_gauss_axis":
+        planes, nd = a[3], a[5]
+        return 8 * planes * _prod(_arr(a[6], nd))
+    return None
+
+
+def entry_label(name, a):
+    return name.replace("advchain_", "")
+
+
+# ------------------------------------------------------------------------------------------------
+def build_solver(wl, device, process_group=None):
+    from advchain_amd.augmentor import (AdvAffine, AdvBias, AdvMorph, AdvNoise,
+                                        ComposeAdversarialTransformSolver)
+    cls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
+    sd = len(wl["dims"])
+    chain = [cls[nm](spatial_dims=sd, config_dict=cfg, device=device)
+             for nm, cfg in transform_configs(wl["dims"], wl["batch"], wl["chain"], morph_div8=wl.get("anatomy", False))]
+    return ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
+                                             divergence_weights=[1.0, 0.5], process_group=process_group)
+
+
+def run_gpu(args, wl, rank, world, device):
+    import torch.distributed as dist
+    from advchain_amd import _lib
+    pg = dist.group.WORLD if world > 1 else None
+    sd = len(wl["dims"])
+    torch.manual_seed(1234 + rank)
+    data = torch.rand(wl["batch"], 1, *wl["dims"], device=device)
+    model = make_model(sd).to(device)
+    solver = build_solver(wl, device, pg)
+    kw = dict(n_iter=wl["n_iter"], step_sizes=1, power_iteration=False)
+    if wl.get("anatomy"):
+        kw.update(anatomy_mask_images=ellipsoid(wl["batch"], wl["dims"]).to(device), anatomy_reg_weight=50,
+                  volume_preserve_tolerance=5e-4)
+
+    def step():
+        return solver.adversarial_training(data=data, model=model, **kw)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = _lib.load()
+    # warm-up; the first warm-up step is instrumented on every entry point to find the dominant kernel
+    dominant = None
+    for i in range(max(1, args.warmup)):
+        if i == 0:
+            lib.records = []
+            with lib.timed():
+                step()
+            torch.cuda.synchronize()
+            tot = {}
+            for name, a, e0, e1 in lib.records:
+                if algorithmic_bytes(name, a) is None:
+                    continue
+                tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+            dominant = max(tot, key=tot.get) if tot else None
+            breakdown = {k.replace("advchain_", ""): round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+        else:
+            step()
+    # timed region: exactly K steps between barrier+sync; only the dominant entry point carries events
+    lib.records = []
+    sync()
+    t0 = time.perf_counter()
+    with lib.timed([dominant] if dominant else []):
+        for _ in range(args.steps):
+            step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    roof = None
+    if dominant and lib.records:
+        durs, bts = [], []
+        for name, a, e0, e1 in lib.records:
+            durs.append(e0.elapsed_time(e1) * 1e-3)
+            bts.append(algorithmic_bytes(name, a))
+        avg_t = sum(durs) / len(durs)
+        avg_b = sum(bts) / len(bts)
+        achieved = avg_b / avg_t / 1e9
+        roof = {"bound": "hbm", "kernel": dominant.replace("advchain_", ""), "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
+                "algorithmic_bytes_per_launch": int(avg_b)}
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, roof, breakdown
+
+
+def grid_sample3d_roofline(device, reps=20):
+    """North-star kernel: 3D trilinear grid_sample fwd+bwd at 4x1x128x128x64 on an AdvMorph field."""
+    from advchain_amd import ops
+    from advchain_amd.augmentor import AdvMorph
+    dims = (128, 128, 64)
+    ds = [4, 1] + list(dims)
+    t = AdvMorph(spatial_dims=3, config_dict=dict(epsilon=1.5, data_size=ds, vector_size=[8, 8, 32]), device=device)
+    torch.manual_seed(0)
+    t.init_parameters()
+    with torch.no_grad():
+        q = t._field(1.0).contiguous()
+    x = torch.rand(*ds, device=device)
+    go = torch.rand(*ds, device=device)
+    for _ in range(3):
+        out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True)
+    ef = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
+    for _ in range(reps):
+        gin = torch.zeros_like(x)
+        ggrid = torch.empty_like(q)
+        ef[0].record()
+        out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        ef[1].record()
+        from advchain_amd import _lib
+        _lib.check(_lib.load().advchain_grid_sample_bwd(ops._ptr(go), ops._ptr(x), ops._ptr(q), ops._ptr(gin),
+                                                        ops._ptr(ggrid), 4, 1, 3, _lib.dims_array(dims),
+                                                        _lib.dims_array(dims), 0, 0, 1, ops._stream()), "bwd")
+        ef[2].record()
+        torch.cuda.synchronize()
+        tf += ef[0].elapsed_time(ef[1]) * 1e-3
+        tb += ef[1].elapsed_time(ef[2]) * 1e-3
+    tf, tb = tf / reps, tb / reps
+    nv = 4 * 128 * 128 * 64
+    bf, bb = 20 * nv, 36 * nv
+    return {"bound": "hbm", "kernel": "grid_sample3d fwd+bwd @4x1x128x128x64 (C=1, zeros, AdvMorph field)",
+            "achieved": round((bf + bb) / (tf + tb) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4), "fwd_us": round(tf * 1e6, 2),
+            "bwd_us": round(tb * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "bwd_GBs": round(bb / tb / 1e9, 1),
+            "algorithmic_bytes": bf + bb, "note": "bwd excludes the grad_in memset"}
+
+
+def cpu_baseline(wl, name):
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
+    from oracle import advchain_oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    sd = len(wl["dims"])
+    if sd == 2:
+        batch, n_iter = min(wl["batch"], 16), wl["n_iter"]
+    else:
+        batch, n_iter = 1, 1
+    cls = {"noise": O.OracleNoise, "bias": O.OracleBias, "morph": O.OracleMorph, "affine": O.OracleAffine}
+    chain = [cls[nm](sd, cfg) for nm, cfg in transform_configs(wl["dims"], batch, wl["chain"],
+                                                                morph_div8=wl.get("anatomy", False))]
+    torch.manual_seed(0)
+    data = torch.rand(batch, 1, *wl["dims"])
+    model = make_model(sd)
+    solver = O.OracleSolver(chain)
+    t0 = time.perf_counter()
+    solver.adversarial_training(data=data, model=model, n_iter=n_iter, step_sizes=1)
+    dt = time.perf_counter() - t0
+    # scale to the workload's n_iter: cost ~ (n_iter ascent steps + 1 final pass ~ 0.4 step)
+    scale = (wl["n_iter"] + 0.4) / (n_iter + 0.4)
+    return {"value": round(batch / (dt * scale), 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d image(s), %d of %d ascent steps (+ final pass) of %s in %.1f s; scaled linearly in steps"
+                      % (batch, n_iter, wl["n_iter"], name, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU path for the product kernels)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    wl = WORKLOADS[args.workload]
+    elapsed, roof, breakdown = run_gpu(args, wl, rank, world, device)
+    if rank == 0:
+        images = wl["batch"] * world * args.steps
+        out = {
+            "metric": "augmented images/sec (N adv steps, chain=noise+bias+morph+affine)",
+            "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "global_batch": wl["batch"] * world,
+                       "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
+                       "model": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},
+            "roofline": roof,
+            "kernel_time_ms_first_step": breakdown,
+        }
+        if world == 1:
+            out["roofline_grid_sample3d"] = grid_sample3d_roofline(device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(wl, args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

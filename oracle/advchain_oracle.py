@@ -115,8 +115,9 @@ def field_exponentiation(u, nb_steps=8):
     return phi - phi0, nb_steps
 
 
-def demons_compose(duv, dims):
-    """Low-res velocity (N,d,v...) -> clamped sampling grid (N,d,*dims).  adv_morph.py:454-491 (Q4)."""
+def demons_compose(duv, dims, final_clamp=True):
+    """Low-res velocity (N,d,v...) -> clamped sampling grid (N,d,*dims).  adv_morph.py:454-491 (Q4).
+    ``final_clamp=False`` (test aid) stops before the last torch.clamp of adv_morph.py:490."""
     d = len(dims)
     base = identity_grid(duv.shape[0], dims, duv.device)
     duv = gaussian_smooth(duv)
@@ -125,7 +126,7 @@ def demons_compose(duv, dims):
     offsets, _ = field_exponentiation(duv, 8)
     composed = compose_fields(base, offsets + base)
     composed = gaussian_smooth(composed - base) + base
-    return torch.clamp(composed, -1, 1)
+    return torch.clamp(composed, -1, 1) if final_clamp else composed
 
 
 def _warp_with_padding(data, grid_nhwc, interp, padding_mode):
