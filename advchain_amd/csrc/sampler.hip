@@ -7,103 +7,35 @@
 //   advchain_affine_warp_{fwd,bwd}   <- F.affine_grid + F.grid_sample, reference adv_affine.py:289-314
 //                                       (grid evaluated in registers, never materialised)
 //
-// All are HBM-bound gather/scatter kernels: one thread owns VEC consecutive output voxels along the
-// fastest axis (16-byte loads/stores when VEC == 4), gathers its 2^d corners through L1/L2 (near-
-// identity warps keep them in the same or neighbouring cache lines) and, in backward, scatters with
-// hardware fp32 atomics.  No MFMA: there is no contraction here.
-#include "common.h"
+// All are HBM-bound gather/scatter kernels.  One thread owns UNR output voxels spaced one workgroup apart
+// (voxel k of thread t = base + k*256 + t): every load/gather/store instruction of a wave then touches 64
+// consecutive voxels (256 contiguous bytes for near-identity warps -- measured 1.4-1.9x faster than 16-byte
+// per-lane ownership, whose gathers stride 16 B across lanes), while the UNR independent chains per thread
+// supply the memory-level parallelism a dependent grid -> gather -> store sequence lacks.  Backward scatters
+// go through the LDS-tiled owner-computes kernel (scatter_tiled.hip); the global-atomic kernels here are the
+// fallback for resampling / nearest.  No MFMA: there is no contraction here.
+#include <stdlib.h>
+#include "sampler_common.h"
 
 namespace advchain {
 
-template <int DIM, int PAD>
-struct Taps {
-  AxisTap x, y, z;
-  __device__ __forceinline__ void build(float gx, float gy, float gz, const Dims& d) {
-    x = make_tap<PAD>(gx, d.s2);
-    y = make_tap<PAD>(gy, d.s1);
-    if (DIM == 3) z = make_tap<PAD>(gz, d.s0);
-    else { z.i0 = 0; z.w0 = 1.f; z.w1 = 0.f; z.mult = 0.f; z.v0 = true; z.v1 = false; }
-  }
-  __device__ __forceinline__ bool ok(int cz, int cy, int cx) const {
-    return (cx ? x.v1 : x.v0) && (cy ? y.v1 : y.v0) && (DIM == 3 ? (cz ? z.v1 : z.v0) : true);
-  }
-  __device__ __forceinline__ int off(int cz, int cy, int cx, const Dims& d) const {
-    return ((z.i0 + cz) * d.s1 + (y.i0 + cy)) * d.s2 + (x.i0 + cx);
-  }
-  __device__ __forceinline__ float wx(int c) const { return c ? x.w1 : x.w0; }
-  __device__ __forceinline__ float wy(int c) const { return c ? y.w1 : y.w0; }
-  __device__ __forceinline__ float wz(int c) const { return c ? z.w1 : z.w0; }
-  __device__ __forceinline__ float w(int cz, int cy, int cx) const {
-    float r = wx(cx) * wy(cy);
-    if (DIM == 3) r *= wz(cz);
-    return r;
-  }
-};
-
-template <int DIM, int PAD>
-__device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
-  float acc = 0.f;
+// strided ownership: element k of a thread lives at p[k * kBlock]; `n` = number of valid elements
+template <int UNR>
+__device__ __forceinline__ void load_str(const float* __restrict__ p, int n, float (&r)[UNR]) {
 #pragma unroll
-  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
-#pragma unroll
-    for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-      for (int cx = 0; cx < 2; ++cx) {
-        if (t.ok(cz, cy, cx)) acc += in[t.off(cz, cy, cx, d)] * t.w(cz, cy, cx);
-      }
-  return acc;
+  for (int k = 0; k < UNR; ++k) r[k] = k < n ? p[k * kBlock] : 0.f;
 }
-
-// scatter go*w into gin and accumulate d(out)/d(unnormalised coordinate) * go into (ax, ay, az)
-template <int DIM, int PAD, bool NEED_GIN, bool NEED_GGRID>
-__device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, float* __restrict__ gin, float go,
-                                                  const Taps<DIM, PAD>& t, const Dims& d, float& ax, float& ay,
-                                                  float& az) {
+template <int UNR>
+__device__ __forceinline__ void store_str(float* __restrict__ p, int n, const float (&r)[UNR]) {
 #pragma unroll
-  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
-#pragma unroll
-    for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-      for (int cx = 0; cx < 2; ++cx) {
-        if (t.ok(cz, cy, cx)) {
-          const int o = t.off(cz, cy, cx, d);
-          if (NEED_GIN) atomic_add_f32(gin + o, t.w(cz, cy, cx) * go);
-          if (NEED_GGRID) {
-            const float val = in[o];
-            if (DIM == 3) {
-              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
-              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
-              az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
-            } else {
-              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
-              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
-            }
-          }
-        }
-      }
+  for (int k = 0; k < UNR; ++k)
+    if (k < n) p[k * kBlock] = r[k];
 }
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&r)[VEC]) {
-  if constexpr (VEC == 4) {
-    const float4 q = *reinterpret_cast<const float4*>(p);
-    r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) r[k] = p[k];
-  }
+__device__ __forceinline__ int active_count(int64_t v0, int64_t total, int unr) {
+  if (v0 >= total) return 0;
+  const int64_t left = (total - v0 + kBlock - 1) / kBlock;
+  return left < unr ? (int)left : unr;
 }
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
-  if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
-  } else {
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) p[k] = r[k];
-  }
-}
-
-__device__ __forceinline__ float clamp_unit(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
 // =============================================================================================
 // generic grid_sample with a planar grid
@@ -114,13 +46,14 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
                   Dims id, Dims od, int clamp_grid) {
   const int64_t IV = id.voxels(), OV = od.voxels();
   const int n = blockIdx.y;
-  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  if (v >= OV) return;
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, OV, VEC);
+  if (na == 0) return;
   const float* g = grid + (int64_t)n * DIM * OV + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_vec<VEC>(g, gx);
-  load_vec<VEC>(g + OV, gy);
-  if (DIM == 3) load_vec<VEC>(g + 2 * OV, gz);
+  load_str<VEC>(g, na, gx);
+  load_str<VEC>(g + OV, na, gy);
+  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, gz);
   const float* inn = in + (int64_t)n * C * IV;
   float* outn = out + (int64_t)n * C * OV + v;
   if (INTERP == INTERP_LINEAR) {
@@ -134,7 +67,7 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD>(inn + (int64_t)c * IV, t[k], id);
-      store_vec<VEC>(outn + (int64_t)c * OV, r);
+      store_str<VEC>(outn + (int64_t)c * OV, na, r);
     }
   } else {
     int off[VEC];
@@ -153,7 +86,7 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = ok[k] ? inn[(int64_t)c * IV + off[k]] : 0.f;
-      store_vec<VEC>(outn + (int64_t)c * OV, r);
+      store_str<VEC>(outn + (int64_t)c * OV, na, r);
     }
   }
 }
@@ -164,13 +97,14 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
                   float* __restrict__ gin, float* __restrict__ ggrid, int C, Dims id, Dims od, int clamp_grid) {
   const int64_t IV = id.voxels(), OV = od.voxels();
   const int n = blockIdx.y;
-  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  if (v >= OV) return;
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, OV, VEC);
+  if (na == 0) return;
   const float* g = grid + (int64_t)n * DIM * OV + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_vec<VEC>(g, gx);
-  load_vec<VEC>(g + OV, gy);
-  if (DIM == 3) load_vec<VEC>(g + 2 * OV, gz);
+  load_str<VEC>(g, na, gx);
+  load_str<VEC>(g + OV, na, gy);
+  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, gz);
   const float* inn = in + (int64_t)n * C * IV;
   float* ginn = NEED_GIN ? gin + (int64_t)n * C * IV : nullptr;
   const float* gon = gout + (int64_t)n * C * OV + v;
@@ -192,7 +126,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
     }
     for (int c = 0; c < C; ++c) {
       float go[VEC];
-      load_vec<VEC>(gon + (int64_t)c * OV, go);
+      load_str<VEC>(gon + (int64_t)c * OV, na, go);
 #pragma unroll
       for (int k = 0; k < VEC; ++k)
         sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GGRID>(inn + (int64_t)c * IV, NEED_GIN ? ginn + (int64_t)c * IV : nullptr,
@@ -203,14 +137,14 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = pass_x[k] ? t[k].x.mult * ax[k] : 0.f;
-      store_vec<VEC>(gg, r);
+      store_str<VEC>(gg, na, r);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = pass_y[k] ? t[k].y.mult * ay[k] : 0.f;
-      store_vec<VEC>(gg + OV, r);
+      store_str<VEC>(gg + OV, na, r);
       if (DIM == 3) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) r[k] = pass_z[k] ? t[k].z.mult * az[k] : 0.f;
-        store_vec<VEC>(gg + 2 * OV, r);
+        store_str<VEC>(gg + 2 * OV, na, r);
       }
     }
   } else {
@@ -221,9 +155,9 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       const int ix = nearest_index<PAD>(gx[k], id.s2, vx);
       const int iy = nearest_index<PAD>(gy[k], id.s1, vy);
       const int iz = DIM == 3 ? nearest_index<PAD>(gz[k], id.s0, vz) : 0;
-      if (NEED_GIN && vx && vy && vz) {
+      if (NEED_GIN && k < na && vx && vy && vz) {
         const int off = (iz * id.s1 + iy) * id.s2 + ix;
-        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * IV + off, gon[(int64_t)c * OV + k]);
+        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * IV + off, gon[(int64_t)c * OV + k * kBlock]);
       }
     }
     if (NEED_GGRID) {  // nearest has zero gradient w.r.t. the grid (ATen does the same)
@@ -231,7 +165,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = 0.f;
-      for (int a = 0; a < DIM; ++a) store_vec<VEC>(gg + (int64_t)a * OV, r);
+      for (int a = 0; a < DIM; ++a) store_str<VEC>(gg + (int64_t)a * OV, na, r);
     }
   }
 }
@@ -248,13 +182,14 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
                    Dims d, int final_mode) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
-  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  if (v >= V) return;
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, V, VEC);
+  if (na == 0) return;
   const float* pn = phi + (int64_t)n * DIM * V;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_vec<VEC>(pn + v, gx);
-  load_vec<VEC>(pn + V + v, gy);
-  if (DIM == 3) load_vec<VEC>(pn + 2 * V + v, gz);
+  load_str<VEC>(pn + v, na, gx);
+  load_str<VEC>(pn + V + v, na, gy);
+  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, gz);
   Taps<DIM, PAD_BORDER> t[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
@@ -266,10 +201,10 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
     for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD_BORDER>(pn + (int64_t)c * V, t[k], d);
     if (final_mode == 1) {
       float p0[VEC];
-      load_vec<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, p0);
+      load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, p0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const int64_t vv = v + k;
+        const int64_t vv = v + (int64_t)k * kBlock;
         int idx;
         int S;
         if (c == 0) { idx = (int)(vv % d.s2); S = d.s2; }
@@ -278,7 +213,7 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
         r[k] = (r[k] - p0[k]) + lin_coord(idx, S);
       }
     }
-    store_vec<VEC>(on + (int64_t)c * V, r);
+    store_str<VEC>(on + (int64_t)c * V, na, r);
   }
 }
 
@@ -288,15 +223,16 @@ __global__ void __launch_bounds__(kBlock)
 k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
-  const int64_t v = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  if (v >= V) return;
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, V, VEC);
+  if (na == 0) return;
   const float* pn = phi + (int64_t)n * DIM * V;
   float* gpn = gphi + (int64_t)n * DIM * V;
   const float* gon = gout + (int64_t)n * DIM * V + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_vec<VEC>(pn + v, gx);
-  load_vec<VEC>(pn + V + v, gy);
-  if (DIM == 3) load_vec<VEC>(pn + 2 * V + v, gz);
+  load_str<VEC>(pn + v, na, gx);
+  load_str<VEC>(pn + V + v, na, gy);
+  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, gz);
   Taps<DIM, PAD_BORDER> t[VEC];
   float ax[VEC], ay[VEC], az[VEC];
 #pragma unroll
@@ -307,7 +243,7 @@ k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi
 #pragma unroll
   for (int c = 0; c < DIM; ++c) {
     float go[VEC];
-    load_vec<VEC>(gon + (int64_t)c * V, go);
+    load_str<VEC>(gon + (int64_t)c * V, na, go);
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
       sample_linear_bwd<DIM, PAD_BORDER, true, true>(pn + (int64_t)c * V, gpn + (int64_t)c * V, go[k], t[k], d, ax[k],
@@ -316,9 +252,11 @@ k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi
   // the coordinate path lands on the same tensor (input == grid)
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
-    if (t[k].x.mult != 0.f) atomic_add_f32(gpn + v + k, t[k].x.mult * ax[k]);
-    if (t[k].y.mult != 0.f) atomic_add_f32(gpn + V + v + k, t[k].y.mult * ay[k]);
-    if (DIM == 3 && t[k].z.mult != 0.f) atomic_add_f32(gpn + 2 * V + v + k, t[k].z.mult * az[k]);
+    if (k >= na) continue;
+    const int64_t vk = v + (int64_t)k * kBlock;
+    if (t[k].x.mult != 0.f) atomic_add_f32(gpn + vk, t[k].x.mult * ax[k]);
+    if (t[k].y.mult != 0.f) atomic_add_f32(gpn + V + vk, t[k].y.mult * ay[k]);
+    if (DIM == 3 && t[k].z.mult != 0.f) atomic_add_f32(gpn + 2 * V + vk, t[k].z.mult * az[k]);
   }
 }
 
@@ -457,10 +395,23 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, float* __re
 
 using namespace advchain;
 
+// scatter_tiled.hip
+int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
+                                  float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
+                                  int32_t* workspace, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// UNR = 4 independent voxels per thread once the volume fills the chip; ADVCHAIN_UNR1 forces 1 (A/B tests)
+// Measured on MI355X (tools/kernel_bench.py): 2D gathers gain 1.2x from 4 chains per thread; in 3D the 4 chains
+// sit 4 rows apart in 2 z-planes x C channels and thrash the 32 KiB L1, so one voxel per thread wins (1.3x).
+static inline bool use_unroll(int64_t voxels, int ndim) {
+  static const bool force1 = getenv("ADVCHAIN_UNR1") != nullptr;
+  static const bool force4 = getenv("ADVCHAIN_UNR4") != nullptr;
+  if (force4) return true;
+  return !force1 && ndim == 2 && voxels >= 4 * kBlock;
+}
 
 #define DISPATCH_PAD(PADV, ...)                                            \
   switch (PADV) {                                                          \
@@ -473,7 +424,7 @@ template <int DIM>
 static int launch_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, Dims id, Dims od,
                                   int interp, int padding, int clamp_grid, hipStream_t st) {
   const int64_t OV = od.voxels();
-  const bool vec4 = (OV % 4 == 0) && aligned16(grid) && aligned16(out);
+  const bool vec4 = use_unroll(OV, DIM);
   const int vec = vec4 ? 4 : 1;
   dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
   DISPATCH_PAD(padding, {
@@ -502,7 +453,7 @@ static int launch_grid_sample_bwd(const float* gout, const float* in, const floa
                                   int64_t N, int64_t C, Dims id, Dims od, int interp, int padding, int clamp_grid,
                                   hipStream_t st) {
   const int64_t OV = od.voxels();
-  const bool vec4 = (OV % 4 == 0) && aligned16(grid) && aligned16(gout) && (!ggrid || aligned16(ggrid));
+  const bool vec4 = use_unroll(OV, DIM);
   const int vec = vec4 ? 4 : 1;
   dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
   DISPATCH_PAD(padding, {
@@ -560,8 +511,9 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
 }
 
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
-                             float* grad_grid, int64_t N, int64_t C, int ndim, const int64_t* in_dims,
-                             const int64_t* out_dims, int interp, int padding, int clamp_grid, void* stream) {
+                             float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
+                             const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
+                             void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && in && grid, "grid_sample_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(grad_in || grad_grid, "grid_sample_bwd: nothing to compute");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_bwd: bad dims");
@@ -571,6 +523,10 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
   if (N == 0) return ADVCHAIN_OK;
   const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_bwd: per-sample volume too large");
+  const bool same = id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2;
+  if (workspace && grad_in && same && interp == INTERP_LINEAR)  // LDS-tiled owner-computes scatter (no atomics, no pre-zero)
+    return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
+                                         clamp_grid, workspace, (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
@@ -585,7 +541,7 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
-  const bool vec4 = (V % 4 == 0) && aligned16(phi) && aligned16(out) && (!phi0 || aligned16(phi0));
+  const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (ndim == 3) {
@@ -599,8 +555,8 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   return ADVCHAIN_OK;
 }
 
-int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int64_t N, int ndim,
-                              const int64_t* dims, void* stream) {
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int64_t N,
+                              int ndim, const int64_t* dims, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && phi && grad_phi, "compose_self_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_bwd: bad N");
@@ -608,7 +564,10 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
-  const bool vec4 = (V % 4 == 0) && aligned16(phi) && aligned16(grad_out);
+  if (workspace)
+    return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
+                                         workspace, (hipStream_t)stream);
+  const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (ndim == 3) {

@@ -1,0 +1,98 @@
+// Device helpers shared by the sampler kernels (sampler.hip, scatter_tiled.hip).
+#pragma once
+#include "common.h"
+
+namespace advchain {
+
+template <int DIM, int PAD>
+struct Taps {
+  AxisTap x, y, z;
+  __device__ __forceinline__ void build(float gx, float gy, float gz, const Dims& d) {
+    x = make_tap<PAD>(gx, d.s2);
+    y = make_tap<PAD>(gy, d.s1);
+    if (DIM == 3) z = make_tap<PAD>(gz, d.s0);
+    else { z.i0 = 0; z.w0 = 1.f; z.w1 = 0.f; z.mult = 0.f; z.v0 = true; z.v1 = false; }
+  }
+  __device__ __forceinline__ bool ok(int cz, int cy, int cx) const {
+    return (cx ? x.v1 : x.v0) && (cy ? y.v1 : y.v0) && (DIM == 3 ? (cz ? z.v1 : z.v0) : true);
+  }
+  __device__ __forceinline__ int off(int cz, int cy, int cx, const Dims& d) const {
+    return ((z.i0 + cz) * d.s1 + (y.i0 + cy)) * d.s2 + (x.i0 + cx);
+  }
+  __device__ __forceinline__ float wx(int c) const { return c ? x.w1 : x.w0; }
+  __device__ __forceinline__ float wy(int c) const { return c ? y.w1 : y.w0; }
+  __device__ __forceinline__ float wz(int c) const { return c ? z.w1 : z.w0; }
+  __device__ __forceinline__ float w(int cz, int cy, int cx) const {
+    float r = wx(cx) * wy(cy);
+    if (DIM == 3) r *= wz(cz);
+    return r;
+  }
+};
+
+template <int DIM, int PAD>
+__device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
+  float acc = 0.f;
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        if (t.ok(cz, cy, cx)) acc += in[t.off(cz, cy, cx, d)] * t.w(cz, cy, cx);
+      }
+  return acc;
+}
+
+// scatter go*w into gin and accumulate d(out)/d(unnormalised coordinate) * go into (ax, ay, az)
+template <int DIM, int PAD, bool NEED_GIN, bool NEED_GGRID>
+__device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, float* __restrict__ gin, float go,
+                                                  const Taps<DIM, PAD>& t, const Dims& d, float& ax, float& ay,
+                                                  float& az) {
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        if (t.ok(cz, cy, cx)) {
+          const int o = t.off(cz, cy, cx, d);
+          if (NEED_GIN) atomic_add_f32(gin + o, t.w(cz, cy, cx) * go);
+          if (NEED_GGRID) {
+            const float val = in[o];
+            if (DIM == 3) {
+              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
+              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
+              az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
+            } else {
+              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
+              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
+            }
+          }
+        }
+      }
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r[k] = p[k];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) p[k] = r[k];
+  }
+}
+
+__device__ __forceinline__ float clamp_unit(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+
+}  // namespace advchain

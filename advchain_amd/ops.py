@@ -59,14 +59,25 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
     return out
 
 
+TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
+
+
+def _scatter_workspace(N, dims, device):
+    n = _lib.load().advchain_scatter_workspace(N, len(dims), _lib.dims_array(dims))
+    return torch.empty(n, device=device, dtype=torch.int32)
+
+
 def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, need_ggrid):
     N, C = inp.shape[:2]
     nd = inp.dim() - 2
-    gin = torch.zeros_like(inp) if need_gin else None
+    tiled = TILED_SCATTER and need_gin and interp == 0 and tuple(inp.shape[2:]) == tuple(grid.shape[2:])
+    ws = _scatter_workspace(N, inp.shape[2:], inp.device) if tiled else None
+    gin = (torch.empty_like(inp) if tiled else torch.zeros_like(inp)) if need_gin else None
     ggrid = torch.empty_like(grid) if need_ggrid else None
-    _lib.check(_lib.load().advchain_grid_sample_bwd(_ptr(gout), _ptr(inp), _ptr(grid), _ptr(gin), _ptr(ggrid), N, C, nd,
-                                                    _lib.dims_array(inp.shape[2:]), _lib.dims_array(grid.shape[2:]),
-                                                    interp, padding, int(clamp_grid), _stream()), "grid_sample_bwd")
+    _lib.check(_lib.load().advchain_grid_sample_bwd(_ptr(gout), _ptr(inp), _ptr(grid), _ptr(gin), _ptr(ggrid), _ptr(ws),
+                                                    N, C, nd, _lib.dims_array(inp.shape[2:]),
+                                                    _lib.dims_array(grid.shape[2:]), interp, padding, int(clamp_grid),
+                                                    _stream()), "grid_sample_bwd")
     return gin, ggrid
 
 
@@ -80,11 +91,13 @@ def raw_compose_self_fwd(phi, phi0=None, final_mode=0):
     return out
 
 
-def raw_compose_self_bwd(gout, phi):
+def raw_compose_self_bwd(gout, phi, ws=None):
     N = phi.shape[0]
     nd = phi.dim() - 2
-    gphi = torch.zeros_like(phi)
-    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), N, nd,
+    if TILED_SCATTER and ws is None:
+        ws = _scatter_workspace(N, phi.shape[2:], phi.device)
+    gphi = torch.empty_like(phi) if ws is not None else torch.zeros_like(phi)
+    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), N, nd,
                                                      _lib.dims_array(phi.shape[2:]), _stream()), "compose_self_bwd")
     return gphi
 
@@ -384,8 +397,9 @@ class _DemonsField(torch.autograd.Function):
         gq = _dev(gq, "grad")
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
+        ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
         for phi in reversed(phis):
-            g = raw_compose_self_bwd(g, phi)
+            g = raw_compose_self_bwd(g, phi, ws)
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)

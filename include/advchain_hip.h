@@ -50,11 +50,15 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding,
                              int clamp_grid, void* stream);
 /* replaces: autograd grid_sampler_{2,3}d_backward for the call above.
- * grad_in (N,C,in_dims) must be pre-zeroed (scatter-add); grad_grid (N,ndim,out_dims) is
- * overwritten.  Either may be NULL.                                                         */
+ * grad_in (N,C,in_dims) and grad_grid (N,ndim,out_dims); either may be NULL.  grad_grid is overwritten.
+ * With `workspace` (int32[advchain_scatter_workspace(N,ndim,dims)], linear interp, in_dims == out_dims)
+ * grad_in is produced by the LDS-tiled owner-computes scatter and is simply overwritten; with
+ * workspace == NULL the global-atomic path is used and grad_in must be pre-zeroed.               */
+int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
-                             float* grad_grid, int64_t N, int64_t C, int ndim, const int64_t* in_dims,
-                             const int64_t* out_dims, int interp, int padding, int clamp_grid, void* stream);
+                             float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
+                             const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
+                             void* stream);
 
 /* ---- scaling-and-squaring step ---------------------------------------------------------
  * replaces: applyComposition{2,3}D(phi, phi) = F.grid_sample(phi, phi^T, 'border',
@@ -65,9 +69,10 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
  * phi, out, phi0: (N, ndim, dims).                                                          */
 int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
                               const int64_t* dims, int final_mode, void* stream);
-/* grad_phi (pre-zeroed) receives both the value path (scatter) and the coordinate path.      */
-int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int64_t N, int ndim,
-                              const int64_t* dims, void* stream);
+/* grad_phi receives both the value path (scatter) and the coordinate path; overwritten when a
+ * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).       */
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int64_t N,
+                              int ndim, const int64_t* dims, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),

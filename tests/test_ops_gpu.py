@@ -26,6 +26,16 @@ def rel(a, b):
     return maxdiff(a, b) / max(1e-6, float(b.abs().max()))
 
 
+@pytest.fixture(params=["tiled", "atomic"])
+def scatter_path(request):
+    """Both backward scatter implementations: LDS-tiled owner-computes (default) and global atomics."""
+    ops = _ops()
+    old = ops.TILED_SCATTER
+    ops.TILED_SCATTER = request.param == "tiled"
+    yield request.param
+    ops.TILED_SCATTER = old
+
+
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["2d", "3d"])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
@@ -49,8 +59,9 @@ def test_grid_sample_golden(tag, pad):
 @pytest.mark.parametrize("dims,C", [((17, 23), 3), ((16, 24), 1), ((7, 9, 11), 2), ((8, 12, 16), 4)])
 @pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
 @pytest.mark.parametrize("interp", ["bilinear", "nearest"])
-def test_grid_sample_vs_aten_cpu(dims, C, pad, interp):
-    """Seeded inputs incl. out-of-range and on-border coordinates; both the float4 and the scalar kernels."""
+def test_grid_sample_vs_aten_cpu(dims, C, pad, interp, scatter_path):
+    """Seeded inputs incl. out-of-range and on-border coordinates; both the float4 and the scalar kernels.
+    Random positions are far from the identity: every deposit of the tiled path goes through its overflow list."""
     ops = _ops()
     d = len(dims)
     inp = rand((2, C) + dims, 1)
@@ -73,6 +84,34 @@ def test_grid_sample_vs_aten_cpu(dims, C, pad, interp):
         assert float(g2.grad.abs().max()) == 0.0
 
 
+def test_grid_sample_near_identity_tiles(scatter_path):
+    """Near-identity warp on a volume spanning several tiles (+ displacements beyond the halo on a few voxels)."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    for dims, C in (((20, 24, 72), 2), ((70, 150), 3)):
+        d = len(dims)
+        grid = O.identity_grid(2, dims) + 0.04 * rand((2, d) + dims, 81)
+        grid.view(-1)[::97] += 0.5            # outliers: well beyond the halo
+        inp = rand((2, C) + dims, 82)
+        w = rand((2, C) + dims, 83)
+        a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+        ref = F.grid_sample(a, O._to_sampler_layout(torch.clamp(g, -1, 1)), padding_mode="zeros", align_corners=True)
+        (ref * w).sum().backward()
+        a2, g2 = inp.to(DEV).requires_grad_(True), grid.to(DEV).requires_grad_(True)
+        out = ops.grid_sample(a2, g2, "bilinear", "zeros", clamp_grid=True)
+        (out * w.to(DEV)).sum().backward()
+        assert maxdiff(out.cpu(), ref) < TOL
+        assert maxdiff(a2.grad.cpu(), a.grad) < TOL
+        assert maxdiff(g2.grad.cpu(), g.grad) < 1e-4
+        phi = (O.identity_grid(2, dims) + 0.03 * rand((2, d) + dims, 84)).contiguous()
+        phi.view(-1)[::131] -= 0.4
+        p = phi.clone().requires_grad_(True)
+        wp = rand((2, d) + dims, 85)
+        (O.compose_fields(p, p) * wp).sum().backward()
+        gphi = ops.raw_compose_self_bwd(wp.to(DEV), phi.to(DEV))
+        assert maxdiff(gphi.cpu(), p.grad) < 1e-4
+
+
 def test_grid_sample_clamp_grid_and_resample():
     """clamp_grid == torch.clamp(grid,-1,1) before sampling (value and sub-gradient); in/out sizes may differ."""
     ops = _ops()
@@ -91,7 +130,7 @@ def test_grid_sample_clamp_grid_and_resample():
 
 
 @pytest.mark.parametrize("dims", [(20, 28), (19, 21), (8, 12, 16), (7, 9, 5)])
-def test_compose_self(dims):
+def test_compose_self(dims, scatter_path):
     from oracle import advchain_oracle as O
     ops = _ops()
     d = len(dims)

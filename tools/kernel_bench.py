@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark (GPU): every hot C-ABI entry at the BASELINE shapes, HIP-event timed on the
+launch stream, reported against its algorithmic bytes.  Also times the stock ATen-HIP op and a
+device copy of the same size for calibration.
+
+    python tools/kernel_bench.py [--shape 3d|2d] [--reps 20] [--only name]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="3d")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--batch", type=int, default=None)
+    args = ap.parse_args()
+    from advchain_amd import bands, ops
+    from advchain_amd.augmentor import AdvMorph
+    dev = torch.device("cuda")
+    if args.shape == "3d":
+        N, dims, vs = args.batch or 4, (128, 128, 64), [8, 8, 32]
+    else:
+        N, dims, vs = args.batch or 32, (256, 256), [16, 16]
+    d = len(dims)
+    V = 1
+    for s in dims:
+        V *= s
+    NV = N * V
+    torch.manual_seed(0)
+    t = AdvMorph(spatial_dims=d, config_dict=dict(epsilon=1.5, data_size=[N, 1] + list(dims), vector_size=vs), device=dev)
+    t.init_parameters()
+    with torch.no_grad():
+        q = t._field(1.0).contiguous()
+    tabs = t._tables
+    phi = ops.raw_tp_interp(ops.raw_gauss(t.param, d, pre=1, scale=1.5), tabs, d, add_identity=True, scale=1.0 / 256)
+    x1 = torch.rand(N, 1, *dims, device=dev)
+    x4 = torch.rand(N, 4, *dims, device=dev)
+    g1, g4, gq = torch.rand_like(x1), torch.rand_like(x4), torch.rand_like(q)
+    theta = (torch.eye(d, d + 1, device=dev).repeat(N, 1, 1) + 0.05 * torch.randn(N, d, d + 1, device=dev)).contiguous()
+    rows = []
+
+    def add(name, fn, nbytes):
+        if args.only and args.only not in name:
+            return
+        dt = timeit(fn, args.reps)
+        rows.append((name, dt * 1e6, nbytes / dt / 1e9, nbytes / 1e6))
+
+    add("copy %d ch (torch clone)" % d, lambda: q.clone(), 8 * d * NV)
+    add("copy 1 ch (torch clone)", lambda: x1.clone(), 8 * NV)
+    add("grid_sample fwd C=1", lambda: ops.raw_grid_sample_fwd(x1, q, 0, 0, True), 4 * NV * (2 + d))
+    add("grid_sample fwd C=4", lambda: ops.raw_grid_sample_fwd(x4, q, 0, 0, True), 4 * NV * (8 + d))
+    add("grid_sample bwd C=1 (gin+ggrid)", lambda: ops.raw_grid_sample_bwd(g1, x1, q, 0, 0, True, True, True), 4 * NV * (3 + 2 * d))
+    add("grid_sample bwd C=4 (gin+ggrid)", lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, True), 4 * NV * (12 + 2 * d))
+    add("grid_sample bwd C=1 (ggrid only)", lambda: ops.raw_grid_sample_bwd(g1, x1, q, 0, 0, True, False, True), 4 * NV * (2 + 2 * d))
+    add("grid_sample bwd C=4 (gin only)", lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, False), 4 * NV * (12 + d))
+    qq = q.permute(0, *range(2, 2 + d), 1).contiguous()
+    add("ATen F.grid_sample fwd C=1", lambda: F.grid_sample(x1, qq, align_corners=True), 4 * NV * (2 + d))
+    xr, qr = x1.clone().requires_grad_(True), qq.clone().requires_grad_(True)
+
+    def aten_fb():
+        o = F.grid_sample(xr, qr, align_corners=True)
+        torch.autograd.grad(o, (xr, qr), g1)
+    add("ATen F.grid_sample fwd+bwd C=1", aten_fb, 4 * NV * (5 + 3 * d))
+    add("compose_self fwd", lambda: ops.raw_compose_self_fwd(phi), 8 * d * NV)
+    add("compose_self bwd", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)
+    old = ops.TILED_SCATTER
+    ops.TILED_SCATTER = False
+    add("compose_self bwd (atomic path)", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)
+    ops.TILED_SCATTER = old
+    add("gauss %d passes (d ch, pre2/post1)" % d, lambda: ops.raw_gauss(q, d, pre=2, post=1), 8 * d * NV * d)
+    add("affine_warp fwd C=1", lambda: ops.affine_warp(x1, theta), 8 * NV)
+    add("affine_warp fwd C=4", lambda: ops.affine_warp(x4, theta), 32 * NV)
+    xa, ta = x4.clone().requires_grad_(True), theta.clone().requires_grad_(True)
+
+    def aff_fb():
+        o = ops.affine_warp(xa, ta)
+        torch.autograd.grad(o, (xa, ta), g4)
+    add("affine_warp fwd+bwd C=4", aff_fb, (32 + 48) * NV)
+    add("tp_interp (phi0 init)", lambda: ops.raw_tp_interp(t.param, tabs, d, add_identity=True, scale=1 / 256.), 4 * d * NV)
+    add("tp_adjoint (upsample bwd)", lambda: ops.raw_tp_adjoint(gq, tabs, gfull2=gq, scale=1 / 256.), 8 * d * NV)
+    add("axpy", lambda: ops.raw_axpy(x1, g1, 0.5), 12 * NV)
+    add("normalized_axpy", lambda: ops.normalized_axpy(x1, g1, 1.0), 20 * NV)
+    from advchain_amd.common.loss import calc_segmentation_consistency
+    pr = x4.clone().requires_grad_(True)
+    m1 = (torch.rand_like(x1) > 0.1).float().expand(-1, 4, *([-1] * d))
+
+    def loss_fb():
+        v = calc_segmentation_consistency(pr, g4, ['mse', 'contour'], [1.0, 0.5], mask=m1)
+        torch.autograd.grad(v, pr)
+    add("consistency loss fwd+bwd K=4", loss_fb, 4 * NV * (4 + 4 + 1 + 4))
+    print("shape %s N=%d dims=%s" % (args.shape, N, dims))
+    print("%-40s %10s %10s %10s" % ("kernel", "us", "GB/s(alg)", "MB(alg)"))
+    for r in rows:
+        print("%-40s %10.1f %10.1f %10.1f" % r)
+
+
+if __name__ == "__main__":
+    main()
