@@ -1,0 +1,128 @@
+"""TEST-ONLY operator backend: the signatures of ``advchain_amd.ops`` implemented with the CPU oracle's
+torch ops, so that the product's HOST logic (transform classes, solver control flow, band tables, loss
+normalisers, batch sharding) can be exercised on a machine without a GPU and under ``gloo``.
+
+It is installed by the ``cpu_ops`` fixture (monkeypatching module attributes) and never ships: the product
+itself has no CPU path and raises on CPU tensors."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import advchain_oracle as O
+
+
+def _planar_to_last(grid):
+    d = grid.dim() - 2
+    return grid.permute(0, *range(2, 2 + d), 1)
+
+
+def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
+    if clamp_grid:
+        grid = torch.clamp(grid, -1, 1)
+    mode = "nearest" if interp == "nearest" else "bilinear"
+    return F.grid_sample(inp, _planar_to_last(grid), mode=mode, padding_mode=padding_mode, align_corners=True)
+
+
+def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
+    mode = "nearest" if interp == "nearest" else "bilinear"
+    g = F.affine_grid(theta, inp.size(), align_corners=True)
+    return F.grid_sample(inp, g, mode=mode, padding_mode=padding_mode, align_corners=True)
+
+
+def affine_theta(param, cfg, param_scale, nd):
+    keys = (["rot", "scale_x", "scale_y", "shift_x", "shift_y"] if nd == 2 else
+            ["rot_x", "rot_y", "rot_z", "scale_x", "scale_y", "scale_z", "shift_x", "shift_y", "shift_z"])
+    th = O.affine_theta(param_scale * param, dict(zip(keys, cfg)), nd)
+    return th, O.affine_inverse(th)
+
+
+def axpy(x, y, a):
+    return x + a * y
+
+
+def normalized_axpy(base, x, step=1.0):
+    u = O.unit_normalize(x.detach())
+    return step * u if base is None else base.detach() + step * u
+
+
+def _tp_eval(coef, tables):
+    """Dense evaluation of the band tables (host copies): (N,C,g...) -> (N,C,S...)."""
+    mats = [torch.from_numpy(np.asarray(m)).to(coef.dtype) for m in tables.mats[3 - tables.ndim:]]
+    if tables.ndim == 2:
+        return torch.einsum("ncij,xi,yj->ncxy", coef, mats[0], mats[1])
+    return torch.einsum("ncijk,xi,yj,zk->ncxyz", coef, mats[0], mats[1], mats[2])
+
+
+def bias_apply(cp, data, tables, eps, use_log=True, cp_scale=1.0):
+    L = cp_scale * _tp_eval(cp, tables)
+    e = torch.exp(L) if use_log else 1 + L
+    field = 1 + torch.clamp(e - 1, -eps, eps)
+    return data * field, field.detach()
+
+
+def bias_field_only(cp, tables, eps, use_log=True, cp_scale=1.0):
+    return bias_apply(cp.detach(), torch.ones(1), tables, eps, use_log, cp_scale)[1]
+
+
+def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+    """adv_morph.py:454-491 without the final clamp; the 3D step-count norm may be reduced across ranks."""
+    dims = tuple(tables.full_dims)
+    d = len(dims)
+    base = O.identity_grid(vel.shape[0], dims)
+    u = O.gaussian_smooth(scale * vel)
+    u = F.interpolate(u, size=dims, mode="bilinear" if d == 2 else "trilinear", align_corners=False)
+    n = 8
+    if nsteps_rule:
+        ss = (u.detach().double() ** 2).sum().float().reshape(1)
+        if reduce_sumsq is not None:
+            ss = reduce_sumsq(ss)
+        norm = float(ss.sqrt())
+        while norm / (2.0 ** n) > 0.5:
+            n += 1
+    phi0 = base + u / (2.0 ** n)
+    phi = phi0
+    for _ in range(n):
+        phi = O.compose_fields(phi, phi)
+    composed = O.compose_fields(base, (phi - phi0) + base)
+    return O.gaussian_smooth(composed - base) + base
+
+
+def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
+    """[S_mse, S_edgeA, S_edgeB] raw sums as the HIP kernels define them (advchain_amd/csrc/loss.hip)."""
+    K = pred.shape[1]
+    d = pred.dim() - 2
+    P = torch.softmax(pred, dim=1)
+    T = ref if ref_is_prob else torch.softmax(ref, dim=1)
+    m = torch.ones_like(pred[:, :1]) if mask is None else mask
+    s0 = ((P * m - T * m) ** 2).sum()
+    sa = sb = torch.zeros(())
+    if want_edges and K > 1:
+        m0 = m[:, :1]
+        if d == 2:
+            ka = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]]).reshape(1, 1, 3, 3)
+            kb = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]]).reshape(1, 1, 3, 3)
+            conv = F.conv2d
+        else:
+            h = torch.tensor([1., 2., 1.])
+            hp = torch.tensor([1., 0., -1.])
+            ka = torch.einsum("i,j,k->ijk", h, hp, h).reshape(1, 1, 3, 3, 3)
+            kb = torch.einsum("i,j,k->ijk", h, h, hp).reshape(1, 1, 3, 3, 3)
+            conv = F.conv3d
+        D = (P - T)[:, 1:]
+        Dr = D.reshape(-1, 1, *D.shape[2:])
+        mr = m0.unsqueeze(1).expand(-1, K - 1, *m0.shape[1:]).reshape(-1, 1, *m0.shape[2:])
+        sa = ((conv(Dr, ka, padding=1) * mr) ** 2).sum()
+        sb = ((conv(Dr, kb, padding=1) * mr) ** 2).sum()
+    sums = torch.stack([s0, sa, sb])
+    return torch.dot(sums, torch.tensor(coef, dtype=sums.dtype)), sums.detach()
+
+
+PATCHED = ["grid_sample", "affine_warp", "affine_theta", "axpy", "normalized_axpy", "bias_apply", "bias_field_only",
+           "demons_field", "consistency_sums"]
+
+
+def install(monkeypatch):
+    from advchain_amd import ops
+    import tests.cpu_backend as me
+    for name in PATCHED:
+        monkeypatch.setattr(ops, name, getattr(me, name))
