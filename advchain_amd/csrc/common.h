@@ -138,6 +138,11 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem) {
   }
 }
 
+// Per-workgroup partial sums go to one of kSumSlots accumulators (slot = workgroup id mod kSumSlots): thousands of
+// atomics on ONE address serialise at ~10 ns each on MI355X; the consumer adds the slots up.
+constexpr int kSumSlots = 64;
+__device__ __forceinline__ int sum_slot() { return (int)((blockIdx.x + blockIdx.y * 7u) % kSumSlots); }
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   // hardware global_atomic_add_f32 (no CAS loop); device memory only
   unsafeAtomicAdd(p, v);

@@ -85,7 +85,7 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
   }
   if (sumsq) {
     block_sum<1>(sq, smem);
-    if (threadIdx.x == 0) atomic_add_f32(sumsq, sq[0]);
+    if (threadIdx.x == 0) atomic_add_f32(sumsq + sum_slot(), sq[0]);
   }
 }
 

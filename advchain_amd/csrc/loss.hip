@@ -67,7 +67,7 @@ k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, co
     }
   }
   block_sum<1>(acc, smem);
-  if (threadIdx.x == 0) atomic_add_f32(sums, acc[0]);
+  if (threadIdx.x == 0) atomic_add_f32(sums + sum_slot(), acc[0]);
 }
 
 template <int DIM>
@@ -114,8 +114,8 @@ k_edge_fwd(const float* __restrict__ D, const float* __restrict__ mask, float* _
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    atomic_add_f32(sums + 1, acc[0]);
-    atomic_add_f32(sums + 2, acc[1]);
+    atomic_add_f32(sums + kSumSlots + sum_slot(), acc[0]);
+    atomic_add_f32(sums + 2 * kSumSlots + sum_slot(), acc[1]);
   }
 }
 

@@ -267,14 +267,11 @@ template <int DIM>
 struct Theta { float m[DIM][DIM + 1]; };
 
 template <int DIM>
-__device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v, const Dims& d, float& bx, float& by,
-                                                float& bz, float& gx, float& gy, float& gz) {
-  const int ix = (int)(v % d.s2);
-  const int iy = (int)((v / d.s2) % d.s1);
+__device__ __forceinline__ void affine_position_xyz(const Theta<DIM>& th, int ix, int iy, int iz, const Dims& d,
+                                                    float& bx, float& by, float& bz, float& gx, float& gy, float& gz) {
   bx = affine_base_coord(ix, d.s2);
   by = affine_base_coord(iy, d.s1);
   if constexpr (DIM == 3) {
-    const int iz = (int)(v / ((int64_t)d.s2 * d.s1));
     bz = affine_base_coord(iz, d.s0);
     gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2] * bz + th.m[0][3];
     gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2] * bz + th.m[1][3];
@@ -284,6 +281,15 @@ __device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v,
     gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2];
     gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2];
   }
+}
+
+template <int DIM>
+__device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v, const Dims& d, float& bx, float& by,
+                                                float& bz, float& gx, float& gy, float& gz) {
+  const int ix = (int)(v % d.s2);
+  const int iy = (int)((v / d.s2) % d.s1);
+  const int iz = DIM == 3 ? (int)(v / ((int64_t)d.s2 * d.s1)) : 0;
+  affine_position_xyz<DIM>(th, ix, iy, iz, d, bx, by, bz, gx, gy, gz);
 }
 
 template <int DIM, int INTERP, int PAD>
@@ -322,11 +328,15 @@ k_affine_warp_fwd(const float* __restrict__ in, const float* __restrict__ theta,
 template <int DIM, int INTERP, int PAD, bool NEED_GIN, bool NEED_GTHETA>
 __global__ void __launch_bounds__(kBlock)
 k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
-                  float* __restrict__ gin, float* __restrict__ gtheta_partial, int C, Dims d) {
+                  float* __restrict__ gin, float* __restrict__ gtheta_partial, int C, Dims d,
+                  const int* __restrict__ mode) {
   constexpr int NT = DIM * (DIM + 1);
   __shared__ float smem[4 * NT];
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
+  // mode != null: grad_in of samples with mode[n] == 0 is produced by k_affine_gather_bwd; scatter only the rest
+  const bool do_gin = NEED_GIN && (mode == nullptr || mode[n] != 0);
+  if (!NEED_GTHETA && !do_gin) return;
   Theta<DIM> th;
 #pragma unroll
   for (int r = 0; r < DIM; ++r)
@@ -346,9 +356,11 @@ k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       Taps<DIM, PAD> t;
       t.build(gx, gy, gz, d);
       float ax = 0.f, ay = 0.f, az = 0.f;
-      for (int c = 0; c < C; ++c)
-        sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GTHETA>(inn + (int64_t)c * V, NEED_GIN ? ginn + (int64_t)c * V : nullptr,
-                                                           gon[(int64_t)c * V], t, d, ax, ay, az);
+      for (int c = 0; c < C; ++c) {
+        if (do_gin) sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GTHETA>(inn + (int64_t)c * V, NEED_GIN ? ginn + (int64_t)c * V : nullptr,
+                                                                       gon[(int64_t)c * V], t, d, ax, ay, az);
+        else sample_linear_bwd<DIM, PAD, false, NEED_GTHETA>(inn + (int64_t)c * V, nullptr, gon[(int64_t)c * V], t, d, ax, ay, az);
+      }
       if (NEED_GTHETA) {
         const float ggx = t.x.mult * ax, ggy = t.y.mult * ay, ggz = DIM == 3 ? t.z.mult * az : 0.f;
         const float base[4] = {bx, by, DIM == 3 ? bz : 1.f, 1.f};
@@ -359,7 +371,7 @@ k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
           if constexpr (DIM == 3) acc[2 * (DIM + 1) + c] = ggz * base[c];
         }
       }
-    } else if (NEED_GIN) {
+    } else if (do_gin) {
       bool vx, vy, vz = true;
       const int ix = nearest_index<PAD>(gx, d.s2, vx);
       const int iy = nearest_index<PAD>(gy, d.s1, vy);
@@ -380,6 +392,133 @@ k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Affine warp, grad_in as a GATHER (zeros padding, linear).  The sampling positions x(v) = M v + t form a
+// lattice, so the samples that deposit on voxel u are the lattice points inside M^-1((u-1,u+1)^d - t): a
+// handful of candidates found with slab tests; each candidate's taps are recomputed with exactly the forward's
+// arithmetic, so the weights are bit-identical to the scatter formulation -- without a single atomic.
+//   geo[n] = { M (3x3, xyz order), t (3), Minv (3x3), ext (3) }, mode[n] = 0 gather | 1 fall back to atomics
+// ---------------------------------------------------------------------------------------------
+constexpr int kGeoFloats = 24;
+constexpr float kGatherMaxExt = 6.f;
+
+template <int DIM>
+__global__ void k_affine_geometry(const float* __restrict__ theta, float* __restrict__ geo, int* __restrict__ mode,
+                                  int N, Dims d) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int S[3] = {d.s2, d.s1, d.s0};  // x, y, z
+  float M[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
+  bool ok = true;
+  for (int r = 0; r < DIM; ++r) {
+    float sum = 0.f;
+    for (int a = 0; a < DIM; ++a) {
+      const float th = theta[(n * DIM + r) * (DIM + 1) + a];
+      if (S[a] > 1) { M[r][a] = th * (float)(S[r] - 1) / (float)(S[a] - 1); sum += th; }
+      else { M[r][a] = 0.f; ok = false; }
+    }
+    t[r] = ((theta[(n * DIM + r) * (DIM + 1) + DIM] - sum) + 1.f) * 0.5f * (float)(S[r] - 1);
+  }
+  const float a = M[0][0], b = M[0][1], c = M[0][2], e = M[1][0], f = M[1][1], g = M[1][2], h = M[2][0], i = M[2][1], j = M[2][2];
+  const float A = f * j - g * i, B = -(e * j - g * h), Cc = e * i - f * h;
+  const float det = a * A + b * B + c * Cc;
+  float Mi[3][3];
+  const float rdet = 1.f / det;
+  Mi[0][0] = A * rdet; Mi[0][1] = -(b * j - c * i) * rdet; Mi[0][2] = (b * g - c * f) * rdet;
+  Mi[1][0] = B * rdet; Mi[1][1] = (a * j - c * h) * rdet;  Mi[1][2] = -(a * g - c * e) * rdet;
+  Mi[2][0] = Cc * rdet; Mi[2][1] = -(a * i - b * h) * rdet; Mi[2][2] = (a * f - b * e) * rdet;
+  float* gn = geo + (int64_t)n * kGeoFloats;
+  float ext[3];
+  for (int q = 0; q < 3; ++q) {
+    ext[q] = fabsf(Mi[q][0]) + fabsf(Mi[q][1]) + fabsf(Mi[q][2]) + 0.01f;
+    if (q < DIM && !(ext[q] < kGatherMaxExt)) ok = false;   // also catches NaN / inf
+  }
+  if (!(fabsf(det) > 1e-6f)) ok = false;
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) { gn[r * 3 + q] = M[r][q]; gn[12 + r * 3 + q] = Mi[r][q]; }
+  for (int r = 0; r < 3; ++r) { gn[9 + r] = t[r]; gn[21 + r] = ext[r]; }
+  mode[n] = ok ? 0 : 1;
+}
+
+template <int DIM, int CMAX>
+__global__ void __launch_bounds__(kBlock)
+k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ theta, const float* __restrict__ geo,
+                    const int* __restrict__ mode, float* __restrict__ gin, int C, Dims d) {
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const int u = blockIdx.x * kBlock + threadIdx.x;
+  if (u >= V) return;
+  float* ginn = gin + (int64_t)n * C * V + u;
+  if (mode[n] != 0) {  // this sample goes through the atomic kernel: start from zero
+    for (int c = 0; c < C; ++c) ginn[(int64_t)c * V] = 0.f;
+    return;
+  }
+  Theta<DIM> th;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * DIM * (DIM + 1) + r * (DIM + 1) + c];
+  const float* gn = geo + (int64_t)n * kGeoFloats;
+  float M[3][3], Mi[3][3], t[3], ext[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { M[r][q] = gn[r * 3 + q]; Mi[r][q] = gn[12 + r * 3 + q]; }
+    t[r] = gn[9 + r];
+    ext[r] = gn[21 + r];
+  }
+  const int ux = u % d.s2;
+  const int rq = u / d.s2;
+  const int uy = rq % d.s1;
+  const int uz = rq / d.s1;
+  const float uu[3] = {(float)ux - t[0], (float)uy - t[1], DIM == 3 ? (float)uz - t[2] : 0.f};
+  float cen[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) cen[q] = Mi[q][0] * uu[0] + Mi[q][1] * uu[1] + Mi[q][2] * uu[2];
+  const int zlo = DIM == 3 ? max(0, (int)ceilf(cen[2] - ext[2])) : 0;
+  const int zhi = DIM == 3 ? min(d.s0 - 1, (int)floorf(cen[2] + ext[2])) : 0;
+  const int ylo = max(0, (int)ceilf(cen[1] - ext[1])), yhi = min(d.s1 - 1, (int)floorf(cen[1] + ext[1]));
+  const int xlo0 = max(0, (int)ceilf(cen[0] - ext[0])), xhi0 = min(d.s2 - 1, (int)floorf(cen[0] + ext[0]));
+  float acc[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+  const float* gon = gout + (int64_t)n * C * V;
+  for (int vz = zlo; vz <= zhi; ++vz)
+    for (int vy = ylo; vy <= yhi; ++vy) {
+      // slab tests along x: |M[r][0] vx + k_r| < 1 for every output axis r
+      float lo = (float)xlo0, hi = (float)xhi0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {
+        const float k = M[r][1] * (float)vy + M[r][2] * (float)vz - uu[r];
+        const float m = M[r][0];
+        if (fabsf(m) > 1e-3f) {
+          const float p = (-1.f - k) / m, q = (1.f - k) / m;
+          lo = fmaxf(lo, fminf(p, q) - 1e-3f);
+          hi = fminf(hi, fmaxf(p, q) + 1e-3f);
+        }
+      }
+      const int xl = (int)ceilf(lo), xh = (int)floorf(hi);
+      for (int vx = xl; vx <= xh; ++vx) {
+        float bx, by, bz, gx, gy, gz;
+        affine_position_xyz<DIM>(th, vx, vy, vz, d, bx, by, bz, gx, gy, gz);
+        Taps<DIM, PAD_ZEROS> tp;
+        tp.build(gx, gy, gz, d);
+        const int dx = ux - tp.x.i0, dy = uy - tp.y.i0, dz = DIM == 3 ? uz - tp.z.i0 : 0;
+        if ((unsigned)dx > 1u || (unsigned)dy > 1u || (unsigned)dz > 1u) continue;
+        float w = tp.wx(dx) * tp.wy(dy);
+        if (DIM == 3) w *= tp.wz(dz);
+        const int v = (vz * d.s1 + vy) * d.s2 + vx;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < C) acc[c] += w * gon[(int64_t)c * V + v];
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) ginn[(int64_t)c * V] = acc[c];
+}
+
 // out[row][k] = sum_b partial[row][b][k]      (deterministic second stage)
 __global__ void k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int nb, int K) {
   const int row = blockIdx.x;
@@ -398,7 +537,7 @@ using namespace advchain;
 // scatter_tiled.hip
 int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                  int32_t* workspace, hipStream_t st);
+                                  int32_t* workspace, int chain, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
@@ -487,10 +626,10 @@ static inline Dims make_dims(int ndim, const int64_t* s) {
 // =============================================================================================
 template <int DIM, int INTERP, int PAD>
 static void launch_affine_bwd(dim3 g, dim3 b, hipStream_t st, const float* gout, const float* in, const float* theta,
-                              float* gin, float* gpart, int C, Dims d) {
-  if (gin && gpart) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
-  else if (gin) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, false>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
-  else hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, false, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d);
+                              float* gin, float* gpart, int C, Dims d, const int* mode) {
+  if (gin && gpart) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
+  else if (gin) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, false>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
+  else hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, false, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
 }
 
 extern "C" {
@@ -524,9 +663,10 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
   const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_bwd: per-sample volume too large");
   const bool same = id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2;
-  if (workspace && grad_in && same && interp == INTERP_LINEAR)  // LDS-tiled owner-computes scatter (no atomics, no pre-zero)
+  if (workspace && grad_in && same && interp == INTERP_LINEAR && C <= 4)  // LDS-tiled owner-computes scatter
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                         clamp_grid, workspace, (hipStream_t)stream);
+                                         clamp_grid, workspace, 0, (hipStream_t)stream);
+  if (workspace && grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
@@ -555,8 +695,8 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   return ADVCHAIN_OK;
 }
 
-int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int64_t N,
-                              int ndim, const int64_t* dims, void* stream) {
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
+                              int64_t N, int ndim, const int64_t* dims, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && phi && grad_phi, "compose_self_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_bwd: bad N");
@@ -566,7 +706,7 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
   if (workspace)
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
-                                         workspace, (hipStream_t)stream);
+                                         workspace, chain, (hipStream_t)stream);
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
@@ -609,7 +749,7 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims) {
   if (!dims_ok(ndim, dims)) return -1;
   const Dims d = make_dims(ndim, dims);
-  return N * (int64_t)advchain_blocks(d.voxels(), kBlock) * ndim * (ndim + 1);  // floats
+  return N * (int64_t)advchain_blocks(d.voxels(), kBlock) * ndim * (ndim + 1) + N * (kGeoFloats + 1);  // floats
 }
 
 int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
@@ -617,7 +757,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
                              const int64_t* dims, int interp, int padding, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && in && theta, "affine_warp_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(grad_in || grad_theta, "affine_warp_bwd: nothing to compute");
-  ADVCHAIN_CHECK_ARG(!grad_theta || workspace, "affine_warp_bwd: grad_theta needs a workspace");
+  ADVCHAIN_CHECK_ARG(workspace, "affine_warp_bwd: workspace required (advchain_affine_warp_bwd_workspace floats)");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "affine_warp_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "affine_warp_bwd: bad N/C");
   ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "affine_warp_bwd: interp");
@@ -634,13 +774,34 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
     return ADVCHAIN_OK;
   }
+  const int* mode = nullptr;
+  static const bool no_gather = getenv("ADVCHAIN_AFFINE_ATOMIC") != nullptr;  // A/B knob
+  if (grad_in && workspace && interp == INTERP_LINEAR && padding == PAD_ZEROS && C <= 8 && !no_gather) {
+    // gather formulation of grad_in (no atomics); samples it cannot handle are flagged and scattered below
+    float* geo = workspace + N * (int64_t)nb * ndim * (ndim + 1);
+    int* md = reinterpret_cast<int*>(geo + N * kGeoFloats);
+    if (ndim == 3) {
+      hipLaunchKernelGGL(k_affine_geometry<3>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
+      if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<3, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<3, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      else hipLaunchKernelGGL((k_affine_gather_bwd<3, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+    } else {
+      hipLaunchKernelGGL(k_affine_geometry<2>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
+      if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<2, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<2, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      else hipLaunchKernelGGL((k_affine_gather_bwd<2, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+    }
+    mode = md;
+  } else if (grad_in) {
+    (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * d.voxels(), st);
+  }
   DISPATCH_PAD(padding, {
     if (ndim == 3) {
-      if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d);
-      else launch_affine_bwd<3, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d);
+      if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode);
+      else launch_affine_bwd<3, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d, mode);
     } else {
-      if (interp == INTERP_LINEAR) launch_affine_bwd<2, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d);
-      else launch_affine_bwd<2, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d);
+      if (interp == INTERP_LINEAR) launch_affine_bwd<2, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode);
+      else launch_affine_bwd<2, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d, mode);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();

@@ -70,7 +70,7 @@ def _scatter_workspace(N, dims, device):
 def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, need_ggrid):
     N, C = inp.shape[:2]
     nd = inp.dim() - 2
-    tiled = TILED_SCATTER and need_gin and interp == 0 and tuple(inp.shape[2:]) == tuple(grid.shape[2:])
+    tiled = TILED_SCATTER and need_gin
     ws = _scatter_workspace(N, inp.shape[2:], inp.device) if tiled else None
     gin = (torch.empty_like(inp) if tiled else torch.zeros_like(inp)) if need_gin else None
     ggrid = torch.empty_like(grid) if need_ggrid else None
@@ -91,13 +91,14 @@ def raw_compose_self_fwd(phi, phi0=None, final_mode=0):
     return out
 
 
-def raw_compose_self_bwd(gout, phi, ws=None):
+def raw_compose_self_bwd(gout, phi, ws=None, chain=False):
+    """chain=True: ``gout`` is the result of the previous call that used the same workspace ``ws``."""
     N = phi.shape[0]
     nd = phi.dim() - 2
     if TILED_SCATTER and ws is None:
-        ws = _scatter_workspace(N, phi.shape[2:], phi.device)
+        ws, chain = _scatter_workspace(N, phi.shape[2:], phi.device), False
     gphi = torch.empty_like(phi) if ws is not None else torch.zeros_like(phi)
-    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), N, nd,
+    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), int(bool(chain)), N, nd,
                                                      _lib.dims_array(phi.shape[2:]), _stream()), "compose_self_bwd")
     return gphi
 
@@ -235,12 +236,10 @@ class _AffineWarp(torch.autograd.Function):
         N, C = inp.shape[:2]
         nd = inp.dim() - 2
         dims = _lib.dims_array(inp.shape[2:])
-        gin = torch.zeros_like(inp) if need_in else None
+        gin = torch.empty_like(inp) if need_in else None
         gth = torch.empty_like(theta) if need_th else None
-        ws = None
-        if need_th:
-            ws = torch.empty(max(1, lib.advchain_affine_warp_bwd_workspace(N, nd, dims)), device=inp.device,
-                             dtype=torch.float32)
+        ws = torch.empty(max(1, lib.advchain_affine_warp_bwd_workspace(N, nd, dims)), device=inp.device,
+                         dtype=torch.float32)
         _lib.check(lib.advchain_affine_warp_bwd(_ptr(_dev(gout, "grad")), _ptr(inp), _ptr(theta), _ptr(gin), _ptr(gth),
                                                 _ptr(ws), N, C, nd, dims, interp, padding, _stream()), "affine_warp_bwd")
         return gin, gth, None, None
@@ -371,8 +370,9 @@ class _DemonsField(torch.autograd.Function):
         s1 = raw_gauss(vel, d, pre=1, scale=scale)
         n = 8
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
-            ss = torch.zeros(1, device=vel.device, dtype=torch.float32)
-            raw_tp_interp(s1, tables, d, want_out=False, sumsq=ss)
+            slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
+            raw_tp_interp(s1, tables, d, want_out=False, sumsq=slots)
+            ss = slots.sum().reshape(1)
             if reduce_sumsq is not None:
                 ss = reduce_sumsq(ss)
             norm = float(ss.sqrt().item())
@@ -398,8 +398,8 @@ class _DemonsField(torch.autograd.Function):
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
         ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
-        for phi in reversed(phis):
-            g = raw_compose_self_bwd(g, phi, ws)
+        for i, phi in enumerate(reversed(phis)):
+            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0)
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)
@@ -428,13 +428,14 @@ class _Consistency(torch.autograd.Function):
         R = None
         if need_grad and want_edges and K > 1:
             R = torch.empty((N, 2 * (K - 1)) + tuple(pred.shape[2:]), device=pred.device, dtype=torch.float32)
-        sums = torch.zeros(3, device=pred.device, dtype=torch.float32)
+        slots = torch.zeros(3, 64, device=pred.device, dtype=torch.float32)   # per-workgroup partials, 64 slots per sum
         _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
-                                                        _ptr(sums), N, K, nd, dims, mch, int(ref_is_prob),
+                                                        _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
                                                         int(want_edges), _stream()), "consistency_fwd")
         if need_grad:
             ctx.save_for_backward(P, D, R, mask)
         ctx.cfg = (coef, mch)
+        sums = slots.sum(dim=1)
         ctx.mark_non_differentiable(sums)
         cvec = torch.tensor(coef, device=pred.device, dtype=torch.float32)
         return torch.dot(sums, cvec), sums

@@ -105,8 +105,8 @@ def algorithmic_bytes(name, a):
         extra = 4 * nd * N * V if a[6] == 1 else 0          # final mode also reads phi0
         return 8 * nd * N * V + extra                        # read phi (d ch) + write out (d ch)
     if name == "advchain_compose_self_bwd":
-        N, nd = a[4], a[5]
-        V = _prod(_arr(a[6], nd))
+        N, nd = a[5], a[6]
+        V = _prod(_arr(a[7], nd))
         return 12 * nd * N * V                               # read grad_out, phi; write grad_phi (atomics)
     if name == "advchain_grid_sample_fwd":
         N, C, nd = a[3], a[4], a[5]
@@ -264,11 +264,11 @@ def grid_sample3d_roofline(device, reps=20):
 def cpu_baseline(wl, name):
     """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
     from oracle import advchain_oracle as O
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(os.cpu_count() or 1, 16)   # measured on the GPU box: 16 threads is the fastest setting for this path
     torch.set_num_threads(cores)
     sd = len(wl["dims"])
     if sd == 2:
-        batch, n_iter = min(wl["batch"], 16), wl["n_iter"]
+        batch, n_iter = min(wl["batch"], 8), wl["n_iter"]
     else:
         batch, n_iter = 1, 1
     cls = {"noise": O.OracleNoise, "bias": O.OracleBias, "morph": O.OracleMorph, "affine": O.OracleAffine}

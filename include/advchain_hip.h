@@ -51,9 +51,10 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
                              int clamp_grid, void* stream);
 /* replaces: autograd grid_sampler_{2,3}d_backward for the call above.
  * grad_in (N,C,in_dims) and grad_grid (N,ndim,out_dims); either may be NULL.  grad_grid is overwritten.
- * With `workspace` (int32[advchain_scatter_workspace(N,ndim,dims)], linear interp, in_dims == out_dims)
- * grad_in is produced by the LDS-tiled owner-computes scatter and is simply overwritten; with
- * workspace == NULL the global-atomic path is used and grad_in must be pre-zeroed.               */
+ * With `workspace` (int32[advchain_scatter_workspace(N,ndim,dims)]) grad_in is simply overwritten: the
+ * LDS-tiled owner-computes scatter (64-bit fixed-point accumulation, deterministic) is used for linear
+ * interpolation with in_dims == out_dims and C <= 4, and grad_in is zero-filled internally otherwise;
+ * with workspace == NULL the global-atomic path is used and grad_in must be pre-zeroed by the caller. */
 int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
                              float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
@@ -70,9 +71,11 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
 int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
                               const int64_t* dims, int final_mode, void* stream);
 /* grad_phi receives both the value path (scatter) and the coordinate path; overwritten when a
- * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).       */
-int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int64_t N,
-                              int ndim, const int64_t* dims, void* stream);
+ * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).
+ * chain != 0: grad_out is the grad_phi of the previous call on the same workspace (the backward of
+ * consecutive squarings), whose max|.| is already in the workspace -- saves one pass over grad_out. */
+int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
+                              int64_t N, int ndim, const int64_t* dims, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),
@@ -80,8 +83,10 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
 int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* dims, int interp, int padding, void* stream);
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims); /* floats */
-/* grad_in pre-zeroed or NULL; grad_theta (N, ndim, ndim+1) overwritten (deterministic two-stage
- * reduction through `workspace`) or NULL.                                                     */
+/* grad_in (N,C,dims) and grad_theta (N, ndim, ndim+1) are overwritten; either may be NULL.  grad_theta uses a
+ * deterministic two-stage reduction.  grad_in: for linear interpolation with zeros padding it is computed as a
+ * GATHER over the affine lattice (no atomics, deterministic); otherwise it is zero-filled here and scattered
+ * with atomics.  `workspace` (advchain_affine_warp_bwd_workspace floats) is always required.                */
 int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
                              float* grad_theta, float* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* dims, int interp, int padding, void* stream);
@@ -106,7 +111,7 @@ int advchain_affine_theta_bwd(const float* param, const float* cfg_host, float p
  * replaces: F.interpolate(duv, size=full, 'bilinear'|'trilinear', align_corners=False)
  *           adv_morph.py:464, fused with 'basegrid += duv/2^n' (adv_morph.py:111,129-130) when
  *           add_identity != 0, and with torch.norm(duv_interval) (adv_morph.py:160) when
- *           sumsq != NULL (adds sum(interp^2) over the launch; caller zeroes it).
+ *           sumsq != NULL (64 partial accumulators: sum(sumsq[0..63]) += sum(interp^2); caller zeroes them).
  * coef (planes, g0,g1,g2) -> out (planes, S0,S1,S2) = identity? + scale * interp.               */
 int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
                            const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
@@ -160,9 +165,10 @@ int advchain_norm_axpy(const float* base, const float* x, float* out, float* wor
  * pred/ref (N,K,dims) logits (ref already a probability map when ref_is_prob), mask
  * (N, mask_channels in {1,K}, dims) or NULL.  Outputs: P = softmax(pred), D = P - T (N,K,dims);
  * R (N, 2(K-1), dims) = 2 m^2 (A*D), 2 m^2 (B*D) per class 1..K-1 (NULL when no backward is
- * needed); sums[0] += sum ((P m)-(T m))^2, sums[1] += sum (A*D m)^2, sums[2] += sum (B*D m)^2
- * (caller zeroes `sums` (3 floats) and applies the GLOBAL normalisers -- required for batch
- * sharding).  2D: A = Sobel-x, B = Sobel-y.  3D: A = h(x)hp(x)h (the
+ * needed); sums is 3 x 64 partial accumulators (row r, slot s at sums[64 r + s]; per-workgroup partials are
+ * spread over the slots because same-address atomics serialise): row 0 += sum ((P m)-(T m))^2, row 1 +=
+ * sum (A*D m)^2, row 2 += sum (B*D m)^2 (caller zeroes `sums`, adds the slots up and applies the GLOBAL
+ * normalisers -- required for batch sharding).  2D: A = Sobel-x, B = Sobel-y.  3D: A = h(x)hp(x)h (the
  * reference uses it for conv_x AND conv_y), B = h(x)h(x)hp.                                      */
 int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
                              float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,

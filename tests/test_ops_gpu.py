@@ -168,6 +168,15 @@ def test_affine_warp(dims, C, pad):
     assert maxdiff(out.cpu(), ref) < TOL
     assert maxdiff(a2.grad.cpu(), a.grad) < TOL
     assert rel(t2.grad.cpu(), t.grad) < 2e-5
+    # strong minification (|theta| ~ 8): too many samples per voxel for the gather path -> per-sample atomic fallback
+    theta_s = theta.clone()
+    theta_s[0, :, :d] *= 8.0
+    a3, t3 = inp.clone().requires_grad_(True), theta_s.clone().requires_grad_(True)
+    (O.affine_warp(a3, t3, "bilinear", pad) * w).sum().backward()
+    a4, t4 = inp.to(DEV).requires_grad_(True), theta_s.to(DEV).requires_grad_(True)
+    (ops.affine_warp(a4, t4, "bilinear", pad) * w.to(DEV)).sum().backward()
+    assert maxdiff(a4.grad.cpu(), a3.grad) < TOL
+    assert rel(t4.grad.cpu(), t3.grad) < 5e-5
     n_ref = O.affine_warp(inp, theta, "nearest", pad)
     n_out = ops.affine_warp(inp.to(DEV), theta.to(DEV), "nearest", pad)
     assert float((n_out.cpu() != n_ref).float().mean()) < 2e-3  # rounding ties at .5 may differ by fp order
@@ -232,8 +241,9 @@ def test_tp_interp_upsample_and_adjoint(low, full):
     out = ops.raw_tp_interp(v.to(DEV), tabs, d)
     assert maxdiff(out.cpu(), ref) < 2e-6
     # identity + scale, and sum of squares
-    ss = torch.zeros(1, device=DEV)
-    out2 = ops.raw_tp_interp(v.to(DEV), tabs, d, add_identity=True, scale=0.125, sumsq=ss)
+    slots = torch.zeros(64, device=DEV)
+    out2 = ops.raw_tp_interp(v.to(DEV), tabs, d, add_identity=True, scale=0.125, sumsq=slots)
+    ss = slots.sum()
     assert maxdiff(out2.cpu(), O.identity_grid(n, full) + ref.detach() * 0.125) < 2e-6
     assert abs(float(ss) - float((ref.detach().double() ** 2).sum())) < 1e-4 * float((ref.detach().double() ** 2).sum())
     adj = ops.raw_tp_adjoint(w.to(DEV), tabs, gfull2=w2.to(DEV), scale=0.25)
