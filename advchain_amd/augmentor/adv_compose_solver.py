@@ -298,7 +298,7 @@ class ComposeAdversarialTransformSolver(object):
                 if torch.isnan(value) or torch.isinf(value):
                     dist = 0
                 else:
-                    dist.backward()
+                    self._backward_to_transforms(dist, optimize_flags)
                     i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
                     #           is stepped with step_sizes[0]; kept for result parity
                     for flag, transform in zip(optimize_flags, self.chain_of_transforms):
@@ -348,6 +348,23 @@ class ComposeAdversarialTransformSolver(object):
                 else:
                     stop_flag = True
         return transforms
+
+    def _backward_to_transforms(self, dist, optimize_flags):
+        """``dist.backward()`` of adv_compose_solver.py:348, restricted to the transform parameters: the reference
+        also accumulates (and immediately zeroes, lines 310/366) the gradients of the model's weights -- for a conv
+        net that is a weight-gradient convolution per ascent step that nobody reads.  Set ``full_backward = True``
+        to get the literal behaviour."""
+        if getattr(self, 'full_backward', False):
+            dist.backward()
+            return
+        leaves = [t.param for flag, t in zip(optimize_flags, self.chain_of_transforms)
+                  if flag and isinstance(t.param, torch.Tensor) and t.param.requires_grad]
+        if not leaves:
+            dist.backward()
+            return
+        grads = torch.autograd.grad(dist, leaves, allow_unused=True)
+        for p, g in zip(leaves, grads):
+            p.grad = g
 
     def rescale_intensity(self, data, new_min=0, new_max=1, eps=1e-20):
         # adv_compose_solver.py:407-421
