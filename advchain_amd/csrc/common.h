@@ -138,6 +138,14 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem) {
   }
 }
 
+// whole-wave lane shifts (gfx9 DPP wave_shl / wave_shr: one VALU op, no LDS); lanes shifted in receive 0
+__device__ __forceinline__ float lane_next_f(float v) {   // lane i <- lane i+1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_prev_f(float v) {   // lane i <- lane i-1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
 // Per-workgroup partial sums go to one of kSumSlots accumulators (slot = workgroup id mod kSumSlots): thousands of
 // atomics on ONE address serialise at ~10 ns each on MI355X; the consumer adds the slots up.
 constexpr int kSumSlots = 64;

@@ -537,7 +537,7 @@ using namespace advchain;
 // scatter_tiled.hip
 int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                  int32_t* workspace, int chain, hipStream_t st);
+                                  int32_t* workspace, int chain, int halo, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
@@ -665,7 +665,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
   const bool same = id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2;
   if (workspace && grad_in && same && interp == INTERP_LINEAR && C <= 4)  // LDS-tiled owner-computes scatter
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                         clamp_grid, workspace, 0, (hipStream_t)stream);
+                                         clamp_grid, workspace, 0, 0, (hipStream_t)stream);
   if (workspace && grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
@@ -696,7 +696,7 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
 }
 
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
-                              int64_t N, int ndim, const int64_t* dims, void* stream) {
+                              int halo, int64_t N, int ndim, const int64_t* dims, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && phi && grad_phi, "compose_self_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_bwd: bad N");
@@ -706,7 +706,7 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
   if (workspace)
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
-                                         workspace, chain, (hipStream_t)stream);
+                                         workspace, chain, halo, (hipStream_t)stream);
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(NT)
 k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                float* __restrict__ gin, float* __restrict__ ggrid, Dims d, TileCfg tc, int clamp_grid,
                const float* __restrict__ absmax_in, float* __restrict__ absmax_out, int* __restrict__ ovf_count,
-               int2* __restrict__ ovf_list, int ovf_cap) {
+               int2* __restrict__ ovf_list, int ovf_cap, int dbg) {
   extern __shared__ long long acc[];
   constexpr int NW = NT / 64;
   const int V = (int)d.voxels();
@@ -170,7 +170,7 @@ k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, con
                 const int lo = ((uz - z0) * tc.t1 + (uy - y0)) * tc.t2 + (ux - x0);
                 const float w = t.w(cz, cy, cx) * scale;
 #pragma unroll
-                for (int c = 0; c < C; ++c) lds_add_fixed(acc + c * tvox + lo, w * cur.go[c]);
+                for (int c = 0; c < C; ++c) if (!(dbg & 1)) lds_add_fixed(acc + c * tvox + lo, w * cur.go[c]);
               } else if (owned && !deposit_handled(sz, sy, sx, uz, uy, ux, tc)) {
                 overflow = true;
               }
@@ -178,7 +178,7 @@ k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, con
           }
     }
     if (owned) {
-      if (SELF || NEED_GGRID) {
+      if ((SELF || NEED_GGRID) && !(dbg & 2)) {
         float ax = 0.f, ay = 0.f, az = 0.f, dummy = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -278,7 +278,7 @@ using namespace advchain;
 
 // Tile geometry.  Near-identity warps: 3D displacements are <~ 2 voxels, 2D <~ 8 pixels; anything
 // larger goes through the overflow list.  lane <-> x: a row of the region (owned x-range + halo) is one wave.
-static TileCfg choose_tiles(int ndim, const Dims& d, int C) {
+static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   TileCfg tc;
   static const int h3d = getenv("ADVCHAIN_TILE_H3") ? atoi(getenv("ADVCHAIN_TILE_H3")) : 2;   // tuning knobs
   static const int h2d = getenv("ADVCHAIN_TILE_H2") ? atoi(getenv("ADVCHAIN_TILE_H2")) : 8;
@@ -291,6 +291,10 @@ static TileCfg choose_tiles(int ndim, const Dims& d, int C) {
     tc.h1 = tc.h2 = h2d;
     tc.t1 = 32;
     tc.t0 = 1;
+  }
+  if (halo_hint > 0) {
+    tc.h1 = tc.h2 = halo_hint;
+    if (ndim == 3) tc.h0 = halo_hint;
   }
   if (d.s2 <= 64) {
     tc.t2 = d.s2;  // the whole row: no x-halo needed
@@ -314,11 +318,12 @@ template <int DIM, int PAD, int C>
 static void launch_rows(bool self, bool need_ggrid, dim3 g, size_t lds, hipStream_t st, const float* gout,
                         const float* in, const float* grid, float* gin, float* ggrid, Dims d, TileCfg tc,
                         int clamp_grid, const float* amax_in, float* amax_out, int* cnt, int2* list, int cap) {
+  static const int dbg = getenv("ADVCHAIN_DBG") ? atoi(getenv("ADVCHAIN_DBG")) : 0;  // tuning knob
   // > 48 KiB of LDS leaves <= 3 workgroups per CU: use 8 waves per workgroup to keep the CU busy
   const bool big = lds > 40960;
 #define LAUNCH(SELF_, GG_, NT_)                                                                                      \
   hipLaunchKernelGGL((k_scatter_rows<DIM, PAD, C, SELF_, GG_, NT_>), g, dim3(NT_), lds, st, gout, in, grid, gin,     \
-                     ggrid, d, tc, clamp_grid, amax_in, amax_out, cnt, list, cap)
+                     ggrid, d, tc, clamp_grid, amax_in, amax_out, cnt, list, cap, dbg)
   if (self) {
     if constexpr (C == DIM) { if (big) LAUNCH(true, false, 512); else LAUNCH(true, false, 256); }
   } else if (need_ggrid) {
@@ -352,9 +357,9 @@ static bool launch_rows_c(int C, bool self, bool need_ggrid, dim3 g, size_t lds,
 // Returns ADVCHAIN_ERR_UNSUPPORTED when C is outside 1..4 (caller falls back to the global-atomic kernels).
 int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                  int32_t* workspace, int chain, hipStream_t st) {
+                                  int32_t* workspace, int chain, int halo, hipStream_t st) {
   if (C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
-  const TileCfg tc = choose_tiles(ndim, d, (int)C);
+  const TileCfg tc = choose_tiles(ndim, d, (int)C, halo);
   const int64_t V = d.voxels();
   int* cnt = workspace;
   float* amax = reinterpret_cast<float*>(workspace + 2);  // [0] = in, [1] = out

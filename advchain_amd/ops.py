@@ -91,14 +91,14 @@ def raw_compose_self_fwd(phi, phi0=None, final_mode=0):
     return out
 
 
-def raw_compose_self_bwd(gout, phi, ws=None, chain=False):
+def raw_compose_self_bwd(gout, phi, ws=None, chain=False, halo=0):
     """chain=True: ``gout`` is the result of the previous call that used the same workspace ``ws``."""
     N = phi.shape[0]
     nd = phi.dim() - 2
     if TILED_SCATTER and ws is None:
         ws, chain = _scatter_workspace(N, phi.shape[2:], phi.device), False
     gphi = torch.empty_like(phi) if ws is not None else torch.zeros_like(phi)
-    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), int(bool(chain)), N, nd,
+    _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), int(bool(chain)), int(halo), N, nd,
                                                      _lib.dims_array(phi.shape[2:]), _stream()), "compose_self_bwd")
     return gphi
 
@@ -398,8 +398,14 @@ class _DemonsField(torch.autograd.Function):
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
         ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
+        # squaring m composes a field whose displacement is 2^(m-n) of the total: the early (cheap-halo) steps
+        # dominate.  The halo is a performance hint only (larger displacements go through the overflow list).
+        n = len(phis)
+        big = 2 if d == 3 else 8
         for i, phi in enumerate(reversed(phis)):
-            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0)
+            m = n - 1 - i
+            halo = big if m >= n - 2 else (max(1, big // 2) if m == n - 3 else (1 if d == 3 else 2))
+            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halo)
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)

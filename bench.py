@@ -105,8 +105,8 @@ def algorithmic_bytes(name, a):
         extra = 4 * nd * N * V if a[6] == 1 else 0          # final mode also reads phi0
         return 8 * nd * N * V + extra                        # read phi (d ch) + write out (d ch)
     if name == "advchain_compose_self_bwd":
-        N, nd = a[5], a[6]
-        V = _prod(_arr(a[7], nd))
+        N, nd = a[6], a[7]
+        V = _prod(_arr(a[8], nd))
         return 12 * nd * N * V                               # read grad_out, phi; write grad_phi (atomics)
     if name == "advchain_grid_sample_fwd":
         N, C, nd = a[3], a[4], a[5]

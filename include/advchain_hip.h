@@ -73,9 +73,11 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
 /* grad_phi receives both the value path (scatter) and the coordinate path; overwritten when a
  * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).
  * chain != 0: grad_out is the grad_phi of the previous call on the same workspace (the backward of
- * consecutive squarings), whose max|.| is already in the workspace -- saves one pass over grad_out. */
+ * consecutive squarings), whose max|.| is already in the workspace -- saves one pass over grad_out.
+ * halo > 0: tile halo in voxels (an upper bound on |displacement| of phi keeps every deposit in LDS; larger
+ * displacements stay correct through the overflow list); 0 = default (2 in 3D, 8 in 2D).               */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
-                              int64_t N, int ndim, const int64_t* dims, void* stream);
+                              int halo, int64_t N, int ndim, const int64_t* dims, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),

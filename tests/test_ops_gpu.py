@@ -424,3 +424,23 @@ def test_consistency_loss_golden():
                 assert abs(float(v) - fx.f(k + "value")) < 1e-7 + 2e-5 * abs(fx.f(k + "value")), k
                 g = fx.t(k + "grad")
                 assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, k
+
+
+@pytest.mark.parametrize("dims", [(12, 64), (9, 128), (5, 6, 64), (3, 4, 128)])
+def test_consistency_loss_row_kernels(dims):
+    """S2 % 64 == 0 selects the row/DPP stencil kernels (not reached by the G5 fixture shapes): vs the CPU oracle."""
+    from advchain_amd.common.loss import calc_segmentation_consistency
+    from oracle import advchain_oracle as O
+    pred = rand((2, 4) + dims, 301) * 2
+    ref = rand((2, 4) + dims, 302) * 2
+    m1 = (rand((2, 1) + dims, 303) > -0.7).float()
+    for mask in (None, m1.expand(2, 4, *dims).contiguous()):
+        a = pred.clone().requires_grad_(True)
+        v_ref = O.consistency_loss(a, ref, ["mse", "contour"], [1.0, 0.5], mask=mask)
+        v_ref.backward()
+        b = pred.to(DEV).requires_grad_(True)
+        v = calc_segmentation_consistency(b, ref.to(DEV), ["mse", "contour"], [1.0, 0.5], scales=[0],
+                                          mask=None if mask is None else mask.to(DEV))
+        v.backward()
+        assert abs(float(v) - float(v_ref)) < 1e-7 + 2e-5 * abs(float(v_ref))
+        assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10
