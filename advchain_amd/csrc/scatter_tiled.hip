@@ -86,6 +86,14 @@ __global__ void __launch_bounds__(kBlock) k_absmax(const float* __restrict__ x, 
   if (threadIdx.x == 0 && m > 0.f) atomic_max_abs(out, m);
 }
 
+// workspace header: [0] overflow counter, [1] pad, [2] max|grad_out|, [3] max|result|
+__global__ void k_scatter_prepare(int32_t* ws, int chain) {
+  if (chain) ws[2] = ws[3]; else ws[2] = 0;
+  ws[0] = 0;
+  ws[1] = 0;
+  ws[3] = 0;
+}
+
 template <int DIM, int C>
 struct RowRegs {
   float g[DIM];
@@ -276,12 +284,12 @@ k_scatter_overflow(const float* __restrict__ gout, const float* __restrict__ gri
 
 using namespace advchain;
 
-// Tile geometry.  Near-identity warps: 3D displacements are <~ 2 voxels, 2D <~ 8 pixels; anything
-// larger goes through the overflow list.  lane <-> x: a row of the region (owned x-range + halo) is one wave.
+// Tile geometry.  Near-identity warps: 3D displacements are <~ 2 voxels, 2D <~ 8 pixels at initialisation and up to
+// ~16 after a few un-normalised ascent steps; anything larger goes through the overflow list.  lane <-> x: a row of the region (owned x-range + halo) is one wave.
 static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   TileCfg tc;
   static const int h3d = getenv("ADVCHAIN_TILE_H3") ? atoi(getenv("ADVCHAIN_TILE_H3")) : 2;   // tuning knobs
-  static const int h2d = getenv("ADVCHAIN_TILE_H2") ? atoi(getenv("ADVCHAIN_TILE_H2")) : 8;
+  static const int h2d = getenv("ADVCHAIN_TILE_H2") ? atoi(getenv("ADVCHAIN_TILE_H2")) : 16;  // measured: 16 beats 8/12 at cfg-2
   if (ndim == 3) {
     tc.h0 = tc.h1 = tc.h2 = h3d;
     tc.t1 = 8;
@@ -304,7 +312,8 @@ static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   }
   if (tc.t1 > d.s1) tc.t1 = d.s1;
   if (tc.t0 > d.s0) tc.t0 = d.s0;
-  while ((int64_t)C * tc.t0 * tc.t1 * tc.t2 * 8 > 65536) {   // int64 accumulators, <= 64 KiB of dynamic LDS
+  static const int lds_cap = getenv("ADVCHAIN_TILE_LDS") ? atoi(getenv("ADVCHAIN_TILE_LDS")) : 65536;  // tuning knob
+  while ((int64_t)C * tc.t0 * tc.t1 * tc.t2 * 8 > lds_cap) {   // int64 accumulators in dynamic LDS
     if (tc.t0 > 1) tc.t0 = (tc.t0 + 1) / 2;
     else tc.t1 = (tc.t1 + 1) / 2;
   }
@@ -320,16 +329,20 @@ static void launch_rows(bool self, bool need_ggrid, dim3 g, size_t lds, hipStrea
                         int clamp_grid, const float* amax_in, float* amax_out, int* cnt, int2* list, int cap) {
   static const int dbg = getenv("ADVCHAIN_DBG") ? atoi(getenv("ADVCHAIN_DBG")) : 0;  // tuning knob
   // > 48 KiB of LDS leaves <= 3 workgroups per CU: use 8 waves per workgroup to keep the CU busy
-  const bool big = lds > 40960;
+  const bool big = lds > 40960, huge = lds > 65536;
 #define LAUNCH(SELF_, GG_, NT_)                                                                                      \
-  hipLaunchKernelGGL((k_scatter_rows<DIM, PAD, C, SELF_, GG_, NT_>), g, dim3(NT_), lds, st, gout, in, grid, gin,     \
-                     ggrid, d, tc, clamp_grid, amax_in, amax_out, cnt, list, cap, dbg)
+  do {                                                                                                               \
+    auto kern = k_scatter_rows<DIM, PAD, C, SELF_, GG_, NT_>;                                                        \
+    if (huge) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, g, dim3(NT_), lds, st, gout, in, grid, gin, ggrid, d, tc, clamp_grid, amax_in, amax_out, \
+                       cnt, list, cap, dbg);                                                                         \
+  } while (0)
   if (self) {
-    if constexpr (C == DIM) { if (big) LAUNCH(true, false, 512); else LAUNCH(true, false, 256); }
+    if constexpr (C == DIM) { if (huge) LAUNCH(true, false, 1024); else if (big) LAUNCH(true, false, 512); else LAUNCH(true, false, 256); }
   } else if (need_ggrid) {
-    if (big) LAUNCH(false, true, 512); else LAUNCH(false, true, 256);
+    if (huge) LAUNCH(false, true, 1024); else if (big) LAUNCH(false, true, 512); else LAUNCH(false, true, 256);
   } else {
-    if (big) LAUNCH(false, false, 512); else LAUNCH(false, false, 256);
+    if (huge) LAUNCH(false, false, 1024); else if (big) LAUNCH(false, false, 512); else LAUNCH(false, false, 256);
   }
 #undef LAUNCH
   hipLaunchKernelGGL((k_scatter_overflow<DIM, PAD>), dim3(64), dim3(kBlock), 0, st, gout, grid, gin, C, d, tc,
@@ -366,12 +379,8 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
   int2* list = reinterpret_cast<int2*>(workspace + 4);
   const int64_t cap64 = N * V;
   const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
-  if (chain) {
-    (void)hipMemcpyAsync(amax, amax + 1, sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemsetAsync(cnt, 0, 2 * sizeof(int32_t), st);
-    (void)hipMemsetAsync(amax + 1, 0, sizeof(float), st);
-  } else {
-    (void)hipMemsetAsync(workspace, 0, 4 * sizeof(int32_t), st);
+  hipLaunchKernelGGL(k_scatter_prepare, dim3(1), dim3(1), 0, st, workspace, chain);   // header reset in one launch
+  if (!chain) {
     const int64_t total = N * C * V;
     int blocks = (int)((total / 4 + kBlock - 1) / kBlock);
     if (blocks > 1024) blocks = 1024;

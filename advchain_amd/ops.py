@@ -401,7 +401,7 @@ class _DemonsField(torch.autograd.Function):
         # squaring m composes a field whose displacement is 2^(m-n) of the total: the early (cheap-halo) steps
         # dominate.  The halo is a performance hint only (larger displacements go through the overflow list).
         n = len(phis)
-        big = 2 if d == 3 else 8
+        big = 2 if d == 3 else 16
         for i, phi in enumerate(reversed(phis)):
             m = n - 1 - i
             halo = big if m >= n - 2 else (max(1, big // 2) if m == n - 3 else (1 if d == 3 else 2))
