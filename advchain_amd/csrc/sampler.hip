@@ -19,29 +19,22 @@
 
 namespace advchain {
 
-// strided ownership: element k of a thread lives at p[k * st]; `n` = number of valid elements.
-// st == row length (when it is 64/128/256) makes the UNR voxels of a thread VERTICAL neighbours: their taps share
-// cache lines (row y+1 of voxel k is row y of voxel k+1) while the UNR gather chains overlap their latencies.
+// strided ownership: element k of a thread lives at p[k * kBlock]; `n` = number of valid elements
 template <int UNR>
-__device__ __forceinline__ void load_str(const float* __restrict__ p, int n, int st, float (&r)[UNR]) {
+__device__ __forceinline__ void load_str(const float* __restrict__ p, int n, float (&r)[UNR]) {
 #pragma unroll
-  for (int k = 0; k < UNR; ++k) r[k] = k < n ? p[k * st] : 0.f;
+  for (int k = 0; k < UNR; ++k) r[k] = k < n ? p[k * kBlock] : 0.f;
 }
 template <int UNR>
-__device__ __forceinline__ void store_str(float* __restrict__ p, int n, int st, const float (&r)[UNR]) {
+__device__ __forceinline__ void store_str(float* __restrict__ p, int n, const float (&r)[UNR]) {
 #pragma unroll
   for (int k = 0; k < UNR; ++k)
-    if (k < n) p[k * st] = r[k];
+    if (k < n) p[k * kBlock] = r[k];
 }
-__device__ __forceinline__ int active_count(int64_t v0, int64_t total, int unr, int st) {
+__device__ __forceinline__ int active_count(int64_t v0, int64_t total, int unr) {
   if (v0 >= total) return 0;
-  const int64_t left = (total - v0 + st - 1) / st;
+  const int64_t left = (total - v0 + kBlock - 1) / kBlock;
   return left < unr ? (int)left : unr;
-}
-// first voxel of this thread: the workgroup covers kBlock*UNR consecutive voxels as (kBlock/st) groups x UNR rows x st
-template <int UNR>
-__device__ __forceinline__ int64_t first_voxel(int st) {
-  return (int64_t)blockIdx.x * (kBlock * UNR) + (int64_t)(threadIdx.x / st) * (st * UNR) + (threadIdx.x % st);
 }
 
 // =============================================================================================
@@ -50,17 +43,17 @@ __device__ __forceinline__ int64_t first_voxel(int st) {
 template <int DIM, int INTERP, int PAD, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out, int C,
-                  Dims id, Dims od, int clamp_grid, int st) {
+                  Dims id, Dims od, int clamp_grid) {
   const int64_t IV = id.voxels(), OV = od.voxels();
   const int n = blockIdx.y;
-  const int64_t v = first_voxel<VEC>(st);
-  const int na = active_count(v, OV, VEC, st);
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, OV, VEC);
   if (na == 0) return;
   const float* g = grid + (int64_t)n * DIM * OV + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_str<VEC>(g, na, st, gx);
-  load_str<VEC>(g + OV, na, st, gy);
-  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, st, gz);
+  load_str<VEC>(g, na, gx);
+  load_str<VEC>(g + OV, na, gy);
+  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, gz);
   const float* inn = in + (int64_t)n * C * IV;
   float* outn = out + (int64_t)n * C * OV + v;
   if (INTERP == INTERP_LINEAR) {
@@ -74,7 +67,7 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD>(inn + (int64_t)c * IV, t[k], id);
-      store_str<VEC>(outn + (int64_t)c * OV, na, st, r);
+      store_str<VEC>(outn + (int64_t)c * OV, na, r);
     }
   } else {
     int off[VEC];
@@ -93,7 +86,7 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = ok[k] ? inn[(int64_t)c * IV + off[k]] : 0.f;
-      store_str<VEC>(outn + (int64_t)c * OV, na, st, r);
+      store_str<VEC>(outn + (int64_t)c * OV, na, r);
     }
   }
 }
@@ -101,18 +94,17 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
 template <int DIM, int INTERP, int PAD, int VEC, bool NEED_GIN, bool NEED_GGRID>
 __global__ void __launch_bounds__(kBlock)
 k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
-                  float* __restrict__ gin, float* __restrict__ ggrid, int C, Dims id, Dims od, int clamp_grid,
-                  int st) {
+                  float* __restrict__ gin, float* __restrict__ ggrid, int C, Dims id, Dims od, int clamp_grid) {
   const int64_t IV = id.voxels(), OV = od.voxels();
   const int n = blockIdx.y;
-  const int64_t v = first_voxel<VEC>(st);
-  const int na = active_count(v, OV, VEC, st);
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, OV, VEC);
   if (na == 0) return;
   const float* g = grid + (int64_t)n * DIM * OV + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_str<VEC>(g, na, st, gx);
-  load_str<VEC>(g + OV, na, st, gy);
-  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, st, gz);
+  load_str<VEC>(g, na, gx);
+  load_str<VEC>(g + OV, na, gy);
+  if (DIM == 3) load_str<VEC>(g + 2 * OV, na, gz);
   const float* inn = in + (int64_t)n * C * IV;
   float* ginn = NEED_GIN ? gin + (int64_t)n * C * IV : nullptr;
   const float* gon = gout + (int64_t)n * C * OV + v;
@@ -134,7 +126,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
     }
     for (int c = 0; c < C; ++c) {
       float go[VEC];
-      load_str<VEC>(gon + (int64_t)c * OV, na, st, go);
+      load_str<VEC>(gon + (int64_t)c * OV, na, go);
 #pragma unroll
       for (int k = 0; k < VEC; ++k)
         sample_linear_bwd<DIM, PAD, NEED_GIN, NEED_GGRID>(inn + (int64_t)c * IV, NEED_GIN ? ginn + (int64_t)c * IV : nullptr,
@@ -145,14 +137,14 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = pass_x[k] ? t[k].x.mult * ax[k] : 0.f;
-      store_str<VEC>(gg, na, st, r);
+      store_str<VEC>(gg, na, r);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = pass_y[k] ? t[k].y.mult * ay[k] : 0.f;
-      store_str<VEC>(gg + OV, na, st, r);
+      store_str<VEC>(gg + OV, na, r);
       if (DIM == 3) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) r[k] = pass_z[k] ? t[k].z.mult * az[k] : 0.f;
-        store_str<VEC>(gg + 2 * OV, na, st, r);
+        store_str<VEC>(gg + 2 * OV, na, r);
       }
     }
   } else {
@@ -165,7 +157,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       const int iz = DIM == 3 ? nearest_index<PAD>(gz[k], id.s0, vz) : 0;
       if (NEED_GIN && k < na && vx && vy && vz) {
         const int off = (iz * id.s1 + iy) * id.s2 + ix;
-        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * IV + off, gon[(int64_t)c * OV + k * st]);
+        for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * IV + off, gon[(int64_t)c * OV + k * kBlock]);
       }
     }
     if (NEED_GGRID) {  // nearest has zero gradient w.r.t. the grid (ATen does the same)
@@ -173,7 +165,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
       float r[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = 0.f;
-      for (int a = 0; a < DIM; ++a) store_str<VEC>(gg + (int64_t)a * OV, na, st, r);
+      for (int a = 0; a < DIM; ++a) store_str<VEC>(gg + (int64_t)a * OV, na, r);
     }
   }
 }
@@ -187,17 +179,17 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
 template <int DIM, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
-                   Dims d, int final_mode, int st) {
+                   Dims d, int final_mode) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
-  const int64_t v = first_voxel<VEC>(st);
-  const int na = active_count(v, V, VEC, st);
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, V, VEC);
   if (na == 0) return;
   const float* pn = phi + (int64_t)n * DIM * V;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_str<VEC>(pn + v, na, st, gx);
-  load_str<VEC>(pn + V + v, na, st, gy);
-  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, st, gz);
+  load_str<VEC>(pn + v, na, gx);
+  load_str<VEC>(pn + V + v, na, gy);
+  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, gz);
   Taps<DIM, PAD_BORDER> t[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
@@ -209,10 +201,10 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
     for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD_BORDER>(pn + (int64_t)c * V, t[k], d);
     if (final_mode == 1) {
       float p0[VEC];
-      load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, st, p0);
+      load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, p0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const int64_t vv = v + (int64_t)k * st;
+        const int64_t vv = v + (int64_t)k * kBlock;
         int idx;
         int S;
         if (c == 0) { idx = (int)(vv % d.s2); S = d.s2; }
@@ -221,27 +213,26 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
         r[k] = (r[k] - p0[k]) + lin_coord(idx, S);
       }
     }
-    store_str<VEC>(on + (int64_t)c * V, na, st, r);
+    store_str<VEC>(on + (int64_t)c * V, na, r);
   }
 }
 
 // gphi must be zero-initialised by the caller (scatter target).
 template <int DIM, int VEC>
 __global__ void __launch_bounds__(kBlock)
-k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d,
-                   int st) {
+k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
-  const int64_t v = first_voxel<VEC>(st);
-  const int na = active_count(v, V, VEC, st);
+  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
+  const int na = active_count(v, V, VEC);
   if (na == 0) return;
   const float* pn = phi + (int64_t)n * DIM * V;
   float* gpn = gphi + (int64_t)n * DIM * V;
   const float* gon = gout + (int64_t)n * DIM * V + v;
   float gx[VEC], gy[VEC], gz[VEC];
-  load_str<VEC>(pn + v, na, st, gx);
-  load_str<VEC>(pn + V + v, na, st, gy);
-  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, st, gz);
+  load_str<VEC>(pn + v, na, gx);
+  load_str<VEC>(pn + V + v, na, gy);
+  if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, gz);
   Taps<DIM, PAD_BORDER> t[VEC];
   float ax[VEC], ay[VEC], az[VEC];
 #pragma unroll
@@ -252,7 +243,7 @@ k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi
 #pragma unroll
   for (int c = 0; c < DIM; ++c) {
     float go[VEC];
-    load_str<VEC>(gon + (int64_t)c * V, na, st, go);
+    load_str<VEC>(gon + (int64_t)c * V, na, go);
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
       sample_linear_bwd<DIM, PAD_BORDER, true, true>(pn + (int64_t)c * V, gpn + (int64_t)c * V, go[k], t[k], d, ax[k],
@@ -262,7 +253,7 @@ k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     if (k >= na) continue;
-    const int64_t vk = v + (int64_t)k * st;
+    const int64_t vk = v + (int64_t)k * kBlock;
     if (t[k].x.mult != 0.f) atomic_add_f32(gpn + vk, t[k].x.mult * ax[k]);
     if (t[k].y.mult != 0.f) atomic_add_f32(gpn + V + vk, t[k].y.mult * ay[k]);
     if (DIM == 3 && t[k].z.mult != 0.f) atomic_add_f32(gpn + 2 * V + vk, t[k].z.mult * az[k]);
@@ -552,9 +543,6 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
 // UNR = 4 independent voxels per thread once the volume fills the chip; ADVCHAIN_UNR1 forces 1 (A/B tests)
-static inline int row_stride(const Dims& d, bool unroll) {
-  return (unroll && (d.s2 == 64 || d.s2 == 128 || d.s2 == 256)) ? d.s2 : kBlock;
-}
 // Measured on MI355X (tools/kernel_bench.py): 2D gathers gain 1.2x from 4 chains per thread; in 3D the 4 chains
 // sit 4 rows apart in 2 z-planes x C channels and thrash the 32 KiB L1, so one voxel per thread wins (1.3x).
 static inline bool use_unroll(int64_t voxels, int ndim) {
@@ -580,11 +568,11 @@ static int launch_grid_sample_fwd(const float* in, const float* grid, float* out
   dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
   DISPATCH_PAD(padding, {
     if (interp == INTERP_LINEAR) {
-      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, row_stride(od, vec4));
-      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, row_stride(od, vec4));
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
     } else {
-      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, row_stride(od, vec4));
-      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, row_stride(od, vec4));
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();
@@ -592,11 +580,11 @@ static int launch_grid_sample_fwd(const float* in, const float* grid, float* out
 }
 
 template <int DIM, int INTERP, int PAD, int VEC>
-static void launch_gs_bwd_flags(dim3 g, dim3 b, hipStream_t stream, const float* gout, const float* in, const float* grid,
-                                float* gin, float* ggrid, int C, Dims id, Dims od, int clamp_grid, int st) {
-  if (gin && ggrid) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, true>), g, b, 0, stream, gout, in, grid, gin, ggrid, C, id, od, clamp_grid, st);
-  else if (gin) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, false>), g, b, 0, stream, gout, in, grid, gin, ggrid, C, id, od, clamp_grid, st);
-  else hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, false, true>), g, b, 0, stream, gout, in, grid, gin, ggrid, C, id, od, clamp_grid, st);
+static void launch_gs_bwd_flags(dim3 g, dim3 b, hipStream_t st, const float* gout, const float* in, const float* grid,
+                                float* gin, float* ggrid, int C, Dims id, Dims od, int clamp_grid) {
+  if (gin && ggrid) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, true>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
+  else if (gin) hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, true, false>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
+  else hipLaunchKernelGGL((k_grid_sample_bwd<DIM, INTERP, PAD, VEC, false, true>), g, b, 0, st, gout, in, grid, gin, ggrid, C, id, od, clamp_grid);
 }
 
 template <int DIM>
@@ -609,11 +597,11 @@ static int launch_grid_sample_bwd(const float* gout, const float* in, const floa
   dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
   DISPATCH_PAD(padding, {
     if (interp == INTERP_LINEAR) {
-      if (vec4) launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid, row_stride(od, vec4));
-      else launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid, row_stride(od, vec4));
+      if (vec4) launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+      else launch_gs_bwd_flags<DIM, INTERP_LINEAR, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
     } else {
-      if (vec4) launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid, row_stride(od, vec4));
-      else launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid, row_stride(od, vec4));
+      if (vec4) launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 4>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
+      else launch_gs_bwd_flags<DIM, INTERP_NEAREST, PAD, 1>(g, b, st, gout, in, grid, gin, ggrid, (int)C, id, od, clamp_grid);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();
@@ -697,11 +685,11 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (ndim == 3) {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<3, 4>), g, b, 0, st, phi, out, phi0, d, final_mode, row_stride(d, vec4));
-    else hipLaunchKernelGGL((k_compose_self_fwd<3, 1>), g, b, 0, st, phi, out, phi0, d, final_mode, row_stride(d, vec4));
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<3, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    else hipLaunchKernelGGL((k_compose_self_fwd<3, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
   } else {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<2, 4>), g, b, 0, st, phi, out, phi0, d, final_mode, row_stride(d, vec4));
-    else hipLaunchKernelGGL((k_compose_self_fwd<2, 1>), g, b, 0, st, phi, out, phi0, d, final_mode, row_stride(d, vec4));
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<2, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    else hipLaunchKernelGGL((k_compose_self_fwd<2, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
@@ -723,11 +711,11 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (ndim == 3) {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<3, 4>), g, b, 0, st, grad_out, phi, grad_phi, d, row_stride(d, vec4));
-    else hipLaunchKernelGGL((k_compose_self_bwd<3, 1>), g, b, 0, st, grad_out, phi, grad_phi, d, row_stride(d, vec4));
+    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<3, 4>), g, b, 0, st, grad_out, phi, grad_phi, d);
+    else hipLaunchKernelGGL((k_compose_self_bwd<3, 1>), g, b, 0, st, grad_out, phi, grad_phi, d);
   } else {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<2, 4>), g, b, 0, st, grad_out, phi, grad_phi, d, row_stride(d, vec4));
-    else hipLaunchKernelGGL((k_compose_self_bwd<2, 1>), g, b, 0, st, grad_out, phi, grad_phi, d, row_stride(d, vec4));
+    if (vec4) hipLaunchKernelGGL((k_compose_self_bwd<2, 4>), g, b, 0, st, grad_out, phi, grad_phi, d);
+    else hipLaunchKernelGGL((k_compose_self_bwd<2, 1>), g, b, 0, st, grad_out, phi, grad_phi, d);
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;

@@ -1,0 +1,139 @@
+"""Full BASELINE sizes (cfg-2: 32x1x256x256, cfg-3: 4x1x128x128x64) on the GPU, checked through size-independent
+properties, since the CPU oracle needs minutes there: adjointness <A x, y> = <x, A^T y> of every forward/backward
+kernel pair, linearity, identity warps, agreement of the two independent scatter implementations, bitwise
+run-to-run determinism of the fixed-point scatter, and one whole solver call (finite, ascent does not lower the
+loss, parameters obey their constraints)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+SHAPES = {"cfg2": dict(N=32, dims=(256, 256), vs=[16, 16]), "cfg3": dict(N=4, dims=(128, 128, 64), vs=[8, 8, 32])}
+
+
+def _morph(shape, eps=1.5, seed=0):
+    from advchain_amd.augmentor import AdvMorph
+    s = SHAPES[shape]
+    torch.manual_seed(seed)
+    t = AdvMorph(spatial_dims=len(s["dims"]), config_dict=dict(epsilon=eps, data_size=[s["N"], 1] + list(s["dims"]),
+                                                               vector_size=s["vs"]), device=DEV)
+    t.init_parameters()
+    return t, s
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+def test_warp_adjoint_linearity_and_paths(shape):
+    from advchain_amd import ops
+    t, s = _morph(shape)
+    with torch.no_grad():
+        q = t._field(1.0).contiguous()
+    for C in (1, 4):
+        x = torch.rand(s["N"], C, *s["dims"], device=DEV)
+        y = torch.rand(s["N"], C, *s["dims"], device=DEV)
+        Ax = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        # linear in the image
+        Ax2 = ops.raw_grid_sample_fwd(2.5 * x + y, q, 0, 0, True)
+        Ay = ops.raw_grid_sample_fwd(y, q, 0, 0, True)
+        assert float((Ax2 - (2.5 * Ax + Ay)).abs().max()) < 2e-5
+        # adjoint: <A x, y> == <x, A^T y>
+        ATy, gq = ops.raw_grid_sample_bwd(y, x, q, 0, 0, True, True, True)
+        lhs, rhs = dot(Ax, y), dot(x, ATy)
+        assert abs(lhs - rhs) < 1e-5 * abs(lhs), (lhs, rhs)
+        # the two scatter implementations agree; the tiled (fixed-point) one is bitwise deterministic
+        ATy_again, _ = ops.raw_grid_sample_bwd(y, x, q, 0, 0, True, True, False)
+        assert torch.equal(ATy, ATy_again)
+        old = ops.TILED_SCATTER
+        ops.TILED_SCATTER = False
+        try:
+            ATy_atomic, gq_atomic = ops.raw_grid_sample_bwd(y, x, q, 0, 0, True, True, True)
+        finally:
+            ops.TILED_SCATTER = old
+        scale = float(ATy_atomic.abs().max())
+        assert float((ATy - ATy_atomic).abs().max()) < 2e-5 * scale
+        assert float((gq - gq_atomic).abs().max()) < 1e-4 * float(gq_atomic.abs().max())
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+def test_identity_field_is_identity_warp(shape):
+    from advchain_amd import ops
+    t, s = _morph(shape)
+    zero = torch.zeros_like(t.param)
+    q = ops.demons_field(zero, 1.0, t._tables, len(s["dims"]) == 3)
+    x = torch.rand(s["N"], 2, *s["dims"], device=DEV)
+    out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+    # rounding doubles in each of the 8 squarings (2^8 * 6e-8 = 1.5e-5 normalised = 2e-3 px at S=256): on
+    # white-noise data (|neighbour difference| ~ 1) the identity warp is exact only to that level
+    assert float((out - x).abs().max()) < 1e-2
+    assert float((out - x).abs().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+def test_compose_self_jvp_matches_vjp(shape):
+    """<J dphi, g> == <dphi, J^T g> with J dphi from a central difference of the forward kernel."""
+    from advchain_amd import ops
+    t, s = _morph(shape)
+    d = len(s["dims"])
+    phi = ops.raw_tp_interp(ops.raw_gauss(t.param, d, pre=1, scale=1.5), t._tables, d, add_identity=True, scale=1 / 16.)
+    # smooth direction, small enough that (almost) no sample crosses a cell boundary inside [-h, h]
+    dphi = ops.raw_gauss(torch.randn_like(phi), d)
+    g = torch.randn_like(phi)
+    h = 1e-4
+    jv = (ops.raw_compose_self_fwd(phi + h * dphi) - ops.raw_compose_self_fwd(phi - h * dphi)) / (2 * h)
+    vj = ops.raw_compose_self_bwd(g, phi)
+    lhs, rhs = dot(jv, g), dot(dphi, vj)
+    assert abs(lhs - rhs) < 3e-2 * max(abs(lhs), abs(rhs)) + 1.0, (lhs, rhs)   # fp32 finite difference
+    assert torch.equal(vj, ops.raw_compose_self_bwd(g, phi))   # deterministic
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+def test_linear_kernels_are_adjoint_pairs(shape):
+    from advchain_amd import ops
+    t, s = _morph(shape)
+    d = len(s["dims"])
+    N = s["N"]
+    # separable Gaussian is self-adjoint
+    a = torch.randn(N, d, *s["dims"], device=DEV)
+    b = torch.randn(N, d, *s["dims"], device=DEV)
+    lhs, rhs = dot(ops.raw_gauss(a, d), b), dot(a, ops.raw_gauss(b, d))
+    assert abs(lhs - rhs) < 1e-5 * abs(lhs) + 1e-3
+    # upsample and its adjoint
+    v = torch.randn_like(t.param)
+    up = ops.raw_tp_interp(v, t._tables, d)
+    adj = ops.raw_tp_adjoint(b, t._tables)
+    lhs, rhs = dot(up, b), dot(v, adj)
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    # affine warp: <A x, y> == <x, A^T y>
+    theta = (torch.eye(d, d + 1, device=DEV).repeat(N, 1, 1) + 0.05 * torch.randn(N, d, d + 1, device=DEV)).contiguous()
+    x = torch.rand(N, 4, *s["dims"], device=DEV).requires_grad_(True)
+    y = torch.rand(N, 4, *s["dims"], device=DEV)
+    Ax = ops.affine_warp(x, theta)
+    (gx,) = torch.autograd.grad(Ax, x, y)
+    lhs, rhs = dot(Ax.detach(), y), dot(x.detach(), gx)
+    assert abs(lhs - rhs) < 1e-5 * abs(lhs)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_whole_solver_call_at_full_size(name):
+    import bench
+    wl = dict(bench.WORKLOADS[name])
+    solver = bench.build_solver(wl, DEV)
+    torch.manual_seed(0)
+    data = torch.rand(wl["batch"], 1, *wl["dims"], device=DEV)
+    model = bench.make_model(len(wl["dims"])).to(DEV)
+    loss0 = solver.adversarial_training(data=data, model=model, n_iter=0)
+    params0 = [t.param.clone() for t in solver.chain_of_transforms]
+    loss1 = solver.adversarial_training(data=data, model=model, n_iter=wl["n_iter"], lazy_load=True, step_sizes=1)
+    assert torch.isfinite(loss0) and torch.isfinite(loss1) and float(loss1) > 0
+    assert solver.adv_data.shape == data.shape and torch.isfinite(solver.adv_data).all()
+    for t, p0 in zip(solver.chain_of_transforms, params0):
+        assert torch.isfinite(t.param).all() and not torch.equal(t.param, p0)
+        if t.get_name() in ("noise", "morph"):     # rescaled to the unit L2 ball per sample at the end
+            norms = t.param.reshape(t.param.shape[0], -1).norm(dim=1)
+            assert float((norms - 1).abs().max()) < 1e-4
+        if t.get_name() == "bias":
+            assert float(t.param.max()) <= t.high + 1e-6 and float(t.param.min()) >= t.low - 1e-6
