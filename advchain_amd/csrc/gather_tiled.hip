@@ -1,0 +1,225 @@
+// LDS-staged forward sampler (gfx950): advchain_compose_self_fwd and advchain_grid_sample_fwd for near-identity
+// warps at equal input/output size.
+//
+// Measured rule on MI355X (profiles/): a vector-memory instruction costs a CU ~26 clk (dword) to
+// ~47 clk (dwordx4) whatever it carries, so a kernel that gathers 2^d corners x C channels per voxel from global
+// memory is bound by its instruction count (compose_self_fwd: 30 per voxel-wave = 1.3 TB/s), not by bytes.
+// Here a workgroup stages the input tile plus a halo into LDS with 16-byte loads (each line is fetched once per
+// workgroup), then every thread takes its taps from LDS (ds_read, ~100 clk latency instead of ~2 us) and writes
+// 4 consecutive voxels with one 16-byte store.  Corners outside the staged region (displacement beyond the halo)
+// fall back to global gathers, so results do not depend on the halo size.
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+struct GTile {
+  int t0, t1, t2;   // output tile (z, y, x); t2 % 4 == 0
+  int h0, h1, h2;   // halo; h2 % 4 == 0
+  int n0, n1, n2;   // tiles per axis
+  int rw;           // staged row pitch (floats), multiple of 4
+};
+
+template <int DIM, int PAD, int C, bool SELF>
+__global__ void __launch_bounds__(kBlock)
+k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
+               const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode) {
+  extern __shared__ float lds[];
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  int b = blockIdx.x;
+  const int tx = b % tc.n2; b /= tc.n2;
+  const int ty = b % tc.n1;
+  const int tz = b / tc.n1;
+  const int x0 = tx * tc.t2, y0 = ty * tc.t1, z0 = tz * tc.t0;
+  // staged region, clipped to the volume (x bounds stay multiples of 4 because S2 % 4 == 0)
+  const int rx0 = max(x0 - tc.h2, 0), rx1 = min(x0 + tc.t2 + tc.h2, d.s2);
+  const int ry0 = max(y0 - tc.h1, 0), ry1 = min(y0 + tc.t1 + tc.h1, d.s1);
+  const int rz0 = max(z0 - tc.h0, 0), rz1 = min(z0 + tc.t0 + tc.h0, d.s0);
+  const int rw = tc.rw, rh = ry1 - ry0, rd = rz1 - rz0;
+  const int rw4 = (rx1 - rx0) >> 2;
+  const int plane = rw * rh * rd;       // floats per staged channel
+  const float* inn = in + (int64_t)n * C * V;
+  // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
+  const int rows = C * rd * rh;
+  for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
+    const int q = e % rw4;
+    const int r = e / rw4;
+    const int ly = r % rh;
+    const int r2 = r / rh;
+    const int lz = r2 % rd;
+    const int c = r2 / rd;
+    const float4 v = *reinterpret_cast<const float4*>(inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q);
+    *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+  }
+  __syncthreads();
+  // ---- compute: each thread owns quads of 4 consecutive x
+  const int tq = tc.t2 >> 2;                       // quads per tile row
+  const int nquads = tc.t0 * tc.t1 * tq;
+  const float* gn = SELF ? nullptr : grid + (int64_t)n * DIM * V;
+  float* on = out + (int64_t)n * C * V;
+  for (int qi = threadIdx.x; qi < nquads; qi += kBlock) {
+    const int qx = qi % tq;
+    const int r = qi / tq;
+    const int ly = r % tc.t1;
+    const int lz = r / tc.t1;
+    const int sx = x0 + 4 * qx, sy = y0 + ly, sz = z0 + lz;
+    if (sx >= d.s2 || sy >= d.s1 || sz >= d.s0) continue;
+    const int s = (sz * d.s1 + sy) * d.s2 + sx;
+    float g[3][4];
+    if (SELF) {
+      const int lo = ((sz - rz0) * rh + (sy - ry0)) * rw + (sx - rx0);
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + a * plane + lo);
+        g[a][0] = v.x; g[a][1] = v.y; g[a][2] = v.z; g[a][3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        const float4 v = *reinterpret_cast<const float4*>(gn + (int64_t)a * V + s);
+        g[a][0] = v.x; g[a][1] = v.y; g[a][2] = v.z; g[a][3] = v.w;
+      }
+    }
+    float res[C][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gx = g[0][k], gy = g[1][k], gz = DIM == 3 ? g[DIM - 1][k] : 0.f;
+      if (clamp_grid) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
+      Taps<DIM, PAD> t;
+      t.build(gx, gy, gz, d);
+      // corner box clamped to the volume; inside the staged region?
+      const int cx0 = max(t.x.i0, 0), cx1 = min(t.x.i0 + 1, d.s2 - 1);
+      const int cy0 = max(t.y.i0, 0), cy1 = min(t.y.i0 + 1, d.s1 - 1);
+      const int cz0 = DIM == 3 ? max(t.z.i0, 0) : 0, cz1 = DIM == 3 ? min(t.z.i0 + 1, d.s0 - 1) : 0;
+      const bool staged = (cx0 >= rx0) && (cx1 < rx1) && (cy0 >= ry0) && (cy1 < ry1) && (cz0 >= rz0) && (cz1 < rz1) &&
+                          (cx0 <= cx1) && (cy0 <= cy1) && (cz0 <= cz1);
+      if (staged) {
+        const int ox[2] = {cx0 - rx0, cx1 - rx0};
+        const int oy[2] = {(cy0 - ry0) * rw, (cy1 - ry0) * rw};
+        const int oz[2] = {(cz0 - rz0) * rh * rw, (cz1 - rz0) * rh * rw};
+        float w[8];
+#pragma unroll
+        for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) w[(cz * 2 + cy) * 2 + cx] = t.ok(cz, cy, cx) ? t.w(cz, cy, cx) : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float* p = lds + c * plane;
+          float acc = 0.f;
+#pragma unroll
+          for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+              for (int cx = 0; cx < 2; ++cx) acc += p[oz[cz] + oy[cy] + ox[cx]] * w[(cz * 2 + cy) * 2 + cx];
+          res[c][k] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][k] = sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float4 o = make_float4(res[c][0], res[c][1], res[c][2], res[c][3]);
+      if (SELF && final_mode == 1) {
+        // (sample - phi0) + identity   (adv_morph.py:143,176 + 474,483)
+        const float4 p0 = *reinterpret_cast<const float4*>(phi0 + ((int64_t)n * DIM + c) * V + s);
+        float id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          id[k] = c == 0 ? lin_coord(sx + k, d.s2) : (c == 1 ? lin_coord(sy, d.s1) : lin_coord(sz, d.s0));
+        o = make_float4((o.x - p0.x) + id[0], (o.y - p0.y) + id[1], (o.z - p0.z) + id[2], (o.w - p0.w) + id[3]);
+      }
+      *reinterpret_cast<float4*>(on + (int64_t)c * V + s) = o;
+    }
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& tc) {
+  static const int h3 = getenv("ADVCHAIN_GTILE_H3") ? atoi(getenv("ADVCHAIN_GTILE_H3")) : 1;   // tuning knobs
+  static const int h2 = getenv("ADVCHAIN_GTILE_H2") ? atoi(getenv("ADVCHAIN_GTILE_H2")) : 8;
+  if (d.s2 % 4 != 0 || d.s2 < 8) return false;
+  static const bool tiles_2d = getenv("ADVCHAIN_GTILE_2D") != nullptr;
+  if (ndim == 2 && !tiles_2d) return false;   // measured: in 2D (4 corners) the direct 4-chain gather kernels are faster
+  int h = ndim == 3 ? h3 : h2;
+  if (halo_hint > 0) h = halo_hint;
+  static const int t0_3 = getenv("ADVCHAIN_GTILE_T0") ? atoi(getenv("ADVCHAIN_GTILE_T0")) : 2;   // measured: small tiles (more resident workgroups) beat low halo amplification
+  static const int t1_3 = getenv("ADVCHAIN_GTILE_T1") ? atoi(getenv("ADVCHAIN_GTILE_T1")) : 8;
+  static const int t1_2 = getenv("ADVCHAIN_GTILE_T1_2D") ? atoi(getenv("ADVCHAIN_GTILE_T1_2D")) : 16;
+  if (ndim == 3) { tc.t0 = t0_3; tc.t1 = t1_3; tc.h0 = tc.h1 = h; }
+  else { tc.t0 = 1; tc.t1 = t1_2; tc.h0 = 0; tc.h1 = h; }
+  if (d.s2 <= 64) { tc.t2 = d.s2; tc.h2 = 0; }
+  else { tc.t2 = 64; tc.h2 = (h + 3) / 4 * 4; }
+  if (tc.t1 > d.s1) tc.t1 = d.s1;
+  if (tc.t0 > d.s0) tc.t0 = d.s0;
+  auto bytes = [&]() {
+    return (int64_t)C * (tc.t0 + 2 * tc.h0) * (tc.t1 + 2 * tc.h1) * (tc.t2 + 2 * tc.h2) * 4;
+  };
+  while (bytes() > 65536) {
+    if (tc.t0 > 1) tc.t0 = (tc.t0 + 1) / 2;
+    else if (tc.t1 > 2) tc.t1 = (tc.t1 + 1) / 2;
+    else return false;
+  }
+  tc.rw = tc.t2 + 2 * tc.h2;
+  tc.n2 = (d.s2 + tc.t2 - 1) / tc.t2;
+  tc.n1 = (d.s1 + tc.t1 - 1) / tc.t1;
+  tc.n0 = (d.s0 + tc.t0 - 1) / tc.t0;
+  return true;
+}
+
+template <int DIM, int PAD, bool SELF>
+static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const float* in, const float* grid, float* out,
+                            const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode) {
+#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode)
+  switch (C) {
+    case 1: if constexpr (!SELF) { LAUNCH(1); return true; } return false;
+    case 2: if constexpr (!SELF || DIM == 2) { LAUNCH(2); return true; } return false;
+    case 3: if constexpr (!SELF || DIM == 3) { LAUNCH(3); return true; } return false;
+    case 4: if constexpr (!SELF) { LAUNCH(4); return true; } return false;
+    default: return false;
+  }
+#undef LAUNCH
+}
+
+// Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify (caller uses the direct-gather kernels).
+int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
+                                 int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
+                                 int halo, hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_GATHER_TILES") != nullptr;   // A/B knob
+  if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
+                       reinterpret_cast<uintptr_t>(grid) | reinterpret_cast<uintptr_t>(phi0);
+  if (al & 15) return ADVCHAIN_ERR_UNSUPPORTED;
+  GTile tc;
+  if (!choose_gtile(ndim, d, (int)C, halo, tc)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)C * (tc.t0 + 2 * tc.h0) * (tc.t1 + 2 * tc.h1) * tc.rw * sizeof(float);
+  dim3 g((unsigned)(tc.n0 * tc.n1 * tc.n2), (unsigned)N);
+  bool ok = false;
+  if (self) {
+    ok = ndim == 3 ? launch_sample_c<3, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode)
+                   : launch_sample_c<2, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode);
+  } else if (ndim == 3) {
+    switch (padding) {
+      case PAD_ZEROS: ok = launch_sample_c<3, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      case PAD_BORDER: ok = launch_sample_c<3, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      default: ok = launch_sample_c<3, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+    }
+  } else {
+    switch (padding) {
+      case PAD_ZEROS: ok = launch_sample_c<2, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      case PAD_BORDER: ok = launch_sample_c<2, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      default: ok = launch_sample_c<2, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+    }
+  }
+  if (!ok) return ADVCHAIN_ERR_UNSUPPORTED;
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}

@@ -539,6 +539,11 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                   int32_t* workspace, int chain, int halo, hipStream_t st);
 
+// gather_tiled.hip
+int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
+                                 int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
+                                 int halo, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
@@ -645,6 +650,11 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
   if (N == 0) return ADVCHAIN_OK;
   const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_fwd: per-sample volume too large");
+  if (interp == INTERP_LINEAR && id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2) {   // LDS-staged tiles
+    const int rc = advchain_sample_tiled_launch(false, in, grid, out, nullptr, N, C, ndim, id, padding, clamp_grid, 0, 0,
+                                                (hipStream_t)stream);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
   return ndim == 3 ? launch_grid_sample_fwd<3>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_fwd<2>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
@@ -681,6 +691,11 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
+  {
+    const int rc = advchain_sample_tiled_launch(true, phi, nullptr, out, phi0, N, ndim, ndim, d, PAD_BORDER, 0,
+                                                final_mode, 0, (hipStream_t)stream);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
