@@ -1,0 +1,390 @@
+// Gather-form adjoint of the self-composition  phi -> phi o phi  for sub-H-voxel displacements (gfx950).
+//
+// The backward of grid_sample is a scatter-add: sample s deposits w * grad_out[s] on the 2^d corners of its sampling
+// position p_s.  When |p_s - s| < H voxels on every axis (the early squarings of adv_morph.py:132-135,165-168 compose
+// fields whose displacement is 2^-k of the total) every corner of s lies within s +- H, so the same sum can be
+// written from the receiving side with the (bi/tri)linear weight in its tent form:
+//
+//     grad_phi_c[u] = sum_{s in u +- H} grad_out_c[s] * prod_a max(0, 1 - |p_s,a - u_a|)  +  (coordinate path at s = u)
+//
+// No atomics, no fixed point, fixed summation order.  A workgroup stages phi and grad_out of its tile plus an H-halo
+// in LDS (16 bytes per lane), then
+//   stage    phi is stored as the offset o = unnormalize(phi) - s of the sampling position from the sample's own voxel
+//            (phi itself is recoverable from it); samples whose clipped offset leaves -H <= f < H ("irregular": large
+//            displacement, NaN) get grad_out = 0 in LDS, and their owner appends them to the overflow list;
+//   phase A  every owned sample takes the 2^d corner values of the field from LDS and forms the coordinate-path
+//            gradient (the part ATen calls grad_grid) in registers;
+//   phase B  lane <-> x: for every owned output row the wave walks the (2H+1)^(d-1) neighbouring sample rows; each
+//            lane keeps 2H+1 partial sums (its sample's deposits on x-H..x+H), which 2H whole-wave DPP shifts fold
+//            into the owning lanes at the end.
+// The overflow list (normally empty) is drained by a second launch with global atomics, all corners of a sample.
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+constexpr int kXPad = 4;   // x halo of a 64-lane row when the row is wider than one wave (multiple of 4, >= H)
+
+__global__ void k_gather_prepare(int32_t* ws, int chain) {
+  ws[2] = chain ? ws[3] : 0;
+  ws[0] = 0;
+  ws[1] = 0;
+  ws[3] = 0;
+}
+
+// weight of a sample at offset f (= p - s) for the output at s + E
+template <int E>
+__device__ __forceinline__ float tent(float f) { return fmaxf(0.f, 1.f - fabsf(f - (float)E)); }
+
+template <int H, int K = -H>
+struct XSpread {
+  // acc[c][K + H] += a[c] * tent<K>(fx) for K = -H..H
+  template <int C>
+  static __device__ __forceinline__ void run(float (&acc)[C][2 * H + 1], const float (&a)[C], float fx) {
+    const float w = tent<K>(fx);
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c][K + H] = fmaf(a[c], w, acc[c][K + H]);
+    if constexpr (K < H) XSpread<H, K + 1>::template run<C>(acc, a, fx);
+  }
+};
+
+template <int DIM, int H, int TZ, int TY, int NT>
+struct GatherCfg {
+  static constexpr int RZ = DIM == 3 ? TZ + 2 * H : 1;
+  static constexpr int RY = TY + 2 * H;
+  static constexpr int ROWS = RZ * RY;
+  static constexpr int NW = NT / 64;
+  static constexpr int OWNED = (DIM == 3 ? TZ : 1) * TY;
+  static constexpr int RPW = OWNED / NW;
+  static constexpr int CH = 2 * DIM;
+  static constexpr size_t LDS = (size_t)CH * ROWS * 64 * sizeof(float);
+  static_assert(OWNED % NW == 0, "owned rows must divide evenly among the waves");
+};
+
+// unnormalised source coordinate of a normalised grid value (GridSampler.h grid_sampler_unnormalize, align_corners)
+__device__ __forceinline__ float unnormalize(float g, int S) { return ((g + 1.f) * 0.5f) * (float)(S - 1); }
+
+template <int DIM, int H, int TZ, int TY, int NT>
+__global__ void __launch_bounds__(NT)
+k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d,
+                      int n1, int n2, int wide, float* __restrict__ absmax_out, int* __restrict__ ovf_count,
+                      int2* __restrict__ ovf_list, int ovf_cap, int dbg) {
+  using G = GatherCfg<DIM, H, TZ, TY, NT>;
+  constexpr int RY = G::RY, ROWS = G::ROWS, NW = G::NW, RPW = G::RPW;
+  // [2*DIM][ROWS][64]: channels 0..DIM-1 hold o = unnormalize(phi) - s (unclipped offset of the sampling position from
+  // the sample's own voxel, in voxels), channels DIM..2*DIM-1 grad_out (0 for irregular samples)
+  extern __shared__ float lds[];
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int b = blockIdx.x;
+  const int tx = b % n2; b /= n2;
+  const int ty = b % n1;
+  const int tz = b / n1;
+  const int xown = wide ? 64 - 2 * kXPad : 64;
+  const int x0 = tx * xown, y0 = ty * TY, z0 = DIM == 3 ? tz * TZ : 0;
+  const int rx0 = wide ? x0 - kXPad : 0;          // x of lane 0 (multiple of 4)
+  const int ry0 = y0 - H, rz0 = DIM == 3 ? z0 - H : 0;
+  const float* phin = phi + (int64_t)n * DIM * V;
+  const float* gon = gout + (int64_t)n * DIM * V;
+  const int S[3] = {d.s2, d.s1, d.s0};
+  const float fH = (float)H;
+
+  // ---- stage: one item = 4 consecutive x of one region row, all channels (rows / quads outside the volume: zeros)
+  for (int e = threadIdx.x; e < ROWS * 16; e += NT) {
+    const int q = e & 15;
+    const int r = e >> 4;
+    const int sy = ry0 + r % RY, sz = rz0 + r / RY;
+    const int x = rx0 + 4 * q;
+    float o[DIM][4], g[DIM][4];
+    const bool inside = !(dbg & 8) && sy >= 0 && sy < d.s1 && sz >= 0 && sz < d.s0 && x >= 0 && x < d.s2;
+    if (inside) {
+      const int s = (sz * d.s1 + sy) * d.s2 + x;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) load_vec<4>(phin + (int64_t)a * V + s, o[a]);
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) load_vec<4>(gon + (int64_t)a * V + s, g[a]);
+      const int sc[3] = {x, sy, sz};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bool regular = true;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+          const float xs = unnormalize(o[a][k], S[a]);
+          const float sa = (float)(sc[a] + (a == 0 ? k : 0));
+          const float f = fminf(fmaxf(xs, 0.f), (float)(S[a] - 1)) - sa;     // clipped (border padding)
+          regular = regular && (f >= -fH) && (f < fH);                        // false for NaN
+          o[a][k] = (xs > -1.0e9f && xs < 1.0e9f) ? xs - sa : 0.f;
+        }
+        if (!regular) {
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) g[a][k] = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < DIM; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[a][k] = 0.f; g[a][k] = 0.f; }
+    }
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+      store_vec<4>(lds + (a * ROWS + r) * 64 + 4 * q, o[a]);
+      store_vec<4>(lds + ((DIM + a) * ROWS + r) * 64 + 4 * q, g[a]);
+    }
+  }
+  __syncthreads();
+
+  const int sx = rx0 + lane;
+  const bool xowned = wide ? (lane >= kXPad && lane < 64 - kXPad && sx < d.s2) : (sx < d.s2);
+  const float xlo = -(float)sx, xhi = (float)(d.s2 - 1 - sx);   // clip bounds of a sample in this lane, as offsets
+  float* gpn = gphi + (int64_t)n * DIM * V;
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int o = wave + j * NW;
+    const int ly = o % TY, lz = o / TY;
+    const int uy = y0 + ly, uz = z0 + lz;
+    if (uy >= d.s1 || uz >= d.s0) continue;   // wave-uniform
+    const int rc = (DIM == 3 ? (lz + H) * RY : 0) + ly + H;
+
+    // ---- phase A: coordinate-path gradient of the sample at this output position
+    float gg[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) gg[a] = 0.f;
+    if (xowned && !(dbg & 1)) {
+      const int sc[3] = {sx, uy, uz};
+      float w1[3] = {0.f, 0.f, 0.f}, mult[3] = {0.f, 0.f, 0.f};
+      int i0[3] = {0, 0, 0};
+      bool regular = true;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) {
+        float xs = lds[(a * ROWS + rc) * 64 + lane] + (float)sc[a];
+        mult[a] = 0.5f * (float)(S[a] - 1);
+        if (xs <= 0.f) { xs = 0.f; mult[a] = 0.f; }
+        else if (xs >= (float)(S[a] - 1)) { xs = (float)(S[a] - 1); mult[a] = 0.f; }
+        const float fl = floorf(xs);
+        i0[a] = (int)fl;
+        w1[a] = xs - fl;
+        const float f = xs - (float)sc[a];
+        regular = regular && (f >= -fH) && (f < fH);
+      }
+      float acc3[3] = {0.f, 0.f, 0.f};
+      if (regular) {
+        float go[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) go[c] = lds[((DIM + c) * ROWS + rc) * 64 + lane];
+        // corners clamped into the volume: a clamped corner carries weight 0 / multiplier 0 under border padding
+        const int lx0 = i0[0] - rx0, ex = min(i0[0] + 1, d.s2 - 1) - i0[0];
+        const int r00 = (DIM == 3 ? (i0[2] - rz0) * RY : 0) + (i0[1] - ry0);
+        const int ey = min(i0[1] + 1, d.s1 - 1) - i0[1];
+        const int ez = DIM == 3 ? min(i0[2] + 1, d.s0 - 1) - i0[2] : 0;
+        const float wx1 = w1[0], wx0 = 1.f - wx1, wy1 = w1[1], wy0 = 1.f - wy1, wz1 = w1[2], wz0 = 1.f - wz1;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          const float* p = lds + c * ROWS * 64;
+          float v[2][2][2];
+#pragma unroll
+          for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+              const int r = r00 + (cz ? ez * RY : 0) + (cy ? ey : 0);
+              v[cz][cy][0] = p[r * 64 + lx0];
+              v[cz][cy][1] = p[r * 64 + lx0 + ex];
+            }
+          // phi_c(u) = (v(u) + u_c) * 2/(S_c-1) - 1: only differences along an axis enter; the identity part of the
+          // difference is the (clamped) index step on axis c
+          const float ux = c == 0 ? (float)ex : 0.f, uyy = c == 1 ? (float)ey : 0.f, uzz = c == 2 ? (float)ez : 0.f;
+          float dx, dy, dz = 0.f;
+          if (DIM == 3) {
+            dx = ((v[0][0][1] - v[0][0][0] + ux) * wy0 + (v[0][1][1] - v[0][1][0] + ux) * wy1) * wz0 +
+                 ((v[1][0][1] - v[1][0][0] + ux) * wy0 + (v[1][1][1] - v[1][1][0] + ux) * wy1) * wz1;
+            dy = ((v[0][1][0] - v[0][0][0] + uyy) * wx0 + (v[0][1][1] - v[0][0][1] + uyy) * wx1) * wz0 +
+                 ((v[1][1][0] - v[1][0][0] + uyy) * wx0 + (v[1][1][1] - v[1][0][1] + uyy) * wx1) * wz1;
+            dz = ((v[1][0][0] - v[0][0][0] + uzz) * wx0 + (v[1][0][1] - v[0][0][1] + uzz) * wx1) * wy0 +
+                 ((v[1][1][0] - v[0][1][0] + uzz) * wx0 + (v[1][1][1] - v[0][1][1] + uzz) * wx1) * wy1;
+          } else {
+            dx = (v[0][0][1] - v[0][0][0] + ux) * wy0 + (v[0][1][1] - v[0][1][0] + ux) * wy1;
+            dy = (v[0][1][0] - v[0][0][0] + uyy) * wx0 + (v[0][1][1] - v[0][0][1] + uyy) * wx1;
+          }
+          const float kc = go[c] * (2.f / (float)(S[c] - 1));
+          acc3[0] = fmaf(dx, kc, acc3[0]); acc3[1] = fmaf(dy, kc, acc3[1]); acc3[2] = fmaf(dz, kc, acc3[2]);
+        }
+      } else {
+        // irregular sample: taps and corner values from global memory, deposits through the overflow list
+        const int s = (uz * d.s1 + uy) * d.s2 + sx;
+        Taps<DIM, PAD_BORDER> t;
+        t.build(phin[s], phin[V + s], DIM == 3 ? phin[2 * V + s] : 0.f, d);
+        float dummy = 0.f;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+          sample_linear_bwd<DIM, PAD_BORDER, false, true>(phin + (int64_t)c * V, nullptr, gon[(int64_t)c * V + s], t, d,
+                                                          acc3[0], acc3[1], DIM == 3 ? acc3[2] : dummy);
+        mult[0] = t.x.mult; mult[1] = t.y.mult; mult[2] = t.z.mult;
+        const int slot = atomicAdd(ovf_count, 1);
+        if (slot < ovf_cap) ovf_list[slot] = make_int2(n, s);
+      }
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) gg[a] = mult[a] * acc3[a];
+    }
+
+    // ---- phase B: gather the deposits of the (2H+1)^d neighbouring samples
+    float acc[DIM][2 * H + 1];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c)
+#pragma unroll
+      for (int k = 0; k < 2 * H + 1; ++k) acc[c][k] = 0.f;
+    if (!(dbg & 4))
+#pragma unroll
+    for (int dz = (DIM == 3 ? -H : 0); dz <= (DIM == 3 ? H : 0); ++dz)
+#pragma unroll
+      for (int dy = -H; dy <= H; ++dy) {
+        // sample row (uz + dz, uy + dy): this output sits at offset (-dz, -dy) from it
+        const int r = rc + (DIM == 3 ? dz * RY : 0) + dy;
+        const float ylo = -(float)(uy + dy), yhi = (float)(d.s1 - 1 - uy - dy);     // wave-uniform clip bounds
+        const float fx = __builtin_amdgcn_fmed3f(lds[(0 * ROWS + r) * 64 + lane], xlo, xhi);
+        const float fy = __builtin_amdgcn_fmed3f(lds[(1 * ROWS + r) * 64 + lane], ylo, yhi);
+        float w = fmaxf(0.f, 1.f - fabsf(fy + (float)dy));
+        if (DIM == 3) {
+          const float zlo = -(float)(uz + dz), zhi = (float)(d.s0 - 1 - uz - dz);
+          const float fz = __builtin_amdgcn_fmed3f(lds[(2 * ROWS + r) * 64 + lane], zlo, zhi);
+          w *= fmaxf(0.f, 1.f - fabsf(fz + (float)dz));
+        }
+        float a[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) a[c] = lds[((DIM + c) * ROWS + r) * 64 + lane] * w;
+        XSpread<H>::template run<DIM>(acc, a, fx);
+      }
+    // fold the x partial sums into the owning lanes: out(x) = sum_k acc[k](lane x - k)
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      float up = acc[c][2 * H];               // deposits on x + H
+#pragma unroll
+      for (int k = H - 1; k >= 0; --k) up = lane_prev_f(up) + acc[c][k + H];
+      float dn = acc[c][0];                   // deposits on x - H
+#pragma unroll
+      for (int k = -H + 1; k <= -1; ++k) dn = lane_next_f(dn) + acc[c][k + H];
+      dn = lane_next_f(dn);
+      const float v = (up + dn) + gg[c];
+      if (xowned) {
+        gpn[(int64_t)c * V + (uz * d.s1 + uy) * d.s2 + sx] = v;
+        m = fmaxf(m, fabsf(v));
+      }
+    }
+  }
+  if (absmax_out) {
+    __shared__ float smem[NT / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) smem[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, smem[w]);
+      if (m > __builtin_nontemporal_load(absmax_out)) atomicMax(reinterpret_cast<unsigned int*>(absmax_out), __float_as_uint(m));
+    }
+  }
+}
+
+// Drains the overflow list: every corner of a listed sample, global atomics (runs after the tiles were stored).
+template <int DIM>
+__global__ void __launch_bounds__(kBlock)
+k_gather_overflow(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d,
+                  const int* __restrict__ ovf_count, const int2* __restrict__ ovf_list, int ovf_cap,
+                  float* __restrict__ absmax_out) {
+  const int V = (int)d.voxels();
+  const int count = min(*ovf_count, ovf_cap);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
+    const int2 e = ovf_list[i];
+    const int n = e.x, s = e.y;
+    const float* pn = phi + (int64_t)n * DIM * V;
+    Taps<DIM, PAD_BORDER> t;
+    t.build(pn[s], pn[V + s], DIM == 3 ? pn[2 * V + s] : 0.f, d);
+#pragma unroll
+    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          if (!t.ok(cz, cy, cx)) continue;
+          const int o = t.off(cz, cy, cx, d);
+          const float wgt = t.w(cz, cy, cx);
+          for (int c = 0; c < DIM; ++c) {
+            const float v = wgt * gout[((int64_t)n * DIM + c) * V + s];
+            const float old = atomicAdd(gphi + ((int64_t)n * DIM + c) * V + o, v);
+            const float nv = fabsf(old + v);
+            if (absmax_out && nv > __builtin_nontemporal_load(absmax_out))
+              atomicMax(reinterpret_cast<unsigned int*>(absmax_out), __float_as_uint(nv));
+          }
+        }
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+template <int DIM, int H, int TZ, int TY, int NT>
+static void launch_gather(const float* gout, const float* phi, float* gphi, int64_t N, Dims d, int32_t* ws, int chain,
+                          hipStream_t st) {
+  using G = GatherCfg<DIM, H, TZ, TY, NT>;
+  const int wide = d.s2 > 64;
+  const int n2 = wide ? (d.s2 + (64 - 2 * kXPad) - 1) / (64 - 2 * kXPad) : 1;
+  const int n1 = (d.s1 + TY - 1) / TY;
+  const int n0 = DIM == 3 ? (d.s0 + TZ - 1) / TZ : 1;
+  int* cnt = ws;
+  float* amax_out = reinterpret_cast<float*>(ws + 3);
+  int2* list = reinterpret_cast<int2*>(ws + 4);
+  const int64_t cap64 = N * d.voxels();
+  const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
+  static const int dbg = getenv("ADVCHAIN_GDBG") ? atoi(getenv("ADVCHAIN_GDBG")) : 0;  // tuning knob
+  auto kern = k_self_adjoint_gather<DIM, H, TZ, TY, NT>;
+  static bool attr_set = false;
+  if (G::LDS > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_gather_prepare, dim3(1), dim3(1), 0, st, ws, chain);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, phi, gphi, d, n1, n2,
+                     wide, amax_out, cnt, list, cap, dbg);
+  hipLaunchKernelGGL((k_gather_overflow<DIM>), dim3(16), dim3(kBlock), 0, st, gout, phi, gphi, d, cnt, list, cap, amax_out);
+}
+
+// Self-composition backward in gather form.  `halo` is the caller's displacement bound in voxels; shapes or bounds the
+// gather form does not cover return ADVCHAIN_ERR_UNSUPPORTED (the caller uses the LDS-tiled scatter).
+// Workspace protocol identical to advchain_scatter_tiled_launch (header [0] overflow count, [3] max|result|).
+int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, float* gphi, int64_t N, int ndim, Dims d,
+                                        int32_t* workspace, int chain, int halo, hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
+  if (off || !workspace || halo < 1) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s2 % 4 != 0 || d.s2 < 8) return ADVCHAIN_ERR_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(phi);
+  if (al & 15) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (ndim == 3) {
+    if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
+    static const int var = getenv("ADVCHAIN_GVAR") ? atoi(getenv("ADVCHAIN_GVAR")) : 0;  // tuning knob
+    if (var == 1) launch_gather<3, 1, 4, 8, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 2) launch_gather<3, 1, 2, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 3) launch_gather<3, 1, 2, 4, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 5) launch_gather<3, 1, 4, 6, 768>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 6) launch_gather<3, 1, 2, 6, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 7) launch_gather<3, 1, 4, 6, 384>(gout, phi, gphi, N, d, workspace, chain, st);
+    else if (var == 8) launch_gather<3, 1, 4, 4, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    else launch_gather<3, 1, 4, 4, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+  } else {
+    static const int var2 = getenv("ADVCHAIN_GVAR2") ? atoi(getenv("ADVCHAIN_GVAR2")) : 0;  // tuning knob
+    if (halo == 1) {
+      if (var2 == 1) launch_gather<2, 1, 1, 16, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+      else if (var2 == 2) launch_gather<2, 1, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+      else if (var2 == 3) launch_gather<2, 1, 1, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+      else launch_gather<2, 1, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    } else if (halo == 2) {
+      if (var2 == 1) launch_gather<2, 2, 1, 16, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+      else if (var2 == 2) launch_gather<2, 2, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+      else if (var2 == 3) launch_gather<2, 2, 1, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+      else launch_gather<2, 2, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    }
+    else return ADVCHAIN_ERR_UNSUPPORTED;
+  }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}

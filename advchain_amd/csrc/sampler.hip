@@ -539,6 +539,10 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                   int32_t* workspace, int chain, int halo, hipStream_t st);
 
+// adjoint_gather.hip
+int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, float* gphi, int64_t N, int ndim, Dims d,
+                                        int32_t* workspace, int chain, int halo, hipStream_t st);
+
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
@@ -719,9 +723,14 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
-  if (workspace)
+  if (workspace) {
+    // sub-voxel steps of the squaring chain: gather form (adjoint_gather.hip); otherwise the LDS-tiled scatter
+    const int rc = advchain_self_adjoint_gather_launch(grad_out, phi, grad_phi, N, ndim, d, workspace, chain, halo,
+                                                       (hipStream_t)stream);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
                                          workspace, chain, halo, (hipStream_t)stream);
+  }
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;

@@ -150,6 +150,37 @@ def test_compose_self(dims, scatter_path):
     assert maxdiff(fin.cpu(), (ref.detach() - phi0) + O.identity_grid(2, dims)) < TOL
 
 
+@pytest.mark.parametrize("dims", [(20, 28), (40, 72), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
+@pytest.mark.parametrize("halo", [1, 2])
+@pytest.mark.parametrize("amp", [0.005, 0.6])
+def test_compose_self_bwd_gather_form(dims, halo, amp):
+    """advchain_compose_self_bwd with a displacement bound (`halo`) takes the gather-form adjoint (adjoint_gather.hip):
+    same result as autograd through F.grid_sample(phi, phi) whether the bound holds (amp 0.005: below one voxel at every size here)
+    or not (amp 0.6: most samples exceed it and go through the overflow list), narrow and wide rows, chained calls."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    phi = (O.identity_grid(2, dims) + amp * rand((2, d) + dims, 31)).contiguous()
+    w = rand((2, d) + dims, 32)
+    p = phi.clone().requires_grad_(True)
+    q = O.compose_fields(p, p)
+    (q * w).sum().backward()
+    pd = phi.to(DEV)
+    ws = ops._scatter_workspace(2, dims, DEV)
+    g1 = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=halo)
+    scale = float(p.grad.abs().max())
+    assert maxdiff(g1.cpu(), p.grad) < 5e-5 * max(1.0, scale)
+    # chained second application on the same workspace (header carries max|result| for a fixed-point successor)
+    g2 = ops.raw_compose_self_bwd(g1, pd, ws, chain=True, halo=0)
+    p2 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p2, p2) * p.grad).sum().backward()
+    assert maxdiff(g2.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
+    # deterministic
+    g1b = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=halo)
+    if amp < 0.1:
+        assert torch.equal(g1, g1b)
+
+
 @pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4)])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
 def test_affine_warp(dims, C, pad):

@@ -83,6 +83,9 @@ def main():
     add("ATen F.grid_sample fwd+bwd C=1", aten_fb, 4 * NV * (5 + 3 * d))
     add("compose_self fwd", lambda: ops.raw_compose_self_fwd(phi), 8 * d * NV)
     add("compose_self bwd", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)
+    ws = ops._scatter_workspace(N, dims, dev)   # phi is the 2^-8-scaled field: well below one voxel
+    add("compose_self bwd halo=1 (gather form)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 1), 12 * d * NV)
+    add("compose_self bwd halo=2%s" % (" (gather form)" if d == 2 else ""), lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 2), 12 * d * NV)
     old = ops.TILED_SCATTER
     ops.TILED_SCATTER = False
     add("compose_self bwd (atomic path)", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the rocprofv3 kernel-trace summaries that profiles/ holds (run on the GPU box through gpurun).
+#   tools/profile_bench.sh <tag>      -> gpurun_out/<tag>/{cfg2,cfg3,kb3d}_kernel_stats.csv + logs
+set -u
+tag=${1:-prof}
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+out=$repo/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+cd /tmp
+run() {  # name, command...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
+  cp "$(find /tmp/rp_$name -name "${name}_kernel_stats.csv" | head -1)" "$out/${name}_kernel_stats.csv"
+}
+run cfg2 python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline
+run cfg3 python $repo/bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline
+run kb3d python $repo/tools/kernel_bench.py --shape 3d
+python $repo/tools/stats_per_call.py "$out/cfg2_kernel_stats.csv" 13 30
+python $repo/tools/stats_per_call.py "$out/cfg3_kernel_stats.csv" 7 30
