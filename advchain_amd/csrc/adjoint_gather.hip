@@ -319,6 +319,38 @@ k_gather_overflow(const float* __restrict__ gout, const float* __restrict__ phi,
   }
 }
 
+// max over samples and axes of |unnormalize(phi_a) - s_a|: the displacement bound (in voxels) that selects the halo
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) k_max_displacement(const float* __restrict__ phi, float* __restrict__ out, Dims d, int ndim) {
+  const int V = (int)d.voxels();
+  const int plane = blockIdx.y;              // n * ndim + a
+  const int a = plane % ndim;
+  const int Sa = a == 0 ? d.s2 : (a == 1 ? d.s1 : d.s0);
+  const float* p = phi + (int64_t)plane * V;
+  float m = 0.f;
+  for (int i = (blockIdx.x * kBlock + threadIdx.x) * VEC; i < V; i += gridDim.x * kBlock * VEC) {
+    float v[VEC];
+    load_vec<VEC>(p + i, v);
+    const int x = i % d.s2, q = i / d.s2;
+    const int y = q % d.s1, z = q / d.s1;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int sa = a == 0 ? x + k : (a == 1 ? y : z);
+      const float dv = fabsf(unnormalize(v[k], Sa) - (float)sa);
+      m = fmaxf(m, dv < 1.0e9f ? dv : 1.0e9f);   // NaN -> ignored by fmaxf; inf -> capped
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float smem[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, smem[w]);
+    if (m > __builtin_nontemporal_load(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -377,6 +409,8 @@ int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, flo
       else if (var2 == 2) launch_gather<2, 1, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
       else if (var2 == 3) launch_gather<2, 1, 1, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
       else launch_gather<2, 1, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
+    } else if (halo == 3 || halo == 4) {
+      launch_gather<2, 4, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
     } else if (halo == 2) {
       if (var2 == 1) launch_gather<2, 2, 1, 16, 512>(gout, phi, gphi, N, d, workspace, chain, st);
       else if (var2 == 2) launch_gather<2, 2, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
@@ -385,6 +419,29 @@ int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, flo
     }
     else return ADVCHAIN_ERR_UNSUPPORTED;
   }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+extern "C" int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim, const int64_t* dims,
+                                         void* stream) {
+  ADVCHAIN_CHECK_ARG(phi && out && dims, "max_displacement: null pointer");
+  ADVCHAIN_CHECK_ARG(ndim == 2 || ndim == 3, "max_displacement: ndim");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N * ndim < 65536, "max_displacement: bad N");
+  if (N == 0) return ADVCHAIN_OK;
+  Dims d;
+  d.s0 = ndim == 3 ? (int)dims[0] : 1;
+  d.s1 = (int)dims[ndim - 2];
+  d.s2 = (int)dims[ndim - 1];
+  ADVCHAIN_CHECK_ARG(d.s0 > 0 && d.s1 > 0 && d.s2 > 0 && d.voxels() < (1ll << 31), "max_displacement: bad dims");
+  const bool vec = d.s2 % 4 == 0 && (reinterpret_cast<uintptr_t>(phi) & 15) == 0;
+  // ~512 workgroups in all: every workgroup ends in one same-address atomic (~10 ns each when they collide)
+  int blocks = advchain_blocks(d.voxels(), kBlock * (vec ? 4 : 1));
+  const int cap = (int)(512 / (N * ndim)) > 1 ? (int)(512 / (N * ndim)) : 1;
+  if (blocks > cap) blocks = cap;
+  dim3 g((unsigned)blocks, (unsigned)(N * ndim));
+  if (vec) hipLaunchKernelGGL((k_max_displacement<4>), g, dim3(kBlock), 0, (hipStream_t)stream, phi, out, d, ndim);
+  else hipLaunchKernelGGL((k_max_displacement<1>), g, dim3(kBlock), 0, (hipStream_t)stream, phi, out, d, ndim);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

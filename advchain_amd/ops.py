@@ -59,6 +59,7 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
     return out
 
 
+ADAPTIVE_HALO = True   # measure the displacement in forward and size the backward halos from it
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 
 
@@ -101,6 +102,41 @@ def raw_compose_self_bwd(gout, phi, ws=None, chain=False, halo=0):
     _lib.check(_lib.load().advchain_compose_self_bwd(_ptr(gout), _ptr(phi), _ptr(gphi), _ptr(ws), int(bool(chain)), int(halo), N, nd,
                                                      _lib.dims_array(phi.shape[2:]), _stream()), "compose_self_bwd")
     return gphi
+
+
+def raw_max_displacement(phi):
+    """max |sampling position - own voxel| of a deformation `phi` (N,d,...) in voxels -> 1-element device tensor."""
+    out = torch.zeros(1, device=phi.device, dtype=torch.float32)
+    _lib.check(_lib.load().advchain_max_displacement(_ptr(phi), _ptr(out), phi.shape[0], phi.dim() - 2,
+                                                     _lib.dims_array(phi.shape[2:]), _stream()), "max_displacement")
+    return out
+
+
+def squaring_halos(disp_last, n, d):
+    """Displacement bounds for the backward of the n squarings, last squaring first.
+
+    `disp_last` = measured max displacement (voxels) of the input of the LAST squaring; the input of squaring m moves
+    about half as far as that of m+1 (measured ratio 0.50-0.53: bounded with 0.55).  Bounds below 1 voxel (3D) /
+    4 voxels (2D) select the gather-form adjoint, the rest the tile halo of the scatter kernels."""
+    halos = []
+    est = float(disp_last)
+    for _ in range(n):
+        if not est == est:       # NaN field: nothing to tune
+            halos.append(0)
+        elif est < 0.9:
+            halos.append(1)
+        elif d == 3:
+            halos.append(2)
+        elif est < 1.8:
+            halos.append(2)
+        elif est < 3.6:
+            halos.append(4)
+        elif est < 7.0:
+            halos.append(8)
+        else:
+            halos.append(16)     # beyond 16 voxels the overflow list is cheaper than a wider halo
+        est *= 0.55
+    return halos
 
 
 def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
@@ -385,6 +421,7 @@ class _DemonsField(torch.autograd.Function):
         pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1)
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
+        ctx.disp = raw_max_displacement(phis[-1]) if ADAPTIVE_HALO else None
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
         return q
@@ -398,14 +435,17 @@ class _DemonsField(torch.autograd.Function):
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
         ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
-        # squaring m composes a field whose displacement is 2^(m-n) of the total: the early (cheap-halo) steps
-        # dominate.  The halo is a performance hint only (larger displacements go through the overflow list).
+        # squaring m composes a field whose displacement is ~2^(m-n) of the total: the early steps are sub-voxel and
+        # take the gather-form adjoint.  The bound is a performance hint only (larger displacements stay correct
+        # through the overflow list); it comes from the displacement measured in forward (one 4-byte read-back).
         n = len(phis)
-        big = 2 if d == 3 else 16
+        if ctx.disp is not None:
+            halos = squaring_halos(float(ctx.disp.item()), n, d)
+        else:
+            big = 2 if d == 3 else 16
+            halos = [big, big, max(1, big // 2)] + [1 if d == 3 else 2] * n
         for i, phi in enumerate(reversed(phis)):
-            m = n - 1 - i
-            halo = big if m >= n - 2 else (max(1, big // 2) if m == n - 3 else (1 if d == 3 else 2))
-            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halo)
+            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halos[i])
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)

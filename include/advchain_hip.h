@@ -74,10 +74,15 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).
  * chain != 0: grad_out is the grad_phi of the previous call on the same workspace (the backward of
  * consecutive squarings), whose max|.| is already in the workspace -- saves one pass over grad_out.
- * halo > 0: tile halo in voxels (an upper bound on |displacement| of phi keeps every deposit in LDS; larger
- * displacements stay correct through the overflow list); 0 = default (2 in 3D, 8 in 2D).               */
+ * halo > 0: an upper bound on |displacement| of phi in voxels -- a performance hint only: samples beyond it stay
+ * correct through the overflow list (global atomics).  Small bounds (1 in 3D; 1..4 in 2D) select the gather-form
+ * adjoint (no atomics, bit-reproducible); larger ones the LDS-tiled fixed-point scatter with that tile halo;
+ * 0 = default scatter tiles (halo 2 in 3D, 16 in 2D).                                                   */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
                               int halo, int64_t N, int ndim, const int64_t* dims, void* stream);
+/* max over samples and axes of |sampling position - own voxel| of the field phi, in voxels: the displacement
+ * bound `halo` above wants.  out: one float, zero-initialised by the caller (atomic max).            */
+int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim, const int64_t* dims, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),
