@@ -48,7 +48,12 @@ struct XSpread {
   }
 };
 
-template <int DIM, int H, int TZ, int TY, int NT>
+// flags
+constexpr int kClip = 1;        // sampling positions are clipped to [0, S-1] (border padding and/or clamp_grid)
+constexpr int kBorder = 2;      // border padding: zero coordinate gradient AT and beyond the border (else: beyond only)
+constexpr int kClampGrid = 4;   // the caller asked for clamp(grid, -1, 1) (only the fallback path needs to know)
+
+template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 struct GatherCfg {
   static constexpr int RZ = DIM == 3 ? TZ + 2 * H : 1;
   static constexpr int RY = TY + 2 * H;
@@ -56,23 +61,52 @@ struct GatherCfg {
   static constexpr int NW = NT / 64;
   static constexpr int OWNED = (DIM == 3 ? TZ : 1) * TY;
   static constexpr int RPW = OWNED / NW;
-  static constexpr int CH = 2 * DIM;
+  static constexpr bool STAGE_IN = GG && !SELF;
+  static constexpr int CH = DIM + C + (STAGE_IN ? C : 0);
   static constexpr size_t LDS = (size_t)CH * ROWS * 64 * sizeof(float);
   static_assert(OWNED % NW == 0, "owned rows must divide evenly among the waves");
+  static_assert(!SELF || C == DIM, "self-composition carries DIM channels");
 };
 
 // unnormalised source coordinate of a normalised grid value (GridSampler.h grid_sampler_unnormalize, align_corners)
 __device__ __forceinline__ float unnormalize(float g, int S) { return ((g + 1.f) * 0.5f) * (float)(S - 1); }
 
-template <int DIM, int H, int TZ, int TY, int NT>
+// coordinate-path gradient of one sample straight from global memory (irregular samples only)
+template <int DIM, int PAD, int C>
+__device__ __forceinline__ void coord_grad_global(const float* __restrict__ inn, const float* __restrict__ gn,
+                                                  const float* __restrict__ gon, int s, int V, const Dims& d,
+                                                  int clamp_grid, float (&gg)[3]) {
+  float gx = gn[s], gy = gn[V + s], gz = DIM == 3 ? gn[2 * V + s] : 0.f;
+  bool px = true, py = true, pz = true;
+  if (clamp_grid) {
+    px = gx >= -1.f && gx <= 1.f; py = gy >= -1.f && gy <= 1.f; pz = gz >= -1.f && gz <= 1.f;
+    gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz);
+  }
+  Taps<DIM, PAD> t;
+  t.build(gx, gy, gz, d);
+  float ax = 0.f, ay = 0.f, az = 0.f, dummy = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, gon[(int64_t)c * V + s], t, d, ax, ay,
+                                             DIM == 3 ? az : dummy);
+  gg[0] = px ? t.x.mult * ax : 0.f;
+  gg[1] = py ? t.y.mult * ay : 0.f;
+  gg[2] = (DIM == 3 && pz) ? t.z.mult * az : 0.f;
+}
+
+// SELF : in == grid == phi (C == DIM); gin receives value path + coordinate path      (advchain_compose_self_bwd)
+// !SELF: gin <- value path; GG: ggrid <- coordinate path (needs `in`, staged as well)  (advchain_grid_sample_bwd)
+template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 __global__ void __launch_bounds__(NT)
-k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d,
-                      int n1, int n2, int wide, float* __restrict__ absmax_out, int* __restrict__ ovf_count,
-                      int2* __restrict__ ovf_list, int ovf_cap, int dbg) {
-  using G = GatherCfg<DIM, H, TZ, TY, NT>;
+k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                 float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int wide, int flags,
+                 float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap,
+                 int dbg) {
+  using G = GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>;
   constexpr int RY = G::RY, ROWS = G::ROWS, NW = G::NW, RPW = G::RPW;
-  // [2*DIM][ROWS][64]: channels 0..DIM-1 hold o = unnormalize(phi) - s (unclipped offset of the sampling position from
-  // the sample's own voxel, in voxels), channels DIM..2*DIM-1 grad_out (0 for irregular samples)
+  constexpr int OG = DIM, OI = DIM + C;   // first grad_out / input channel in LDS
+  // [CH][ROWS][64]: channels 0..DIM-1 hold o = unnormalize(grid) - s (unclipped offset of the sampling position from
+  // the sample's own voxel, in voxels), then C channels grad_out (0 for irregular samples), then (STAGE_IN) C of `in`
   extern __shared__ float lds[];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -85,10 +119,13 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
   const int x0 = tx * xown, y0 = ty * TY, z0 = DIM == 3 ? tz * TZ : 0;
   const int rx0 = wide ? x0 - kXPad : 0;          // x of lane 0 (multiple of 4)
   const int ry0 = y0 - H, rz0 = DIM == 3 ? z0 - H : 0;
-  const float* phin = phi + (int64_t)n * DIM * V;
-  const float* gon = gout + (int64_t)n * DIM * V;
+  const float* gn = grid + (int64_t)n * DIM * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  const float* inn = in + (int64_t)n * C * V;
   const int S[3] = {d.s2, d.s1, d.s0};
   const float fH = (float)H;
+  // the self-composition always runs clip + border: constants there, run-time flags for the image warps
+  const bool clip = SELF ? true : (flags & kClip) != 0, border = SELF ? true : (flags & kBorder) != 0;
 
   // ---- stage: one item = 4 consecutive x of one region row, all channels (rows / quads outside the volume: zeros)
   for (int e = threadIdx.x; e < ROWS * 16; e += NT) {
@@ -96,14 +133,18 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
     const int r = e >> 4;
     const int sy = ry0 + r % RY, sz = rz0 + r / RY;
     const int x = rx0 + 4 * q;
-    float o[DIM][4], g[DIM][4];
+    float o[DIM][4], g[C][4], vin[G::STAGE_IN ? C : 1][4];
     const bool inside = !(dbg & 8) && sy >= 0 && sy < d.s1 && sz >= 0 && sz < d.s0 && x >= 0 && x < d.s2;
     if (inside) {
       const int s = (sz * d.s1 + sy) * d.s2 + x;
 #pragma unroll
-      for (int a = 0; a < DIM; ++a) load_vec<4>(phin + (int64_t)a * V + s, o[a]);
+      for (int a = 0; a < DIM; ++a) load_vec<4>(gn + (int64_t)a * V + s, o[a]);
 #pragma unroll
-      for (int a = 0; a < DIM; ++a) load_vec<4>(gon + (int64_t)a * V + s, g[a]);
+      for (int c = 0; c < C; ++c) load_vec<4>(gon + (int64_t)c * V + s, g[c]);
+      if (G::STAGE_IN) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) load_vec<4>(inn + (int64_t)c * V + s, vin[c]);
+      }
       const int sc[3] = {x, sy, sz};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -112,25 +153,36 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
         for (int a = 0; a < DIM; ++a) {
           const float xs = unnormalize(o[a][k], S[a]);
           const float sa = (float)(sc[a] + (a == 0 ? k : 0));
-          const float f = fminf(fmaxf(xs, 0.f), (float)(S[a] - 1)) - sa;     // clipped (border padding)
+          const float p = clip ? fminf(fmaxf(xs, 0.f), (float)(S[a] - 1)) : xs;
+          const float f = p - sa;
           regular = regular && (f >= -fH) && (f < fH);                        // false for NaN
           o[a][k] = (xs > -1.0e9f && xs < 1.0e9f) ? xs - sa : 0.f;
         }
         if (!regular) {
 #pragma unroll
-          for (int a = 0; a < DIM; ++a) g[a][k] = 0.f;
+          for (int c = 0; c < C; ++c) g[c][k] = 0.f;
         }
       }
     } else {
 #pragma unroll
-      for (int a = 0; a < DIM; ++a)
+      for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o[a][k] = 0.f; g[a][k] = 0.f; }
+        for (int a = 0; a < DIM; ++a) o[a][k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c][k] = 0.f;
+        if (G::STAGE_IN) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) vin[c][k] = 0.f;
+        }
+      }
     }
 #pragma unroll
-    for (int a = 0; a < DIM; ++a) {
-      store_vec<4>(lds + (a * ROWS + r) * 64 + 4 * q, o[a]);
-      store_vec<4>(lds + ((DIM + a) * ROWS + r) * 64 + 4 * q, g[a]);
+    for (int a = 0; a < DIM; ++a) store_vec<4>(lds + (a * ROWS + r) * 64 + 4 * q, o[a]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) store_vec<4>(lds + ((OG + c) * ROWS + r) * 64 + 4 * q, g[c]);
+    if (G::STAGE_IN) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) store_vec<4>(lds + ((OI + c) * ROWS + r) * 64 + 4 * q, vin[c]);
     }
   }
   __syncthreads();
@@ -138,7 +190,7 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
   const int sx = rx0 + lane;
   const bool xowned = wide ? (lane >= kXPad && lane < 64 - kXPad && sx < d.s2) : (sx < d.s2);
   const float xlo = -(float)sx, xhi = (float)(d.s2 - 1 - sx);   // clip bounds of a sample in this lane, as offsets
-  float* gpn = gphi + (int64_t)n * DIM * V;
+  float* ginn = gin + (int64_t)n * C * V;
   float m = 0.f;
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
@@ -147,12 +199,11 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
     const int uy = y0 + ly, uz = z0 + lz;
     if (uy >= d.s1 || uz >= d.s0) continue;   // wave-uniform
     const int rc = (DIM == 3 ? (lz + H) * RY : 0) + ly + H;
+    const int s = (uz * d.s1 + uy) * d.s2 + sx;
 
     // ---- phase A: coordinate-path gradient of the sample at this output position
-    float gg[DIM];
-#pragma unroll
-    for (int a = 0; a < DIM; ++a) gg[a] = 0.f;
-    if (xowned && !(dbg & 1)) {
+    float gg[3] = {0.f, 0.f, 0.f};
+    if ((SELF || GG) && xowned && !(dbg & 1)) {
       const int sc[3] = {sx, uy, uz};
       float w1[3] = {0.f, 0.f, 0.f}, mult[3] = {0.f, 0.f, 0.f};
       int i0[3] = {0, 0, 0};
@@ -160,41 +211,45 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
 #pragma unroll
       for (int a = 0; a < DIM; ++a) {
         float xs = lds[(a * ROWS + rc) * 64 + lane] + (float)sc[a];
-        mult[a] = 0.5f * (float)(S[a] - 1);
-        if (xs <= 0.f) { xs = 0.f; mult[a] = 0.f; }
-        else if (xs >= (float)(S[a] - 1)) { xs = (float)(S[a] - 1); mult[a] = 0.f; }
+        const float top = (float)(S[a] - 1);
+        mult[a] = 0.5f * top;
+        if (clip) {
+          if (border ? xs <= 0.f : xs < 0.f) mult[a] = 0.f;
+          if (border ? xs >= top : xs > top) mult[a] = 0.f;
+          xs = fminf(fmaxf(xs, 0.f), top);
+        }
         const float fl = floorf(xs);
         i0[a] = (int)fl;
         w1[a] = xs - fl;
         const float f = xs - (float)sc[a];
         regular = regular && (f >= -fH) && (f < fH);
       }
-      float acc3[3] = {0.f, 0.f, 0.f};
       if (regular) {
-        float go[DIM];
+        float go[C];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) go[c] = lds[((DIM + c) * ROWS + rc) * 64 + lane];
-        // corners clamped into the volume: a clamped corner carries weight 0 / multiplier 0 under border padding
-        const int lx0 = i0[0] - rx0, ex = min(i0[0] + 1, d.s2 - 1) - i0[0];
+        for (int c = 0; c < C; ++c) go[c] = lds[((OG + c) * ROWS + rc) * 64 + lane];
+        // a corner outside the volume reads as 0 (zeros padding skips it; under border padding / clamp it carries
+        // weight 0 or multiplier 0).  Rows outside the volume are staged as zeros; only x needs the select.
+        const bool okx0 = i0[0] >= 0, okx1 = i0[0] + 1 < d.s2;
+        const int lx0 = max(i0[0], 0) - rx0, lx1 = min(i0[0] + 1, d.s2 - 1) - rx0;
         const int r00 = (DIM == 3 ? (i0[2] - rz0) * RY : 0) + (i0[1] - ry0);
-        const int ey = min(i0[1] + 1, d.s1 - 1) - i0[1];
-        const int ez = DIM == 3 ? min(i0[2] + 1, d.s0 - 1) - i0[2] : 0;
         const float wx1 = w1[0], wx0 = 1.f - wx1, wy1 = w1[1], wy0 = 1.f - wy1, wz1 = w1[2], wz0 = 1.f - wz1;
+        float acc3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-          const float* p = lds + c * ROWS * 64;
+        for (int c = 0; c < C; ++c) {
+          const float* p = lds + (SELF ? c : OI + c) * ROWS * 64;
           float v[2][2][2];
 #pragma unroll
           for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
             for (int cy = 0; cy < 2; ++cy) {
-              const int r = r00 + (cz ? ez * RY : 0) + (cy ? ey : 0);
-              v[cz][cy][0] = p[r * 64 + lx0];
-              v[cz][cy][1] = p[r * 64 + lx0 + ex];
+              const int r = r00 + cz * RY + cy;
+              v[cz][cy][0] = okx0 ? p[r * 64 + lx0] : 0.f;
+              v[cz][cy][1] = okx1 ? p[r * 64 + lx1] : 0.f;
             }
-          // phi_c(u) = (v(u) + u_c) * 2/(S_c-1) - 1: only differences along an axis enter; the identity part of the
-          // difference is the (clamped) index step on axis c
-          const float ux = c == 0 ? (float)ex : 0.f, uyy = c == 1 ? (float)ey : 0.f, uzz = c == 2 ? (float)ez : 0.f;
+          // SELF: phi_c(u) = (o_c(u) + u_c) * 2/(S_c-1) - 1: only differences along an axis enter; the identity part
+          // of a difference along axis c is the index step (1)
+          const float ux = (SELF && c == 0) ? 1.f : 0.f, uyy = (SELF && c == 1) ? 1.f : 0.f, uzz = (SELF && c == 2) ? 1.f : 0.f;
           float dx, dy, dz = 0.f;
           if (DIM == 3) {
             dx = ((v[0][0][1] - v[0][0][0] + ux) * wy0 + (v[0][1][1] - v[0][1][0] + ux) * wy1) * wz0 +
@@ -207,31 +262,38 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
             dx = (v[0][0][1] - v[0][0][0] + ux) * wy0 + (v[0][1][1] - v[0][1][0] + ux) * wy1;
             dy = (v[0][1][0] - v[0][0][0] + uyy) * wx0 + (v[0][1][1] - v[0][0][1] + uyy) * wx1;
           }
-          const float kc = go[c] * (2.f / (float)(S[c] - 1));
+          const float kc = SELF ? go[c] * (2.f / (float)(S[c] - 1)) : go[c];
           acc3[0] = fmaf(dx, kc, acc3[0]); acc3[1] = fmaf(dy, kc, acc3[1]); acc3[2] = fmaf(dz, kc, acc3[2]);
         }
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) gg[a] = mult[a] * acc3[a];
       } else {
         // irregular sample: taps and corner values from global memory, deposits through the overflow list
-        const int s = (uz * d.s1 + uy) * d.s2 + sx;
-        Taps<DIM, PAD_BORDER> t;
-        t.build(phin[s], phin[V + s], DIM == 3 ? phin[2 * V + s] : 0.f, d);
-        float dummy = 0.f;
+        if (border) coord_grad_global<DIM, PAD_BORDER, C>(inn, gn, gon, s, V, d, flags & kClampGrid, gg);
+        else coord_grad_global<DIM, PAD_ZEROS, C>(inn, gn, gon, s, V, d, flags & kClampGrid, gg);
+      }
+    }
+    if (xowned) {
+      // the owner lists its irregular samples (same test as at staging time: grad_out was zeroed there)
+      const int sc[3] = {sx, uy, uz};
+      bool regular = true;
 #pragma unroll
-        for (int c = 0; c < DIM; ++c)
-          sample_linear_bwd<DIM, PAD_BORDER, false, true>(phin + (int64_t)c * V, nullptr, gon[(int64_t)c * V + s], t, d,
-                                                          acc3[0], acc3[1], DIM == 3 ? acc3[2] : dummy);
-        mult[0] = t.x.mult; mult[1] = t.y.mult; mult[2] = t.z.mult;
+      for (int a = 0; a < DIM; ++a) {
+        float xs = lds[(a * ROWS + rc) * 64 + lane] + (float)sc[a];
+        if (clip) xs = fminf(fmaxf(xs, 0.f), (float)(S[a] - 1));
+        const float f = xs - (float)sc[a];
+        regular = regular && (f >= -fH) && (f < fH);
+      }
+      if (!regular) {
         const int slot = atomicAdd(ovf_count, 1);
         if (slot < ovf_cap) ovf_list[slot] = make_int2(n, s);
       }
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) gg[a] = mult[a] * acc3[a];
     }
 
     // ---- phase B: gather the deposits of the (2H+1)^d neighbouring samples
-    float acc[DIM][2 * H + 1];
+    float acc[C][2 * H + 1];
 #pragma unroll
-    for (int c = 0; c < DIM; ++c)
+    for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int k = 0; k < 2 * H + 1; ++k) acc[c][k] = 0.f;
     if (!(dbg & 4))
@@ -241,23 +303,24 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
       for (int dy = -H; dy <= H; ++dy) {
         // sample row (uz + dz, uy + dy): this output sits at offset (-dz, -dy) from it
         const int r = rc + (DIM == 3 ? dz * RY : 0) + dy;
-        const float ylo = -(float)(uy + dy), yhi = (float)(d.s1 - 1 - uy - dy);     // wave-uniform clip bounds
-        const float fx = __builtin_amdgcn_fmed3f(lds[(0 * ROWS + r) * 64 + lane], xlo, xhi);
-        const float fy = __builtin_amdgcn_fmed3f(lds[(1 * ROWS + r) * 64 + lane], ylo, yhi);
-        float w = fmaxf(0.f, 1.f - fabsf(fy + (float)dy));
-        if (DIM == 3) {
-          const float zlo = -(float)(uz + dz), zhi = (float)(d.s0 - 1 - uz - dz);
-          const float fz = __builtin_amdgcn_fmed3f(lds[(2 * ROWS + r) * 64 + lane], zlo, zhi);
-          w *= fmaxf(0.f, 1.f - fabsf(fz + (float)dz));
+        float fx = lds[(0 * ROWS + r) * 64 + lane];
+        float fy = lds[(1 * ROWS + r) * 64 + lane];
+        float fz = DIM == 3 ? lds[(2 * ROWS + r) * 64 + lane] : 0.f;
+        if (clip) {
+          fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
+          fy = __builtin_amdgcn_fmed3f(fy, -(float)(uy + dy), (float)(d.s1 - 1 - uy - dy));     // wave-uniform bounds
+          if (DIM == 3) fz = __builtin_amdgcn_fmed3f(fz, -(float)(uz + dz), (float)(d.s0 - 1 - uz - dz));
         }
-        float a[DIM];
+        float w = fmaxf(0.f, 1.f - fabsf(fy + (float)dy));
+        if (DIM == 3) w *= fmaxf(0.f, 1.f - fabsf(fz + (float)dz));
+        float a[C];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) a[c] = lds[((DIM + c) * ROWS + r) * 64 + lane] * w;
-        XSpread<H>::template run<DIM>(acc, a, fx);
+        for (int c = 0; c < C; ++c) a[c] = lds[((OG + c) * ROWS + r) * 64 + lane] * w;
+        XSpread<H>::template run<C>(acc, a, fx);
       }
     // fold the x partial sums into the owning lanes: out(x) = sum_k acc[k](lane x - k)
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) {
+    for (int c = 0; c < C; ++c) {
       float up = acc[c][2 * H];               // deposits on x + H
 #pragma unroll
       for (int k = H - 1; k >= 0; --k) up = lane_prev_f(up) + acc[c][k + H];
@@ -265,14 +328,20 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
 #pragma unroll
       for (int k = -H + 1; k <= -1; ++k) dn = lane_next_f(dn) + acc[c][k + H];
       dn = lane_next_f(dn);
-      const float v = (up + dn) + gg[c];
+      float v = up + dn;
+      if (SELF) v += gg[c < 3 ? c : 0];
       if (xowned) {
-        gpn[(int64_t)c * V + (uz * d.s1 + uy) * d.s2 + sx] = v;
+        ginn[(int64_t)c * V + s] = v;
         m = fmaxf(m, fabsf(v));
       }
     }
+    if (!SELF && GG && xowned) {
+      float* gq = ggrid + (int64_t)n * DIM * V + s;
+#pragma unroll
+      for (int a = 0; a < DIM; ++a) gq[(int64_t)a * V] = gg[a];
+    }
   }
-  if (absmax_out) {
+  if (SELF && absmax_out) {
     __shared__ float smem[NT / 64];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -286,19 +355,21 @@ k_self_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ 
 }
 
 // Drains the overflow list: every corner of a listed sample, global atomics (runs after the tiles were stored).
-template <int DIM>
+template <int DIM, int PAD>
 __global__ void __launch_bounds__(kBlock)
-k_gather_overflow(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gphi, Dims d,
-                  const int* __restrict__ ovf_count, const int2* __restrict__ ovf_list, int ovf_cap,
+k_gather_overflow(const float* __restrict__ gout, const float* __restrict__ grid, float* __restrict__ gin, int C, Dims d,
+                  int clamp_grid, const int* __restrict__ ovf_count, const int2* __restrict__ ovf_list, int ovf_cap,
                   float* __restrict__ absmax_out) {
   const int V = (int)d.voxels();
   const int count = min(*ovf_count, ovf_cap);
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < count; i += gridDim.x * kBlock) {
     const int2 e = ovf_list[i];
     const int n = e.x, s = e.y;
-    const float* pn = phi + (int64_t)n * DIM * V;
-    Taps<DIM, PAD_BORDER> t;
-    t.build(pn[s], pn[V + s], DIM == 3 ? pn[2 * V + s] : 0.f, d);
+    const float* pn = grid + (int64_t)n * DIM * V;
+    float gx = pn[s], gy = pn[V + s], gz = DIM == 3 ? pn[2 * V + s] : 0.f;
+    if (clamp_grid) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
+    Taps<DIM, PAD> t;
+    t.build(gx, gy, gz, d);
 #pragma unroll
     for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
@@ -308,9 +379,9 @@ k_gather_overflow(const float* __restrict__ gout, const float* __restrict__ phi,
           if (!t.ok(cz, cy, cx)) continue;
           const int o = t.off(cz, cy, cx, d);
           const float wgt = t.w(cz, cy, cx);
-          for (int c = 0; c < DIM; ++c) {
-            const float v = wgt * gout[((int64_t)n * DIM + c) * V + s];
-            const float old = atomicAdd(gphi + ((int64_t)n * DIM + c) * V + o, v);
+          for (int c = 0; c < C; ++c) {
+            const float v = wgt * gout[((int64_t)n * C + c) * V + s];
+            const float old = atomicAdd(gin + ((int64_t)n * C + c) * V + o, v);
             const float nv = fabsf(old + v);
             if (absmax_out && nv > __builtin_nontemporal_load(absmax_out))
               atomicMax(reinterpret_cast<unsigned int*>(absmax_out), __float_as_uint(nv));
@@ -355,30 +426,41 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement(const float* __rest
 
 using namespace advchain;
 
-template <int DIM, int H, int TZ, int TY, int NT>
-static void launch_gather(const float* gout, const float* phi, float* gphi, int64_t N, Dims d, int32_t* ws, int chain,
-                          hipStream_t st) {
-  using G = GatherCfg<DIM, H, TZ, TY, NT>;
+template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
+static void launch_gather(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
+                          Dims d, int padding, int clamp_grid, int32_t* ws, int chain, hipStream_t st) {
+  using G = GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>;
   const int wide = d.s2 > 64;
   const int n2 = wide ? (d.s2 + (64 - 2 * kXPad) - 1) / (64 - 2 * kXPad) : 1;
   const int n1 = (d.s1 + TY - 1) / TY;
   const int n0 = DIM == 3 ? (d.s0 + TZ - 1) / TZ : 1;
   int* cnt = ws;
-  float* amax_out = reinterpret_cast<float*>(ws + 3);
+  float* amax_out = SELF ? reinterpret_cast<float*>(ws + 3) : nullptr;
   int2* list = reinterpret_cast<int2*>(ws + 4);
   const int64_t cap64 = N * d.voxels();
   const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
   static const int dbg = getenv("ADVCHAIN_GDBG") ? atoi(getenv("ADVCHAIN_GDBG")) : 0;  // tuning knob
-  auto kern = k_self_adjoint_gather<DIM, H, TZ, TY, NT>;
+  const bool border = padding == PAD_BORDER;
+  const int flags = ((border || clamp_grid) ? kClip : 0) | (border ? kBorder : 0) | (clamp_grid ? kClampGrid : 0);
+  auto kern = k_adjoint_gather<DIM, C, H, SELF, GG, TZ, TY, NT>;
   static bool attr_set = false;
   if (G::LDS > 65536 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
   hipLaunchKernelGGL(k_gather_prepare, dim3(1), dim3(1), 0, st, ws, chain);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, phi, gphi, d, n1, n2,
-                     wide, amax_out, cnt, list, cap, dbg);
-  hipLaunchKernelGGL((k_gather_overflow<DIM>), dim3(16), dim3(kBlock), 0, st, gout, phi, gphi, d, cnt, list, cap, amax_out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
+                     n1, n2, wide, flags, amax_out, cnt, list, cap, dbg);
+  if (border) hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_BORDER>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,
+                                 clamp_grid, cnt, list, cap, amax_out);
+  else hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_ZEROS>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,
+                          clamp_grid, cnt, list, cap, amax_out);
+}
+
+static bool gather_shape_ok(const Dims& d, const void* a, const void* b, const void* c) {
+  if (d.s2 % 4 != 0 || d.s2 < 8) return false;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+  return (al & 15) == 0;
 }
 
 // Self-composition backward in gather form.  `halo` is the caller's displacement bound in voxels; shapes or bounds the
@@ -387,38 +469,48 @@ static void launch_gather(const float* gout, const float* phi, float* gphi, int6
 int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, float* gphi, int64_t N, int ndim, Dims d,
                                         int32_t* workspace, int chain, int halo, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
-  if (off || !workspace || halo < 1) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (d.s2 % 4 != 0 || d.s2 < 8) return ADVCHAIN_ERR_UNSUPPORTED;
-  const uintptr_t al = reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(phi);
-  if (al & 15) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (off || !workspace || halo < 1 || !gather_shape_ok(d, gout, phi, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+#define SELF_GO(DIM_, H_, TZ_, TY_, NT_) \
+  launch_gather<DIM_, DIM_, H_, true, false, TZ_, TY_, NT_>(gout, phi, phi, gphi, nullptr, N, d, PAD_BORDER, 0, workspace, chain, st)
   if (ndim == 3) {
     if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
-    static const int var = getenv("ADVCHAIN_GVAR") ? atoi(getenv("ADVCHAIN_GVAR")) : 0;  // tuning knob
-    if (var == 1) launch_gather<3, 1, 4, 8, 512>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 2) launch_gather<3, 1, 2, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 3) launch_gather<3, 1, 2, 4, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 5) launch_gather<3, 1, 4, 6, 768>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 6) launch_gather<3, 1, 2, 6, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 7) launch_gather<3, 1, 4, 6, 384>(gout, phi, gphi, N, d, workspace, chain, st);
-    else if (var == 8) launch_gather<3, 1, 4, 4, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    else launch_gather<3, 1, 4, 4, 512>(gout, phi, gphi, N, d, workspace, chain, st);
+    SELF_GO(3, 1, 4, 4, 512);
   } else {
-    static const int var2 = getenv("ADVCHAIN_GVAR2") ? atoi(getenv("ADVCHAIN_GVAR2")) : 0;  // tuning knob
-    if (halo == 1) {
-      if (var2 == 1) launch_gather<2, 1, 1, 16, 512>(gout, phi, gphi, N, d, workspace, chain, st);
-      else if (var2 == 2) launch_gather<2, 1, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
-      else if (var2 == 3) launch_gather<2, 1, 1, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-      else launch_gather<2, 1, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    } else if (halo == 3 || halo == 4) {
-      launch_gather<2, 4, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    } else if (halo == 2) {
-      if (var2 == 1) launch_gather<2, 2, 1, 16, 512>(gout, phi, gphi, N, d, workspace, chain, st);
-      else if (var2 == 2) launch_gather<2, 2, 1, 32, 512>(gout, phi, gphi, N, d, workspace, chain, st);
-      else if (var2 == 3) launch_gather<2, 2, 1, 8, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-      else launch_gather<2, 2, 1, 16, 256>(gout, phi, gphi, N, d, workspace, chain, st);
-    }
+    if (halo == 1) SELF_GO(2, 1, 1, 16, 256);
+    else if (halo == 2) SELF_GO(2, 2, 1, 16, 256);
+    else if (halo <= 4) SELF_GO(2, 4, 1, 16, 256);
     else return ADVCHAIN_ERR_UNSUPPORTED;
   }
+#undef SELF_GO
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// grid_sample backward (grad_in [+ grad_grid]) in gather form: same contract; C in {1, 4}, zeros / border padding.
+int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                        int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
+                                        int32_t* workspace, int halo, hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
+  if (off || !workspace || halo < 1 || !gin || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (!gather_shape_ok(d, gout, grid, ggrid ? in : nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (C != 1 && C != 4) return ADVCHAIN_ERR_UNSUPPORTED;
+#define WARP_GO(DIM_, C_, H_, GG_, TZ_, TY_, NT_) \
+  launch_gather<DIM_, C_, H_, false, GG_, TZ_, TY_, NT_>(gout, in, grid, gin, ggrid, N, d, padding, clamp_grid, workspace, 0, st)
+  const bool gg = ggrid != nullptr;
+  if (ndim == 3) {
+    if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
+    if (C == 1) { if (gg) WARP_GO(3, 1, 1, true, 4, 4, 512); else WARP_GO(3, 1, 1, false, 4, 4, 512); }
+    else { if (gg) WARP_GO(3, 4, 1, true, 2, 4, 512); else WARP_GO(3, 4, 1, false, 4, 4, 512); }
+  } else {
+    if (halo <= 2) {
+      if (C == 1) { if (gg) WARP_GO(2, 1, 2, true, 1, 16, 256); else WARP_GO(2, 1, 2, false, 1, 16, 256); }
+      else { if (gg) WARP_GO(2, 4, 2, true, 1, 16, 256); else WARP_GO(2, 4, 2, false, 1, 16, 256); }
+    } else if (halo <= 4) {
+      if (C == 1) { if (gg) WARP_GO(2, 1, 4, true, 1, 16, 256); else WARP_GO(2, 1, 4, false, 1, 16, 256); }
+      else { if (gg) WARP_GO(2, 4, 4, true, 1, 16, 256); else WARP_GO(2, 4, 4, false, 1, 16, 256); }
+    } else return ADVCHAIN_ERR_UNSUPPORTED;
+  }
+#undef WARP_GO
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

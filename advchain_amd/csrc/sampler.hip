@@ -543,6 +543,10 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
 int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, float* gphi, int64_t N, int ndim, Dims d,
                                         int32_t* workspace, int chain, int halo, hipStream_t st);
 
+int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                        int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
+                                        int32_t* workspace, int halo, hipStream_t st);
+
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
@@ -666,7 +670,7 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
                              float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
-                             void* stream) {
+                             int halo, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && in && grid, "grid_sample_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(grad_in || grad_grid, "grid_sample_bwd: nothing to compute");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_bwd: bad dims");
@@ -677,9 +681,14 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
   const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_bwd: per-sample volume too large");
   const bool same = id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2;
-  if (workspace && grad_in && same && interp == INTERP_LINEAR && C <= 4)  // LDS-tiled owner-computes scatter
+  if (workspace && grad_in && same && interp == INTERP_LINEAR && C <= 4) {
+    // small displacement bound: gather form (adjoint_gather.hip); otherwise the LDS-tiled owner-computes scatter
+    const int rc = advchain_warp_adjoint_gather_launch(grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
+                                                       clamp_grid, workspace, halo, (hipStream_t)stream);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                         clamp_grid, workspace, 0, 0, (hipStream_t)stream);
+                                         clamp_grid, workspace, 0, halo, (hipStream_t)stream);
+  }
   if (workspace && grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);

@@ -68,7 +68,7 @@ def _scatter_workspace(N, dims, device):
     return torch.empty(n, device=device, dtype=torch.int32)
 
 
-def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, need_ggrid):
+def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, need_ggrid, halo=0):
     N, C = inp.shape[:2]
     nd = inp.dim() - 2
     tiled = TILED_SCATTER and need_gin
@@ -78,7 +78,7 @@ def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, 
     _lib.check(_lib.load().advchain_grid_sample_bwd(_ptr(gout), _ptr(inp), _ptr(grid), _ptr(gin), _ptr(ggrid), _ptr(ws),
                                                     N, C, nd, _lib.dims_array(inp.shape[2:]),
                                                     _lib.dims_array(grid.shape[2:]), interp, padding, int(clamp_grid),
-                                                    _stream()), "grid_sample_bwd")
+                                                    int(halo), _stream()), "grid_sample_bwd")
     return gin, ggrid
 
 
@@ -223,12 +223,39 @@ def normalized_axpy(base, x, step=1.0):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
+def grid_displacement(grid):
+    """Max displacement (voxels) of a sampling grid, measured once per grid tensor (the entry -- a 1-float device tensor
+    and, after the first read-back, its host value -- rides on the tensor object: the same deformation warps the image
+    and then the prediction)."""
+    hit = getattr(grid, "_advchain_disp", None)
+    if hit is None or hit[2] != grid._version:
+        hit = [raw_max_displacement(grid.detach()), None, grid._version]
+        grid._advchain_disp = hit
+    return hit
+
+
+def warp_halo(entry, d):
+    """Displacement bound for the backward of a warp from the measured value (one 4-byte read-back per grid)."""
+    if entry[1] is None:
+        entry[1] = float(entry[0].item())
+    est = entry[1]
+    if not est == est:
+        return 0
+    if d == 3:
+        return 1 if est < 0.95 else 2   # measured: wider 3D halos cost more than the overflow list saves
+    for h in (2, 4, 8, 16):
+        if est < 0.95 * h:
+            return h
+    return 16
+
+
 class _GridSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, grid, interp, padding, clamp_grid):
+    def forward(ctx, inp, grid, interp, padding, clamp_grid, disp):
         inp, grid = _dev(inp, "input"), _dev(grid, "grid")
         ctx.save_for_backward(inp, grid)
         ctx.cfg = (interp, padding, clamp_grid)
+        ctx.disp = disp
         return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid)
 
     @staticmethod
@@ -237,14 +264,21 @@ class _GridSample(torch.autograd.Function):
         interp, padding, clamp_grid = ctx.cfg
         need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_in or need_grid):
-            return None, None, None, None, None
-        gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid)
-        return gin, ggrid, None, None, None
+            return None, None, None, None, None, None
+        halo = warp_halo(ctx.disp, inp.dim() - 2) if (ctx.disp is not None and need_in) else 0
+        gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid,
+                                         halo)
+        return gin, ggrid, None, None, None, None
 
 
 def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
     """F.grid_sample(inp, grid^T, mode, padding_mode, align_corners=True) with a PLANAR grid (N,d,...)."""
-    return _GridSample.apply(inp, grid, interp_code(interp), pad_code(padding_mode), bool(clamp_grid))
+    code = interp_code(interp)
+    disp = None
+    if (ADAPTIVE_HALO and code == 0 and torch.is_grad_enabled() and inp.requires_grad and grid.is_cuda
+            and inp.shape[2:] == grid.shape[2:] and grid.dtype == torch.float32 and grid.is_contiguous()):
+        disp = grid_displacement(grid)       # the backward sizes its halo / picks the gather form from it
+    return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp)
 
 
 class _AffineWarp(torch.autograd.Function):

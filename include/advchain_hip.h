@@ -54,12 +54,16 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
  * With `workspace` (int32[advchain_scatter_workspace(N,ndim,dims)]) grad_in is simply overwritten: the
  * LDS-tiled owner-computes scatter (64-bit fixed-point accumulation, deterministic) is used for linear
  * interpolation with in_dims == out_dims and C <= 4, and grad_in is zero-filled internally otherwise;
- * with workspace == NULL the global-atomic path is used and grad_in must be pre-zeroed by the caller. */
+ * with workspace == NULL the global-atomic path is used and grad_in must be pre-zeroed by the caller.
+ * halo > 0: an upper bound on the displacement |sampling position - own voxel| in voxels (see
+ * advchain_max_displacement) -- a performance hint only: small bounds (1 in 3D, <= 4 in 2D; C in {1,4}) select the
+ * gather-form adjoint (no atomics), larger ones size the tile halo; samples beyond the bound stay correct through the
+ * overflow list.  0 = default tiles.                                                                  */
 int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
                              float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
-                             void* stream);
+                             int halo, void* stream);
 
 /* ---- scaling-and-squaring step ---------------------------------------------------------
  * replaces: applyComposition{2,3}D(phi, phi) = F.grid_sample(phi, phi^T, 'border',

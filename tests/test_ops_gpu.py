@@ -150,6 +150,32 @@ def test_compose_self(dims, scatter_path):
     assert maxdiff(fin.cpu(), (ref.detach() - phi0) + O.identity_grid(2, dims)) < TOL
 
 
+@pytest.mark.parametrize("dims", [(24, 40), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
+@pytest.mark.parametrize("C", [1, 4])
+@pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
+@pytest.mark.parametrize("amp", [0.004, 0.5])
+def test_grid_sample_bwd_gather_form(dims, C, pad, clamp, amp):
+    """advchain_grid_sample_bwd with a displacement bound takes the gather-form adjoint for C in {1,4}: same grad_in and
+    grad_grid as autograd through F.grid_sample, bound respected (amp 0.004) or violated (amp 0.5: overflow list)."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    grid = (O.identity_grid(2, dims) * 1.02 + amp * rand((2, d) + dims, 41)).contiguous()   # a little beyond [-1, 1]
+    inp = rand((2, C) + dims, 42)
+    w = rand((2, C) + dims, 43)
+    a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    gp = torch.clamp(g, -1, 1) if clamp else g
+    perm = (0, 2, 3, 1) if d == 2 else (0, 2, 3, 4, 1)
+    ref = F.grid_sample(a, gp.permute(*perm), padding_mode=pad, align_corners=True)
+    (ref * w).sum().backward()
+    for halo in ((1,) if d == 3 else (2, 4)):
+        gin, ggrid = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, True, halo)
+        assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
+        assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max()))
+        gin2, none = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, False, halo)
+        assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dims", [(20, 28), (40, 72), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
 @pytest.mark.parametrize("halo", [1, 2])
 @pytest.mark.parametrize("amp", [0.005, 0.6])

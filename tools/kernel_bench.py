@@ -71,6 +71,10 @@ def main():
     add("grid_sample fwd C=4", lambda: ops.raw_grid_sample_fwd(x4, q, 0, 0, True), 4 * NV * (8 + d))
     add("grid_sample bwd C=1 (gin+ggrid)", lambda: ops.raw_grid_sample_bwd(g1, x1, q, 0, 0, True, True, True), 4 * NV * (3 + 2 * d))
     add("grid_sample bwd C=4 (gin+ggrid)", lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, True), 4 * NV * (12 + 2 * d))
+    hq = ops.warp_halo(ops.grid_displacement(q), d)
+    add("grid_sample bwd C=1 (gin+ggrid) halo=%d" % hq, lambda: ops.raw_grid_sample_bwd(g1, x1, q, 0, 0, True, True, True, hq), 4 * NV * (3 + 2 * d))
+    add("grid_sample bwd C=4 (gin+ggrid) halo=%d" % hq, lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, True, hq), 4 * NV * (12 + 2 * d))
+    add("grid_sample bwd C=4 (gin only) halo=%d" % hq, lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, False, hq), 4 * NV * (12 + d))
     add("grid_sample bwd C=1 (ggrid only)", lambda: ops.raw_grid_sample_bwd(g1, x1, q, 0, 0, True, False, True), 4 * NV * (2 + 2 * d))
     add("grid_sample bwd C=4 (gin only)", lambda: ops.raw_grid_sample_bwd(g4, x4, q, 0, 0, True, True, False), 4 * NV * (12 + d))
     qq = q.permute(0, *range(2, 2 + d), 1).contiguous()
