@@ -499,6 +499,14 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
   const bool gg = ggrid != nullptr;
   if (ndim == 3) {
     if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
+    static const int var = getenv("ADVCHAIN_GVAR") ? atoi(getenv("ADVCHAIN_GVAR")) : 0;  // tuning knob
+    if (C == 1 && gg && var == 1) WARP_GO(3, 1, 1, true, 4, 8, 512);
+    else if (C == 1 && gg && var == 2) WARP_GO(3, 1, 1, true, 8, 8, 1024);
+    else if (C == 1 && gg && var == 3) WARP_GO(3, 1, 1, true, 4, 8, 1024);
+    else if (C == 1 && gg && var == 4) WARP_GO(3, 1, 1, true, 4, 4, 256);
+    else if (C == 1 && gg && var == 5) WARP_GO(3, 1, 1, true, 2, 8, 512);
+    else if (C == 1 && gg && var == 6) WARP_GO(3, 1, 1, true, 8, 4, 512);
+    else
     if (C == 1) { if (gg) WARP_GO(3, 1, 1, true, 4, 4, 512); else WARP_GO(3, 1, 1, false, 4, 4, 512); }
     else { if (gg) WARP_GO(3, 4, 1, true, 2, 4, 512); else WARP_GO(3, 4, 1, false, 4, 4, 512); }
   } else {

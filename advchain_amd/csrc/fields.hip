@@ -149,9 +149,39 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
 // adjoint along one axis:  out[o][k][i] = sum_s val(in[o][s][i]) * w[s][k - start[s]]
 //   val = (in - in2) * scale  when in2 != null, else in * scale
 // ---------------------------------------------------------------------------------------------
+constexpr int kBrMaxW = 4096;        // densified band table (g * WB floats)
+
+// Densify the band of every coefficient into LDS: Wd[k][j] = weight of input lo[k] + j for coefficient k, so the
+// reduction loops touch no global table (a dependent global load per term made them latency-bound).
+// Returns the band width WB = max_k (hi[k] - lo[k]), or 0 when the table does not fit (g > 64 or g * WB > kBrMaxW).
+__device__ __forceinline__ int stage_band(const BandAxis& A, float* Wd, int* lo_s) {
+  const int lane = threadIdx.x & 63;
+  if (A.g > 64) return 0;
+  int WB = lane < A.g ? A.hi[lane] - A.lo[lane] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) WB = max(WB, __shfl_xor(WB, o, 64));
+  if (A.g * WB > kBrMaxW) return 0;
+  for (int i = threadIdx.x; i < A.g * WB; i += blockDim.x) {
+    const int k = i / WB, j = i - k * WB;
+    const int s2 = A.lo[k] + j;
+    float w = 0.f;
+    if (s2 < A.hi[k]) {
+      const int b = k - A.start[s2];
+      if (b >= 0 && b < A.B) w = A.w[s2 * A.B + b];
+    }
+    Wd[i] = w;
+  }
+  for (int i = threadIdx.x; i < A.g; i += blockDim.x) lo_s[i] = A.lo[i];
+  __syncthreads();
+  return WB;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_band_reduce_axis(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int64_t outer,
                    int inner, BandAxis A, float scale) {
+  __shared__ float Wd[kBrMaxW];
+  __shared__ int lo_s[64];
+  const int WB = stage_band(A, Wd, lo_s);
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t total = outer * A.g * inner;
   if (t >= total) return;
@@ -159,19 +189,85 @@ k_band_reduce_axis(const float* __restrict__ in, const float* __restrict__ in2, 
   const int64_t r = t / inner;
   const int k = (int)(r % A.g);
   const int64_t o = r / A.g;
-  const int lo = A.lo[k], hi = A.hi[k];
   const float* p = in + (o * A.S) * inner + i;
   const float* p2 = in2 ? in2 + (o * A.S) * inner + i : nullptr;
   float acc = 0.f;
-  for (int s = lo; s < hi; ++s) {
-    const int b = k - A.start[s];
-    if (b >= 0 && b < A.B) {
-      float x = p[(int64_t)s * inner];
-      if (p2) x -= p2[(int64_t)s * inner];
-      acc += x * A.w[s * A.B + b];
+  if (WB > 0) {
+    const int lo = lo_s[k];
+    const int len = min(WB, A.S - lo);
+    const float* w = Wd + k * WB;
+    for (int j = 0; j < len; ++j) {
+      float x = p[(int64_t)(lo + j) * inner];
+      if (p2) x -= p2[(int64_t)(lo + j) * inner];
+      acc = fmaf(x, w[j], acc);
+    }
+  } else {
+    const int lo = A.lo[k], hi = A.hi[k];
+    for (int s = lo; s < hi; ++s) {
+      const int b = k - A.start[s];
+      if (b >= 0 && b < A.B) {
+        float x = p[(int64_t)s * inner];
+        if (p2) x -= p2[(int64_t)s * inner];
+        acc += x * A.w[s * A.B + b];
+      }
     }
   }
   out[t] = acc * scale;
+}
+
+// Innermost-axis variant (inner == 1, S % 4 == 0): the full-resolution pass, which reads the whole gradient once.
+// A wave stages R consecutive rows in its LDS slab with 16-byte loads (fusing (in - in2)); lane (row, k) then takes
+// its banded dot product from LDS.  The band of coefficient k is densified once per workgroup into LDS
+// (Wd[k][j] = weight of input lo[k] + j), so the inner loop touches no global memory.
+constexpr int kBrSlab = 1024;        // floats per wave
+__global__ void __launch_bounds__(kBlock)
+k_band_reduce_rows(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int64_t rows,
+                   BandAxis A, float scale, int R, int iters) {
+  __shared__ __attribute__((aligned(16))) float slab[kBlock / 64][kBrSlab];
+  __shared__ float Wd[kBrMaxW];
+  __shared__ int lo_s[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = A.S, g = A.g, B = A.B;
+  const int WB = stage_band(A, Wd, lo_s);
+  const bool dense = WB > 0;                  // otherwise: weights straight from the (global) band table
+  const int q = S >> 2;                          // float4 per row
+  float* my = slab[wave];
+  const int row = lane / g, k = lane - row * g;  // lanes >= R * g idle in the dot phase
+  for (int it = 0; it < iters; ++it) {
+    const int64_t base = (((int64_t)blockIdx.x * iters + it) * (kBlock / 64) + wave) * R;
+    __syncthreads();   // previous pass consumed (first time: the tables are in place)
+    for (int idx = lane; idx < R * q; idx += 64) {
+      const int r = idx / q, x4 = idx - r * q;
+      const int64_t gr = base + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < rows) {
+        v = *reinterpret_cast<const float4*>(in + gr * S + 4 * x4);
+        if (in2) {
+          const float4 u = *reinterpret_cast<const float4*>(in2 + gr * S + 4 * x4);
+          v = make_float4(v.x - u.x, v.y - u.y, v.z - u.z, v.w - u.w);
+        }
+      }
+      *reinterpret_cast<float4*>(my + r * S + 4 * x4) = v;
+    }
+    __syncthreads();
+    const int64_t gr = base + row;
+    if (row < R && gr < rows) {
+      const float* x = my + row * S;
+      const int lo = dense ? lo_s[k] : A.lo[k];
+      float acc = 0.f;
+      if (dense) {
+        const float* w = Wd + k * WB;
+        const int len = min(WB, S - lo);
+        for (int j = 0; j < len; ++j) acc = fmaf(x[lo + j], w[j], acc);
+      } else {
+        for (int s2 = lo; s2 < A.hi[k]; ++s2) {
+          const int b = k - A.start[s2];
+          if (b >= 0 && b < B) acc = fmaf(x[s2], A.w[s2 * B + b], acc);
+        }
+      }
+      out[gr * g + k] = acc * scale;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -488,6 +584,18 @@ int advchain_band_reduce_axis(const float* in, const float* in2, float* out, con
   ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "band_reduce_axis: bad band tables");
   const int64_t total = outer * T.a[axis].g * inner;
   if (total == 0) return ADVCHAIN_OK;
+  const BandAxis& A = T.a[axis];
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+  if (inner == 1 && A.S % 4 == 0 && A.S <= kBrSlab && A.g <= 64 && aligned) {
+    int R = 64 / A.g;
+    if (R * A.S > kBrSlab) R = kBrSlab / A.S;
+    const int iters = 4;
+    const int64_t rows_per_block = (int64_t)(kBlock / 64) * R * iters;
+    hipLaunchKernelGGL(k_band_reduce_rows, dim3(advchain_blocks(outer, (int)rows_per_block)), dim3(kBlock), 0,
+                       (hipStream_t)stream, in, in2, out, outer, A, scale, R, iters);
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   hipLaunchKernelGGL(k_band_reduce_axis, dim3(advchain_blocks(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      in2, out, outer, (int)inner, T.a[axis], scale);
   ADVCHAIN_LAUNCH_CHECK();

@@ -159,9 +159,25 @@ k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, con
       px = gx >= -1.f && gx <= 1.f; py = gy >= -1.f && gy <= 1.f; pz = gz >= -1.f && gz <= 1.f;
       gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz);
     }
+    const bool rowowned = (sy >= y0) && (sy < y0 + tc.t1) && (sz >= z0) && (sz < z0 + tc.t0);  // wave-uniform
+    if (!rowowned && PAD != PAD_REFLECTION) {
+      // halo row: skip it when no lane's sampling position comes within one voxel of the tile (cheap test first)
+      float qx = ((gx + 1.f) * 0.5f) * (float)(d.s2 - 1), qy = ((gy + 1.f) * 0.5f) * (float)(d.s1 - 1);
+      float qz = DIM == 3 ? ((gz + 1.f) * 0.5f) * (float)(d.s0 - 1) : 0.f;
+      if (PAD == PAD_BORDER) {
+        qx = fminf(fmaxf(qx, 0.f), (float)(d.s2 - 1)); qy = fminf(fmaxf(qy, 0.f), (float)(d.s1 - 1));
+        qz = fminf(fmaxf(qz, 0.f), (float)(d.s0 - 1));
+      }
+      const bool hit = xvalid && qx > (float)(x0 - 1) && qx < (float)(x0 + tc.t2) && qy > (float)(y0 - 1) &&
+                       qy < (float)(y0 + tc.t1) && (DIM < 3 || (qz > (float)(z0 - 1) && qz < (float)(z0 + tc.t0)));
+      if (__builtin_amdgcn_ballot_w64(hit) == 0) {
+        cur = nxt;
+        row = nrow;
+        continue;
+      }
+    }
     Taps<DIM, PAD> t;
     t.build(gx, gy, gz, d);
-    const bool rowowned = (sy >= y0) && (sy < y0 + tc.t1) && (sz >= z0) && (sz < z0 + tc.t0);  // wave-uniform
     const bool owned = xowned && rowowned;
     bool overflow = false;
     if (xvalid) {
