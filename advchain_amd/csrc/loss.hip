@@ -12,6 +12,7 @@
 // backward: grad_pred = softmax'(P) [ gs * ( c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B ) ]
 // The caller owns the normalisers (global N under batch sharding).
 // Streaming + 3^d stencil: HBM-bound, no MFMA.
+#include <stdlib.h>
 #include "common.h"
 
 namespace advchain {
@@ -299,9 +300,194 @@ k_consistency_bwd_rows(const float* __restrict__ P, const float* __restrict__ D,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Marching form of the row kernels (K known at compile time, S2 % 64 == 0): a wave owns a strip of kMarch
+// consecutive rows (fixed slice i0 and 64-voxel x range) and walks along y.  The stencils are separable,
+// A = h(z) hp(y) h(x), B = h(z) h(y) hp(x)  (2D: A = h(y) hp(x), B = hp(y) h(x)), so each new row needs only its own
+// 3^(d-2) loads per array: they are folded over z and x into one value per array, and the y taps come from a
+// 3-row window kept in registers.  3 (3D) / 1 (2D) loads per row, array and class instead of 9 / 3: the row
+// kernels above were bound by their vector-memory instruction count (65 per voxel-wave at K = 4).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMarch = 8;
+
+// row (i0 +- 1, j1) folded over z (weights h) and over x: zs = h along x, zd = hp along x (l - r)
+template <int DIM>
+__device__ __forceinline__ void fold_row(const float* __restrict__ p, int i0, int j1, int x, const Dims& d, float& zs,
+                                         float& zd) {
+  zs = 0.f; zd = 0.f;
+#pragma unroll
+  for (int a0 = (DIM == 3 ? 0 : 1); a0 < (DIM == 3 ? 3 : 2); ++a0) {
+    const RowTaps t = load_row_taps(p, i0 + a0 - 1, j1, x, d);
+    const float w = DIM == 3 ? hsm(a0) : 1.f;
+    zs += w * (t.l + 2.f * t.c + t.r);
+    zd += w * (t.l - t.r);
+  }
+}
+
+__device__ __forceinline__ bool strip_decode(int strip, const Dims& d, int& i0, int& y0, int& x) {
+  const int nx = d.s2 >> 6, ny = (d.s1 + kMarch - 1) / kMarch;
+  if (strip >= nx * ny * d.s0) return false;
+  const int xc = strip % nx;
+  const int r = strip / nx;
+  y0 = (r % ny) * kMarch;
+  i0 = r / ny;
+  x = xc * 64 + (threadIdx.x & 63);
+  return true;
+}
+
+template <int DIM, int K>
+__global__ void __launch_bounds__(kBlock)
+k_edge_fwd_march(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ R,
+                 float* __restrict__ sums, Dims d, int mask_ch) {
+  __shared__ float smem[8];
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  float acc[2] = {0.f, 0.f};
+  int i0, y0, x;
+  if (strip_decode(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), d, i0, y0, x)) {
+    float zs[K - 1][3], zd[K - 1][3];   // window: rows i1-1, i1, i1+1
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      const float* Dk = D + ((int64_t)n * K + k) * V;
+      fold_row<DIM>(Dk, i0, y0 - 1, x, d, zs[k - 1][0], zd[k - 1][0]);
+      fold_row<DIM>(Dk, i0, y0, x, d, zs[k - 1][1], zd[k - 1][1]);
+    }
+    const int y1 = min(y0 + kMarch, d.s1);
+    for (int i1 = y0; i1 < y1; ++i1) {
+      const int v = (i0 * d.s1 + i1) * d.s2 + x;
+      const float m = mask ? mask[(int64_t)n * mask_ch * V + v] : 1.f;
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const float* Dk = D + ((int64_t)n * K + k) * V;
+        fold_row<DIM>(Dk, i0, i1 + 1, x, d, zs[k - 1][2], zd[k - 1][2]);
+        float ga, gb;
+        if (DIM == 2) {   // A = h[a1] hp[a2], B = hp[a1] h[a2]
+          ga = zd[k - 1][0] + 2.f * zd[k - 1][1] + zd[k - 1][2];
+          gb = zs[k - 1][0] - zs[k - 1][2];
+        } else {          // A = h[a0] hp[a1] h[a2], B = h[a0] h[a1] hp[a2]
+          ga = zs[k - 1][0] - zs[k - 1][2];
+          gb = zd[k - 1][0] + 2.f * zd[k - 1][1] + zd[k - 1][2];
+        }
+        const float ea = ga * m, eb = gb * m;
+        acc[0] += ea * ea;
+        acc[1] += eb * eb;
+        if (R) {
+          R[((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v] = 2.f * m * m * ga;
+          R[((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v] = 2.f * m * m * gb;
+        }
+        zs[k - 1][0] = zs[k - 1][1]; zs[k - 1][1] = zs[k - 1][2];
+        zd[k - 1][0] = zd[k - 1][1]; zd[k - 1][1] = zd[k - 1][2];
+      }
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + kSumSlots + sum_slot(), acc[0]);
+    atomic_add_f32(sums + 2 * kSumSlots + sum_slot(), acc[1]);
+  }
+}
+
+template <int DIM, int K>
+__global__ void __launch_bounds__(kBlock)
+k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
+                        const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
+                        float c_mse, float c_a, float c_b, Dims d, int mask_ch) {
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  int i0, y0, x;
+  if (!strip_decode(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), d, i0, y0, x)) return;
+  const float gs = gscale ? gscale[0] : 1.f;
+  // per class and array one folded value per row: A wants h along x in 3D, hp^T = (r - l) in 2D; B the other way
+  float za[K - 1][3], zb[K - 1][3];
+  auto fold = [&](int k, int j1, float& a, float& b) {
+    const float* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
+    float as, ad, bs, bd;
+    fold_row<DIM>(Ra, i0, j1, x, d, as, ad);
+    fold_row<DIM>(Ra + V, i0, j1, x, d, bs, bd);
+    a = DIM == 3 ? as : -ad;
+    b = DIM == 3 ? -bd : bs;
+  };
+  if (R) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      fold(k, y0 - 1, za[k - 1][0], zb[k - 1][0]);
+      fold(k, y0, za[k - 1][1], zb[k - 1][1]);
+    }
+  }
+  const int y1 = min(y0 + kMarch, d.s1);
+  for (int i1 = y0; i1 < y1; ++i1) {
+    const int v = (i0 * d.s1 + i1) * d.s2 + x;
+    float gp[K], pk[K];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = ((int64_t)n * K + k) * V + v;
+      const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
+      float g = c_mse * 2.f * m * m * D[o];
+      if (k >= 1 && R) {
+        fold(k, i1 + 1, za[k - 1][2], zb[k - 1][2]);
+        // adjoint: tap a1 reads row i1 - (a1 - 1)
+        float sa, sb;
+        if (DIM == 2) {
+          sa = za[k - 1][0] + 2.f * za[k - 1][1] + za[k - 1][2];
+          sb = zb[k - 1][2] - zb[k - 1][0];
+        } else {
+          sa = za[k - 1][2] - za[k - 1][0];
+          sb = zb[k - 1][0] + 2.f * zb[k - 1][1] + zb[k - 1][2];
+        }
+        g += c_a * sa + c_b * sb;
+        za[k - 1][0] = za[k - 1][1]; za[k - 1][1] = za[k - 1][2];
+        zb[k - 1][0] = zb[k - 1][1]; zb[k - 1][1] = zb[k - 1][2];
+      }
+      g *= gs;
+      gp[k] = g;
+      pk[k] = P[o];
+      dot += g * pk[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) gpred[((int64_t)n * K + k) * V + v] = pk[k] * (gp[k] - dot);
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
+
+
+static inline dim3 march_grid(const Dims& d, int64_t N) {
+  const int strips = (d.s2 >> 6) * ((d.s1 + kMarch - 1) / kMarch) * d.s0;
+  return dim3((unsigned)((strips + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)N);
+}
+static const bool g_no_march = getenv("ADVCHAIN_NO_MARCH") != nullptr;   // A/B knob
+
+template <int DIM>
+static bool launch_edge_march(int64_t K, int64_t N, const Dims& d, hipStream_t st, const float* D, const float* mask,
+                              float* R, float* sums, int mask_ch) {
+  if (g_no_march) return false;
+  const dim3 g = march_grid(d, N), b(kBlock);
+  switch (K) {
+    case 2: hipLaunchKernelGGL((k_edge_fwd_march<DIM, 2>), g, b, 0, st, D, mask, R, sums, d, mask_ch); return true;
+    case 3: hipLaunchKernelGGL((k_edge_fwd_march<DIM, 3>), g, b, 0, st, D, mask, R, sums, d, mask_ch); return true;
+    case 4: hipLaunchKernelGGL((k_edge_fwd_march<DIM, 4>), g, b, 0, st, D, mask, R, sums, d, mask_ch); return true;
+    case 5: hipLaunchKernelGGL((k_edge_fwd_march<DIM, 5>), g, b, 0, st, D, mask, R, sums, d, mask_ch); return true;
+    default: return false;
+  }
+}
+
+template <int DIM>
+static bool launch_bwd_march(int64_t K, int64_t N, const Dims& d, hipStream_t st, const float* P, const float* D,
+                             const float* R, const float* mask, const float* gscale, float* gpred, float c_mse,
+                             float c_a, float c_b, int mask_ch) {
+  if (g_no_march) return false;
+  const dim3 g = march_grid(d, N), b(kBlock);
+  switch (K) {
+    case 2: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 2>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
+    case 3: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 3>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
+    case 4: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 4>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
+    case 5: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 5>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
+    default: return false;
+  }
+}
 
 static inline bool ldims_ok(int ndim, const int64_t* s) {
   if (ndim != 2 && ndim != 3) return false;
@@ -335,10 +521,12 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
   if (want_edges && K > 1) {
     const bool rows = (d.s2 % 64) == 0;   // lane <-> x with whole waves per row: DPP neighbour exchange
     if (ndim == 3) {
-      if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
+      if (rows && mask_channels <= 1 && launch_edge_march<3>(K, N, d, st, D, mask, R, sums, mask_channels)) {}
+      else if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
       else hipLaunchKernelGGL(k_edge_fwd<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
     } else {
-      if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
+      if (rows && mask_channels <= 1 && launch_edge_march<2>(K, N, d, st, D, mask, R, sums, mask_channels)) {}
+      else if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
       else hipLaunchKernelGGL(k_edge_fwd<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
     }
   }
@@ -360,10 +548,12 @@ int advchain_consistency_bwd(const float* P, const float* D, const float* R, con
   hipStream_t st = (hipStream_t)stream;
   const bool rows = (d.s2 % 64) == 0;
   if (ndim == 3) {
-    if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+    if (rows && launch_bwd_march<3>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels)) {}
+    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
     else hipLaunchKernelGGL(k_consistency_bwd<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
   } else {
-    if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+    if (rows && launch_bwd_march<2>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels)) {}
+    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
     else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
   }
   ADVCHAIN_LAUNCH_CHECK();
