@@ -19,7 +19,7 @@ PROTOTYPES = {
     "advchain_grid_sample_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P]),
     "advchain_scatter_workspace": (_L, [_L, _I, _P]),
     "advchain_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "advchain_compose_self_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P]),
+    "advchain_compose_self_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
     "advchain_compose_self_bwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "advchain_affine_warp_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _I, _I, _P]),
     "advchain_affine_warp_bwd_workspace": (_L, [_L, _I, _P]),

@@ -273,7 +273,7 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
         else coord_grad_global<DIM, PAD_ZEROS, C>(inn, gn, gon, s, V, d, flags & kClampGrid, gg);
       }
     }
-    if (xowned) {
+    if (xowned && ovf_count) {
       // the owner lists its irregular samples (same test as at staging time: grad_out was zeroed there)
       const int sc[3] = {sx, uy, uz};
       bool regular = true;
@@ -428,7 +428,7 @@ using namespace advchain;
 
 template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 static void launch_gather(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
-                          Dims d, int padding, int clamp_grid, int32_t* ws, int chain, hipStream_t st) {
+                          Dims d, int padding, int clamp_grid, int32_t* ws, int chain, bool strict, hipStream_t st) {
   using G = GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>;
   const int wide = d.s2 > 64;
   const int n2 = wide ? (d.s2 + (64 - 2 * kXPad) - 1) / (64 - 2 * kXPad) : 1;
@@ -447,6 +447,13 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
   if (G::LDS > 65536 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
+  }
+  if (strict) {
+    // the caller guarantees the displacement bound (measured): no sample can be irregular, so there is no overflow
+    // list to reset or drain and the whole step is this one launch
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid,
+                       d, n1, n2, wide, flags, (float*)nullptr, (int*)nullptr, (int2*)nullptr, 0, dbg);
+    return;
   }
   hipLaunchKernelGGL(k_gather_prepare, dim3(1), dim3(1), 0, st, ws, chain);
   hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
@@ -469,9 +476,11 @@ static bool gather_shape_ok(const Dims& d, const void* a, const void* b, const v
 int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, float* gphi, int64_t N, int ndim, Dims d,
                                         int32_t* workspace, int chain, int halo, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
+  const bool strict = halo < 0;     // negative: exact bound |halo|, guaranteed by the caller
+  if (strict) halo = -halo;
   if (off || !workspace || halo < 1 || !gather_shape_ok(d, gout, phi, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
 #define SELF_GO(DIM_, H_, TZ_, TY_, NT_) \
-  launch_gather<DIM_, DIM_, H_, true, false, TZ_, TY_, NT_>(gout, phi, phi, gphi, nullptr, N, d, PAD_BORDER, 0, workspace, chain, st)
+  launch_gather<DIM_, DIM_, H_, true, false, TZ_, TY_, NT_>(gout, phi, phi, gphi, nullptr, N, d, PAD_BORDER, 0, workspace, chain, strict, st)
   if (ndim == 3) {
     if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
     SELF_GO(3, 1, 4, 4, 512);
@@ -491,22 +500,16 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
                                         int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                         int32_t* workspace, int halo, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
+  const bool strict = halo < 0;     // negative: exact bound |halo|, guaranteed by the caller
+  if (strict) halo = -halo;
   if (off || !workspace || halo < 1 || !gin || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   if (!gather_shape_ok(d, gout, grid, ggrid ? in : nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (C != 1 && C != 4) return ADVCHAIN_ERR_UNSUPPORTED;
 #define WARP_GO(DIM_, C_, H_, GG_, TZ_, TY_, NT_) \
-  launch_gather<DIM_, C_, H_, false, GG_, TZ_, TY_, NT_>(gout, in, grid, gin, ggrid, N, d, padding, clamp_grid, workspace, 0, st)
+  launch_gather<DIM_, C_, H_, false, GG_, TZ_, TY_, NT_>(gout, in, grid, gin, ggrid, N, d, padding, clamp_grid, workspace, 0, strict, st)
   const bool gg = ggrid != nullptr;
   if (ndim == 3) {
     if (halo != 1) return ADVCHAIN_ERR_UNSUPPORTED;
-    static const int var = getenv("ADVCHAIN_GVAR") ? atoi(getenv("ADVCHAIN_GVAR")) : 0;  // tuning knob
-    if (C == 1 && gg && var == 1) WARP_GO(3, 1, 1, true, 4, 8, 512);
-    else if (C == 1 && gg && var == 2) WARP_GO(3, 1, 1, true, 8, 8, 1024);
-    else if (C == 1 && gg && var == 3) WARP_GO(3, 1, 1, true, 4, 8, 1024);
-    else if (C == 1 && gg && var == 4) WARP_GO(3, 1, 1, true, 4, 4, 256);
-    else if (C == 1 && gg && var == 5) WARP_GO(3, 1, 1, true, 2, 8, 512);
-    else if (C == 1 && gg && var == 6) WARP_GO(3, 1, 1, true, 8, 4, 512);
-    else
     if (C == 1) { if (gg) WARP_GO(3, 1, 1, true, 4, 4, 512); else WARP_GO(3, 1, 1, false, 4, 4, 512); }
     else { if (gg) WARP_GO(3, 4, 1, true, 2, 4, 512); else WARP_GO(3, 4, 1, false, 4, 4, 512); }
   } else {

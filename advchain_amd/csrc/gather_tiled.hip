@@ -23,7 +23,8 @@ struct GTile {
 template <int DIM, int PAD, int C, bool SELF>
 __global__ void __launch_bounds__(kBlock)
 k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
-               const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode) {
+               const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode,
+               float* __restrict__ disp_out) {
   extern __shared__ float lds[];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -58,6 +59,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int nquads = tc.t0 * tc.t1 * tq;
   const float* gn = SELF ? nullptr : grid + (int64_t)n * DIM * V;
   float* on = out + (int64_t)n * C * V;
+  float dmax = 0.f;
   for (int qi = threadIdx.x; qi < nquads; qi += kBlock) {
     const int qx = qi % tq;
     const int r = qi / tq;
@@ -135,8 +137,15 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
         o = make_float4((o.x - p0.x) + id[0], (o.y - p0.y) + id[1], (o.z - p0.z) + id[2], (o.w - p0.w) + id[3]);
       }
       *reinterpret_cast<float4*>(on + (int64_t)c * V + s) = o;
+      if (SELF && disp_out) {   // displacement of the composed field (the next squaring's input), for its backward
+        const int Sa = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
+        const int sa = c == 0 ? sx : (c == 1 ? sy : sz);
+        dmax = fmaxf(fmaxf(dmax, voxel_displacement(o.x, Sa, sa)), voxel_displacement(o.y, Sa, sa + (c == 0 ? 1 : 0)));
+        dmax = fmaxf(fmaxf(dmax, voxel_displacement(o.z, Sa, sa + (c == 0 ? 2 : 0))), voxel_displacement(o.w, Sa, sa + (c == 0 ? 3 : 0)));
+      }
     }
   }
+  if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
 }
 
 }  // namespace advchain
@@ -177,8 +186,8 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
 
 template <int DIM, int PAD, bool SELF>
 static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const float* in, const float* grid, float* out,
-                            const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode) {
-#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode)
+                            const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode, float* disp_out) {
+#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out)
   switch (C) {
     case 1: if constexpr (!SELF) { LAUNCH(1); return true; } return false;
     case 2: if constexpr (!SELF || DIM == 2) { LAUNCH(2); return true; } return false;
@@ -192,7 +201,7 @@ static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const flo
 // Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify (caller uses the direct-gather kernels).
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
-                                 int halo, hipStream_t st) {
+                                 int halo, float* disp_out, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_GATHER_TILES") != nullptr;   // A/B knob
   if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
   const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
@@ -204,19 +213,19 @@ int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, 
   dim3 g((unsigned)(tc.n0 * tc.n1 * tc.n2), (unsigned)N);
   bool ok = false;
   if (self) {
-    ok = ndim == 3 ? launch_sample_c<3, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode)
-                   : launch_sample_c<2, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode);
+    ok = ndim == 3 ? launch_sample_c<3, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out)
+                   : launch_sample_c<2, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out);
   } else if (ndim == 3) {
     switch (padding) {
-      case PAD_ZEROS: ok = launch_sample_c<3, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
-      case PAD_BORDER: ok = launch_sample_c<3, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
-      default: ok = launch_sample_c<3, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      case PAD_ZEROS: ok = launch_sample_c<3, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      case PAD_BORDER: ok = launch_sample_c<3, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      default: ok = launch_sample_c<3, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
     }
   } else {
     switch (padding) {
-      case PAD_ZEROS: ok = launch_sample_c<2, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
-      case PAD_BORDER: ok = launch_sample_c<2, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
-      default: ok = launch_sample_c<2, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0); break;
+      case PAD_ZEROS: ok = launch_sample_c<2, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      case PAD_BORDER: ok = launch_sample_c<2, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      default: ok = launch_sample_c<2, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
     }
   }
   if (!ok) return ADVCHAIN_ERR_UNSUPPORTED;

@@ -179,7 +179,7 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
 template <int DIM, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
-                   Dims d, int final_mode) {
+                   Dims d, int final_mode, float* __restrict__ disp_out) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
   const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
@@ -194,6 +194,7 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
 #pragma unroll
   for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
   float* on = out + (int64_t)n * DIM * V + v;
+  float dmax = 0.f;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) {
     float r[VEC];
@@ -214,7 +215,30 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
       }
     }
     store_str<VEC>(on + (int64_t)c * V, na, r);
+    if (disp_out) {
+      // voxel coordinates of the VEC strided outputs: one 32-bit division for the first, carries for the rest
+      unsigned vx, vy, vz;
+      if (((d.s2 & (d.s2 - 1)) | (d.s1 & (d.s1 - 1))) == 0) {   // powers of two (uniform branch): shifts and masks
+        const int l2 = 31 - __builtin_clz((unsigned)d.s2), l1 = 31 - __builtin_clz((unsigned)d.s1);
+        vx = (unsigned)v & (unsigned)(d.s2 - 1);
+        vy = ((unsigned)v >> l2) & (unsigned)(d.s1 - 1);
+        vz = (unsigned)v >> (l2 + l1);
+      } else {
+        const unsigned vr = (unsigned)v / (unsigned)d.s2;
+        vx = (unsigned)v - vr * (unsigned)d.s2;
+        vz = vr / (unsigned)d.s1;
+        vy = vr - vz * (unsigned)d.s1;
+      }
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (k < na) dmax = fmaxf(dmax, voxel_displacement(r[k], c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0),
+                                                          (int)(c == 0 ? vx : (c == 1 ? vy : vz))));
+        vx += kBlock;
+        while (vx >= (unsigned)d.s2) { vx -= (unsigned)d.s2; if (++vy >= (unsigned)d.s1) { vy = 0; ++vz; } }
+      }
+    }
   }
+  if (disp_out) wave_max_to_slots(dmax, disp_out);
 }
 
 // gphi must be zero-initialised by the caller (scatter target).
@@ -550,7 +574,7 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
-                                 int halo, hipStream_t st);
+                                 int halo, float* disp_out, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
@@ -659,7 +683,7 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
   const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_fwd: per-sample volume too large");
   if (interp == INTERP_LINEAR && id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2) {   // LDS-staged tiles
-    const int rc = advchain_sample_tiled_launch(false, in, grid, out, nullptr, N, C, ndim, id, padding, clamp_grid, 0, 0,
+    const int rc = advchain_sample_tiled_launch(false, in, grid, out, nullptr, N, C, ndim, id, padding, clamp_grid, 0, 0, nullptr,
                                                 (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
@@ -695,7 +719,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
 }
 
 int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
-                              const int64_t* dims, int final_mode, void* stream) {
+                              const int64_t* dims, int final_mode, float* disp_out, void* stream) {
   ADVCHAIN_CHECK_ARG(phi && out && phi != out, "compose_self_fwd: null/aliased pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(final_mode == 0 || (final_mode == 1 && phi0), "compose_self_fwd: final_mode 1 needs phi0");
@@ -706,18 +730,18 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
   {
     const int rc = advchain_sample_tiled_launch(true, phi, nullptr, out, phi0, N, ndim, ndim, d, PAD_BORDER, 0,
-                                                final_mode, 0, (hipStream_t)stream);
+                                                final_mode, 0, disp_out, (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   if (ndim == 3) {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<3, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
-    else hipLaunchKernelGGL((k_compose_self_fwd<3, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<3, 4>), g, b, 0, st, phi, out, phi0, d, final_mode, disp_out);
+    else hipLaunchKernelGGL((k_compose_self_fwd<3, 1>), g, b, 0, st, phi, out, phi0, d, final_mode, disp_out);
   } else {
-    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<2, 4>), g, b, 0, st, phi, out, phi0, d, final_mode);
-    else hipLaunchKernelGGL((k_compose_self_fwd<2, 1>), g, b, 0, st, phi, out, phi0, d, final_mode);
+    if (vec4) hipLaunchKernelGGL((k_compose_self_fwd<2, 4>), g, b, 0, st, phi, out, phi0, d, final_mode, disp_out);
+    else hipLaunchKernelGGL((k_compose_self_fwd<2, 1>), g, b, 0, st, phi, out, phi0, d, final_mode, disp_out);
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;

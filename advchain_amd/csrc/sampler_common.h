@@ -94,5 +94,24 @@ __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r
 
 __device__ __forceinline__ float clamp_unit(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
+// displacement of a sampling position from its own voxel, in voxels (NaN -> ignored by the max, inf -> capped)
+__device__ __forceinline__ float voxel_displacement(float g, int S, int s) {
+  const float dv = fabsf(((g + 1.f) * 0.5f) * (float)(S - 1) - (float)s);
+  return dv < 1.0e9f ? dv : 1.0e9f;
+}
+
+// wave maximum of a non-negative value -> one of kDispSlots float slots (atomic max on the bit pattern).  Measured: tens of thousands of waves max-ing into 64 slots that start at zero cost 100+ us per launch (every
+// wave sees a stale smaller value and issues its atomic; contended same-address atomics across XCDs are far slower than
+// the uncontended 10 ns) -- with 4096 slots a slot sees a handful of waves.  Callable by partially active waves.
+constexpr int kDispSlots = 4096;
+__device__ __forceinline__ void wave_max_to_slots(float m, float* __restrict__ slots) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float* p = slots + ((blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kDispSlots;
+  // fire and forget (no read-before: a dependent load would keep every wave alive for another memory round trip)
+  if ((threadIdx.x & 63) == __builtin_ffsll(__builtin_amdgcn_ballot_w64(true)) - 1 && m > 0.f)
+    atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(m));
+}
+
 
 }  // namespace advchain

@@ -388,7 +388,7 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                   int32_t* workspace, int chain, int halo, hipStream_t st) {
   if (C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
-  const TileCfg tc = choose_tiles(ndim, d, (int)C, halo);
+  const TileCfg tc = choose_tiles(ndim, d, (int)C, halo < 0 ? -halo : halo);   // sign = exactness, used by the gather form only
   const int64_t V = d.voxels();
   int* cnt = workspace;
   float* amax = reinterpret_cast<float*>(workspace + 2);  // [0] = in, [1] = out

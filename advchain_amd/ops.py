@@ -59,6 +59,7 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
     return out
 
 
+DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
 ADAPTIVE_HALO = True   # measure the displacement in forward and size the backward halos from it
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 
@@ -82,13 +83,14 @@ def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, 
     return gin, ggrid
 
 
-def raw_compose_self_fwd(phi, phi0=None, final_mode=0):
+def raw_compose_self_fwd(phi, phi0=None, final_mode=0, disp_out=None):
+    """phi o phi; `disp_out` (DISP_SLOTS zero-initialised floats) max-accumulates the displacement of the result."""
     N = phi.shape[0]
     nd = phi.dim() - 2
     out = torch.empty_like(phi)
     _lib.check(_lib.load().advchain_compose_self_fwd(_ptr(phi), _ptr(out), _ptr(phi0), N, nd,
-                                                     _lib.dims_array(phi.shape[2:]), final_mode, _stream()),
-               "compose_self_fwd")
+                                                     _lib.dims_array(phi.shape[2:]), final_mode, _ptr(disp_out),
+                                                     _stream()), "compose_self_fwd")
     return out
 
 
@@ -112,31 +114,22 @@ def raw_max_displacement(phi):
     return out
 
 
-def squaring_halos(disp_last, n, d):
-    """Displacement bounds for the backward of the n squarings, last squaring first.
-
-    `disp_last` = measured max displacement (voxels) of the input of the LAST squaring; the input of squaring m moves
-    about half as far as that of m+1 (measured ratio 0.50-0.53: bounded with 0.55).  Bounds below 1 voxel (3D) /
-    4 voxels (2D) select the gather-form adjoint, the rest the tile halo of the scatter kernels."""
-    halos = []
-    est = float(disp_last)
-    for _ in range(n):
-        if not est == est:       # NaN field: nothing to tune
-            halos.append(0)
-        elif est < 0.9:
-            halos.append(1)
-        elif d == 3:
-            halos.append(2)
-        elif est < 1.8:
-            halos.append(2)
-        elif est < 3.6:
-            halos.append(4)
-        elif est < 7.0:
-            halos.append(8)
-        else:
-            halos.append(16)     # beyond 16 voxels the overflow list is cheaper than a wider halo
-        est *= 0.55
-    return halos
+def squaring_halo(disp, d):
+    """Displacement bound for the backward of one squaring from the MEASURED displacement of its input (voxels).
+    Negative = exact (the gather-form adjoint then needs no overflow list): the measurement uses the kernels' own
+    arithmetic, so `disp < H` guarantees every sample is within H voxels.  Larger displacements size the tile halo of
+    the scatter kernels (a hint: anything beyond it goes through their overflow list)."""
+    if not disp == disp:
+        return 0                 # NaN field: nothing to tune
+    if disp < 0.999:
+        return -1
+    if d == 3:
+        return 2                 # measured: wider 3D halos cost more than the overflow list saves
+    if disp < 1.999:
+        return -2
+    if disp < 3.999:
+        return -4
+    return 8 if disp < 7.0 else 16   # beyond 16 voxels the overflow list is cheaper than a wider halo
 
 
 def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
@@ -235,18 +228,20 @@ def grid_displacement(grid):
 
 
 def warp_halo(entry, d):
-    """Displacement bound for the backward of a warp from the measured value (one 4-byte read-back per grid)."""
+    """Displacement bound for the backward of a warp from the measured value (one 4-byte read-back per grid);
+    negative = exact (see squaring_halo)."""
     if entry[1] is None:
         entry[1] = float(entry[0].item())
     est = entry[1]
     if not est == est:
         return 0
     if d == 3:
-        return 1 if est < 0.95 else 2   # measured: wider 3D halos cost more than the overflow list saves
-    for h in (2, 4, 8, 16):
-        if est < 0.95 * h:
-            return h
-    return 16
+        return -1 if est < 0.999 else 2
+    if est < 1.999:
+        return -2
+    if est < 3.999:
+        return -4
+    return 8 if est < 7.0 else 16
 
 
 class _GridSample(torch.autograd.Function):
@@ -450,12 +445,19 @@ class _DemonsField(torch.autograd.Function):
                 n += 1
         inv = 1.0 / (2.0 ** n)
         phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv)]
+        # row m of `disp`: max-slots for the displacement of phis[m] (row 0 from its own pass, the others written by
+        # the squaring that produces them) -- the backward reads them back once and sizes every step exactly
+        disp = torch.zeros(n, DISP_SLOTS, device=vel.device, dtype=torch.float32) if ADAPTIVE_HALO else None
+        if disp is not None:
+            _lib.check(_lib.load().advchain_max_displacement(_ptr(phis[0]), _ptr(disp), phis[0].shape[0], d,
+                                                             _lib.dims_array(phis[0].shape[2:]), _stream()),
+                       "max_displacement")
         for i in range(n - 1):
-            phis.append(raw_compose_self_fwd(phis[-1]))
+            phis.append(raw_compose_self_fwd(phis[-1], disp_out=None if disp is None else disp[i + 1]))
         pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1)
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
-        ctx.disp = raw_max_displacement(phis[-1]) if ADAPTIVE_HALO else None
+        ctx.disp = disp
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
         return q
@@ -474,7 +476,8 @@ class _DemonsField(torch.autograd.Function):
         # through the overflow list); it comes from the displacement measured in forward (one 4-byte read-back).
         n = len(phis)
         if ctx.disp is not None:
-            halos = squaring_halos(float(ctx.disp.item()), n, d)
+            dm = ctx.disp.max(dim=1).values.tolist()            # one read-back for the whole chain
+            halos = [squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
         else:
             big = 2 if d == 3 else 16
             halos = [big, big, max(1, big // 2)] + [1 if d == 3 else 2] * n

@@ -260,9 +260,9 @@ def grid_sample3d_roofline(device, reps=20):
             "achieved": round((bf + bb) / (tf + tb) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4), "fwd_us": round(tf * 1e6, 2),
             "bwd_us": round(tb * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "bwd_GBs": round(bb / tb / 1e9, 1),
-            "algorithmic_bytes": bf + bb, "displacement_bound_voxels": halo,
-            "note": "bwd = gather-form adjoint when the measured displacement bound is 1 voxel, else LDS-tiled scatter; "
-                    "+ header-reset and overflow-drain launches"}
+            "algorithmic_bytes": bf + bb, "displacement_bound_voxels": abs(halo), "bound_is_exact": halo < 0,
+            "note": "bwd = gather-form adjoint (one launch) when the measured displacement is below 1 voxel, else "
+                    "LDS-tiled scatter + header-reset and overflow-drain launches"}
 
 
 def cpu_baseline(wl, name):

@@ -58,7 +58,8 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
  * halo > 0: an upper bound on the displacement |sampling position - own voxel| in voxels (see
  * advchain_max_displacement) -- a performance hint only: small bounds (1 in 3D, <= 4 in 2D; C in {1,4}) select the
  * gather-form adjoint (no atomics), larger ones size the tile halo; samples beyond the bound stay correct through the
- * overflow list.  0 = default tiles.                                                                  */
+ * overflow list.  0 = default tiles.  halo < 0: |halo| is exact (guaranteed by the caller): see
+ * advchain_compose_self_bwd.                                                                          */
 int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
                              float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
@@ -71,9 +72,13 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
  *           vectorFieldExponentiation{2,3}D adv_morph.py:132-135,165-168.
  * final_mode 1 additionally emits (sample - phi0) + identity, i.e. 'phi - grid_wh' (with the
  * in-place aliasing of adv_morph.py:111,143,176) plus '+ self.base_grid' of :474,483.
- * phi, out, phi0: (N, ndim, dims).                                                          */
+ * phi, out, phi0: (N, ndim, dims).
+ * disp_out (may be NULL): ADVCHAIN_DISP_SLOTS (4096) floats, zero-initialised by the caller; the kernel
+ * max-accumulates (atomically, spread over the slots) the displacement |position - own voxel| of `out` in voxels --
+ * the max over the slots is the bound the backward of the NEXT squaring wants (advchain_compose_self_bwd: halo). */
+#define ADVCHAIN_DISP_SLOTS 4096
 int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
-                              const int64_t* dims, int final_mode, void* stream);
+                              const int64_t* dims, int final_mode, float* disp_out, void* stream);
 /* grad_phi receives both the value path (scatter) and the coordinate path; overwritten when a
  * `workspace` (as above) is given, otherwise it must be pre-zeroed (global-atomic path).
  * chain != 0: grad_out is the grad_phi of the previous call on the same workspace (the backward of
@@ -81,7 +86,10 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * halo > 0: an upper bound on |displacement| of phi in voxels -- a performance hint only: samples beyond it stay
  * correct through the overflow list (global atomics).  Small bounds (1 in 3D; 1..4 in 2D) select the gather-form
  * adjoint (no atomics, bit-reproducible); larger ones the LDS-tiled fixed-point scatter with that tile halo;
- * 0 = default scatter tiles (halo 2 in 3D, 16 in 2D).                                                   */
+ * 0 = default scatter tiles (halo 2 in 3D, 16 in 2D).
+ * halo < 0: |halo| is EXACT -- the caller guarantees no sample moves |halo| voxels or more on any axis (measured with
+ * advchain_max_displacement / disp_out): the gather form then skips the overflow list and is a single launch; samples
+ * violating the guarantee would be dropped.  (A chained scatter call after a strict gather call must pass chain = 0.) */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
                               int halo, int64_t N, int ndim, const int64_t* dims, void* stream);
 /* max over samples and axes of |sampling position - own voxel| of the field phi, in voxels: the displacement

@@ -150,6 +150,28 @@ def test_compose_self(dims, scatter_path):
     assert maxdiff(fin.cpu(), (ref.detach() - phi0) + O.identity_grid(2, dims)) < TOL
 
 
+@pytest.mark.parametrize("dims", [(20, 28), (64, 256), (8, 12, 16), (16, 24, 64)])
+def test_displacement_measurements(dims):
+    """advchain_max_displacement and the disp_out slots of advchain_compose_self_fwd report max |position - voxel|."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    ident = O.identity_grid(2, dims)
+    phi = (ident + 0.05 * rand((2, d) + dims, 51)).contiguous()
+
+    def disp_of(f):
+        m = 0.0
+        for a in range(d):
+            S = dims[d - 1 - a]
+            m = max(m, float(((f[:, a] - ident[:, a]) * (S - 1) / 2).abs().max()))
+        return m
+    got = float(ops.raw_max_displacement(phi.to(DEV)).item())
+    assert abs(got - disp_of(phi)) < 1e-3
+    slots = torch.zeros(ops.DISP_SLOTS, device=DEV)
+    out = ops.raw_compose_self_fwd(phi.to(DEV), disp_out=slots)
+    assert abs(float(slots.max()) - disp_of(out.cpu())) < 1e-3
+
+
 @pytest.mark.parametrize("dims", [(24, 40), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
 @pytest.mark.parametrize("C", [1, 4])
 @pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
@@ -174,6 +196,9 @@ def test_grid_sample_bwd_gather_form(dims, C, pad, clamp, amp):
         assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max()))
         gin2, none = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, False, halo)
         assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
+        if float(ops.raw_max_displacement(grid.to(DEV)).item()) < halo:   # bound holds: the exact (single-launch) form agrees
+            gin3, ggrid3 = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, True, -halo)
+            assert torch.equal(gin3, gin) and torch.equal(ggrid3, ggrid)
 
 
 @pytest.mark.parametrize("dims", [(20, 28), (40, 72), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
@@ -205,6 +230,9 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
     g1b = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=halo)
     if amp < 0.1:
         assert torch.equal(g1, g1b)
+        # exact bound (negative halo): single launch without the overflow list, same numbers
+        g1s = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-halo)
+        assert torch.equal(g1, g1s)
 
 
 @pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4)])

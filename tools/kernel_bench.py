@@ -57,6 +57,13 @@ def main():
     x4 = torch.rand(N, 4, *dims, device=dev)
     g1, g4, gq = torch.rand_like(x1), torch.rand_like(x4), torch.rand_like(q)
     theta = (torch.eye(d, d + 1, device=dev).repeat(N, 1, 1) + 0.05 * torch.randn(N, d, d + 1, device=dev)).contiguous()
+    rot = float(os.environ.get("KB_ROT", "0"))
+    if rot:   # in-plane rotation (degrees) on top: the ascent steps of the bench workloads reach 15-30 degrees
+        import math
+        cr, sr = math.cos(math.radians(rot)), math.sin(math.radians(rot))
+        R = torch.eye(d, device=dev)
+        R[0, 0], R[0, 1], R[1, 0], R[1, 1] = cr, -sr, sr, cr
+        theta = torch.cat([R @ theta[:, :, :d], theta[:, :, d:]], dim=2).contiguous()
     rows = []
 
     def add(name, fn, nbytes):
