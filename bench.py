@@ -207,15 +207,30 @@ def run_gpu(args, wl, rank, world, device):
         avg_t = sum(durs) / len(durs)
         avg_b = sum(bts) / len(bts)
         achieved = avg_b / avg_t / 1e9
+        traffic, source = profiled_traffic(args.workload, dominant)
         roof = {"bound": "hbm", "kernel": dominant.replace("advchain_", ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
+                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": source,
+                "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b)}
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, roof, breakdown
+
+
+def profiled_traffic(workload, entry):
+    """HBM bytes per launch of `entry` from the committed PMC passes of this command (profiles/r01/traffic.json, made by
+    tools/profile_pmc.sh + tools/traffic_from_pmc.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
+    corrected as profiles/README.md states).  Counters cannot be read from inside the timed run; None if not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)[workload][entry]
+        return rec["traffic_bytes_per_launch"], "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def grid_sample3d_roofline(device, reps=20):
