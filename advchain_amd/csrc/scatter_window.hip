@@ -1,0 +1,180 @@
+// Source-tiled window scatter for the 2D sampler backward with LARGE displacements (gfx950).
+//
+// The owner-computes tiles of scatter_tiled.hip walk a halo as wide as the largest displacement: at cfg-2 the fields
+// reach 70 px, the halo is 16 px, every sample is processed by 4 owners and what lands beyond the halo goes through
+// an overflow list (image-warp backward: 195 MB of traffic for 96 MB of data, 0.37 TB/s).  But the fields are smooth:
+// the targets of a 32 x 32 tile of SAMPLES form a compact patch -- the tile shifted by its mean displacement and
+// stretched by the local gradient -- however far it moved.  So here a workgroup owns a tile of samples:
+//   1. builds the taps of its 1024 samples once (4 per thread) and reduces the bounding box of their corners and the
+//      tile's max |grad_out|;
+//   2. accumulates the deposits in an LDS window over that box as 32-bit fixed point (value * 2^20 / max|grad_out|:
+//      at most 1024 deposits of weight <= 1 reach a cell, so the sum stays below 2^30; LDS integer atomics run at LDS
+//      rate, LDS float atomics do not); corners outside a window that had to be capped go straight to global atomics;
+//   3. flushes the non-zero cells with global float atomics -- rows of consecutive addresses, ~1.7 per sample instead
+//      of 4 scattered ones.
+// Every sample is read and processed exactly once, there is no halo, no overflow list and no max|grad_out| pre-pass;
+// the price is a zero-filled destination and float-atomic (order-dependent, ~1e-7 relative) accumulation across tiles.
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+constexpr int kWinT = 32;               // sample tile edge
+constexpr int kWinCells = 8192;         // LDS window budget in cells (all channels together): 32 KiB
+
+// SELF : in == grid == phi (C == 2); the coordinate-path gradient is added to the same tensor (atomics: other tiles
+//        deposit there too).  Otherwise GG: grad_grid is written with plain stores.
+template <int PAD, int C, bool SELF, bool GG>
+__global__ void __launch_bounds__(kBlock)
+k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n2, int clamp_grid) {
+  __shared__ int win[kWinCells];
+  __shared__ int red[8][kBlock / 64];
+  constexpr int DIM = 2;
+  constexpr int SPT = kWinT * kWinT / kBlock;   // samples per thread (4)
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const int tx = blockIdx.x % n2, ty = blockIdx.x / n2;
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;      // x in tile, first row; rows ly0 + 8 j
+  const int sx = tx * kWinT + lx;
+  const float* gn = grid + (int64_t)n * DIM * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  const float* inn = in + (int64_t)n * C * V;
+  float* ginn = gin + (int64_t)n * C * V;
+
+  // ---- 1. taps of this thread's samples, bounding box of the valid corners, max |grad_out|
+  Taps<DIM, PAD> t[SPT];
+  float go[SPT][C];
+  bool live[SPT], px[SPT], py[SPT];
+  int bx0 = 1 << 30, bx1 = -(1 << 30), by0 = 1 << 30, by1 = -(1 << 30);
+  float gmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const int sy = ty * kWinT + ly0 + 8 * j;
+    live[j] = sx < d.s2 && sy < d.s1;
+    const int s = live[j] ? sy * d.s2 + sx : 0;
+    float gx = gn[s], gy = gn[V + s];
+    px[j] = py[j] = true;
+    if (clamp_grid) {
+      px[j] = gx >= -1.f && gx <= 1.f; py[j] = gy >= -1.f && gy <= 1.f;
+      gx = clamp_unit(gx); gy = clamp_unit(gy);
+    }
+    t[j].build(gx, gy, 0.f, d);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      go[j][c] = live[j] ? gon[(int64_t)c * V + s] : 0.f;
+      gmax = fmaxf(gmax, fabsf(go[j][c]));
+    }
+    if (live[j]) {
+      if (t[j].x.v0 || t[j].x.v1) { bx0 = min(bx0, t[j].x.i0 + (t[j].x.v0 ? 0 : 1)); bx1 = max(bx1, t[j].x.i0 + (t[j].x.v1 ? 1 : 0)); }
+      if (t[j].y.v0 || t[j].y.v1) { by0 = min(by0, t[j].y.i0 + (t[j].y.v0 ? 0 : 1)); by1 = max(by1, t[j].y.i0 + (t[j].y.v1 ? 1 : 0)); }
+    }
+  }
+  // block reduction: 4 ints + 1 float through the wave, then LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bx0 = min(bx0, __shfl_xor(bx0, o, 64)); bx1 = max(bx1, __shfl_xor(bx1, o, 64));
+    by0 = min(by0, __shfl_xor(by0, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+    gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = bx0; red[1][wave] = bx1; red[2][wave] = by0; red[3][wave] = by1; red[4][wave] = __float_as_int(gmax);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    bx0 = min(bx0, red[0][w]); bx1 = max(bx1, red[1][w]); by0 = min(by0, red[2][w]); by1 = max(by1, red[3][w]);
+    gmax = fmaxf(gmax, __int_as_float(red[4][w]));
+  }
+  // window = box, capped to the LDS budget (keeps the low corner; what falls outside uses global atomics)
+  int ww = max(bx1 - bx0 + 1, 0), wh = max(by1 - by0 + 1, 0);
+  constexpr int cells_per_ch = kWinCells / C;
+  if (ww > 128) ww = 128;
+  if (ww > 0 && wh > cells_per_ch / ww) wh = cells_per_ch / ww;
+  const int cells = ww * wh;
+  for (int i = threadIdx.x; i < C * cells; i += kBlock) win[i] = 0;
+  const float scale = gmax > 0.f ? 1048576.f / gmax : 0.f;   // 2^20
+  __syncthreads();
+
+  // ---- 2. deposits
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    if (!live[j]) continue;
+    const int sy = ty * kWinT + ly0 + 8 * j;
+    const int s = sy * d.s2 + sx;
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        if (!t[j].ok(0, cy, cx)) continue;
+        const int ux = t[j].x.i0 + cx, uy = t[j].y.i0 + cy;
+        const float w = t[j].w(0, cy, cx);
+        const int wx = ux - bx0, wy = uy - by0;
+        if (wx >= 0 && wx < ww && wy >= 0 && wy < wh) {
+          const float ws = w * scale;
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(win + c * cells + wy * ww + wx, __float2int_rn(ws * go[j][c]));
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * V + uy * d.s2 + ux, w * go[j][c]);
+        }
+      }
+    if (SELF || GG) {
+      float ax = 0.f, ay = 0.f, dummy = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, go[j][c], t[j], d, ax, ay, dummy);
+      const float ggx = px[j] ? t[j].x.mult * ax : 0.f, ggy = py[j] ? t[j].y.mult * ay : 0.f;
+      if (SELF) {
+        if (ggx != 0.f) atomic_add_f32(ginn + s, ggx);
+        if (ggy != 0.f) atomic_add_f32(ginn + V + s, ggy);
+      } else {
+        float* gg = ggrid + (int64_t)n * DIM * V + s;
+        gg[0] = ggx;
+        gg[V] = ggy;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. flush the non-zero cells (rows of the window are runs of consecutive addresses)
+  const float inv = gmax * (1.f / 1048576.f);
+  for (int i = threadIdx.x; i < C * cells; i += kBlock) {
+    const int a = win[i];
+    if (a == 0) continue;
+    const int c = i / cells, r = i - c * cells;
+    const int wy = r / ww, wx = r - wy * ww;
+    atomic_add_f32(ginn + (int64_t)c * V + (by0 + wy) * d.s2 + (bx0 + wx), (float)a * inv);
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+// 2D only.  grad_in (and, for SELF, the same tensor) is zero-filled here.  Returns ADVCHAIN_ERR_UNSUPPORTED for shapes
+// the kernel does not cover (the caller keeps the owner-computes tiles).
+int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
+                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
+                                   hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
+  if (off || ndim != 2 || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (self ? C != 2 : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const int n2 = (d.s2 + kWinT - 1) / kWinT, n1 = (d.s1 + kWinT - 1) / kWinT;
+  (void)hipMemsetAsync(gin, 0, sizeof(float) * N * C * d.voxels(), st);
+  dim3 g((unsigned)(n1 * n2), (unsigned)N), b(kBlock);
+  const bool gg = ggrid != nullptr;
+#define GO(PAD_, C_, SELF_, GG_) \
+  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid)
+#define GO_PAD(C_, SELF_, GG_) \
+  do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, SELF_, GG_); else GO(PAD_ZEROS, C_, SELF_, GG_); } while (0)
+  if (self) GO(PAD_BORDER, 2, true, false);
+  else if (C == 1) { if (gg) GO_PAD(1, false, true); else GO_PAD(1, false, false); }
+  else if (C == 2) { if (gg) GO_PAD(2, false, true); else GO_PAD(2, false, false); }
+  else { if (gg) GO_PAD(4, false, true); else GO_PAD(4, false, false); }
+#undef GO_PAD
+#undef GO
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}

@@ -216,13 +216,32 @@ def normalized_axpy(base, x, step=1.0):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
+class _Readback:
+    """A few device floats copied to pinned host memory right where they are produced, with an event recorded behind
+    the copy.  `values()` waits on THAT event only: by the time the backward asks, the copy finished long ago, so the
+    read does not drain the kernels queued since (a `.item()` would enqueue its copy behind all of them)."""
+
+    def __init__(self, dev_tensor):
+        self.host = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
+        self.host.copy_(dev_tensor, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._vals = None
+
+    def values(self):
+        if self._vals is None:
+            self.event.synchronize()
+            self._vals = self.host.tolist()
+        return self._vals
+
+
 def grid_displacement(grid):
     """Max displacement (voxels) of a sampling grid, measured once per grid tensor (the entry -- a 1-float device tensor
     and, after the first read-back, its host value -- rides on the tensor object: the same deformation warps the image
     and then the prediction)."""
     hit = getattr(grid, "_advchain_disp", None)
     if hit is None or hit[2] != grid._version:
-        hit = [raw_max_displacement(grid.detach()), None, grid._version]
+        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version]
         grid._advchain_disp = hit
     return hit
 
@@ -231,7 +250,7 @@ def warp_halo(entry, d):
     """Displacement bound for the backward of a warp from the measured value (one 4-byte read-back per grid);
     negative = exact (see squaring_halo)."""
     if entry[1] is None:
-        entry[1] = float(entry[0].item())
+        entry[1] = float(entry[0].values()[0])
     est = entry[1]
     if not est == est:
         return 0
@@ -457,7 +476,7 @@ class _DemonsField(torch.autograd.Function):
         pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1)
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
-        ctx.disp = disp
+        ctx.disp = None if disp is None else _Readback(disp.max(dim=1).values)   # one read-back for the whole chain
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
         return q
@@ -476,7 +495,7 @@ class _DemonsField(torch.autograd.Function):
         # through the overflow list); it comes from the displacement measured in forward (one 4-byte read-back).
         n = len(phis)
         if ctx.disp is not None:
-            dm = ctx.disp.max(dim=1).values.tolist()            # one read-back for the whole chain
+            dm = ctx.disp.values()
             halos = [squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
         else:
             big = 2 if d == 3 else 16

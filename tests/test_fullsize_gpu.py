@@ -1,7 +1,7 @@
 """Full BASELINE sizes (cfg-2: 32x1x256x256, cfg-3: 4x1x128x128x64) on the GPU, checked through size-independent
 properties, since the CPU oracle needs minutes there: adjointness <A x, y> = <x, A^T y> of every forward/backward
 kernel pair, linearity, identity warps, agreement of the two independent scatter implementations, bitwise
-run-to-run determinism of the fixed-point scatter, and one whole solver call (finite, ascent does not lower the
+run-to-run determinism of the fixed-point scatter (3D), and one whole solver call (finite, ascent does not lower the
 loss, parameters obey their constraints)."""
 import pytest
 import torch
@@ -44,9 +44,13 @@ def test_warp_adjoint_linearity_and_paths(shape):
         ATy, gq = ops.raw_grid_sample_bwd(y, x, q, 0, 0, True, True, True)
         lhs, rhs = dot(Ax, y), dot(x, ATy)
         assert abs(lhs - rhs) < 1e-5 * abs(lhs), (lhs, rhs)
-        # the two scatter implementations agree; the tiled (fixed-point) one is bitwise deterministic
+        # run-to-run: the 3D tiled (fixed-point) scatter is bitwise deterministic; the 2D window scatter flushes with
+        # float atomics (order-dependent in the last bits)
         ATy_again, _ = ops.raw_grid_sample_bwd(y, x, q, 0, 0, True, True, False)
-        assert torch.equal(ATy, ATy_again)
+        if len(s["dims"]) == 3:
+            assert torch.equal(ATy, ATy_again)
+        else:
+            assert float((ATy - ATy_again).abs().max()) < 1e-5 * float(ATy.abs().max())
         old = ops.TILED_SCATTER
         ops.TILED_SCATTER = False
         try:
@@ -87,7 +91,11 @@ def test_compose_self_jvp_matches_vjp(shape):
     vj = ops.raw_compose_self_bwd(g, phi)
     lhs, rhs = dot(jv, g), dot(dphi, vj)
     assert abs(lhs - rhs) < 3e-2 * max(abs(lhs), abs(rhs)) + 1.0, (lhs, rhs)   # fp32 finite difference
-    assert torch.equal(vj, ops.raw_compose_self_bwd(g, phi))   # deterministic
+    vj2 = ops.raw_compose_self_bwd(g, phi)
+    if d == 3:
+        assert torch.equal(vj, vj2)                                  # fixed-point tiles: deterministic
+    else:
+        assert float((vj - vj2).abs().max()) < 1e-5 * float(vj.abs().max())   # window scatter: float-atomic flush
 
 
 @pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
