@@ -118,8 +118,15 @@ def check(rc, what):
         raise AdvchainHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
 
 
+_DIMS = {}
+
+
 def dims_array(dims):
-    return (c_int64 * len(dims))(*[int(d) for d in dims])
+    key = tuple(dims)
+    arr = _DIMS.get(key)
+    if arr is None:
+        arr = _DIMS[key] = (c_int64 * len(key))(*[int(d) for d in key])   # read-only for the library: safe to share
+    return arr
 
 
 def float_array(vals):

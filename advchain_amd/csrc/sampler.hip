@@ -194,13 +194,15 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
 #pragma unroll
   for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
   float* on = out + (int64_t)n * DIM * V + v;
-  float dmax = 0.f;
+  // all gathers first (no control flow between the channels: their loads stay in flight together)
+  float r[DIM][VEC];
 #pragma unroll
-  for (int c = 0; c < DIM; ++c) {
-    float r[VEC];
+  for (int c = 0; c < DIM; ++c)
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD_BORDER>(pn + (int64_t)c * V, t[k], d);
-    if (final_mode == 1) {
+    for (int k = 0; k < VEC; ++k) r[c][k] = sample_linear<DIM, PAD_BORDER>(pn + (int64_t)c * V, t[k], d);
+  if (final_mode == 1) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
       float p0[VEC];
       load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, p0);
 #pragma unroll
@@ -211,34 +213,38 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
         if (c == 0) { idx = (int)(vv % d.s2); S = d.s2; }
         else if (c == 1) { idx = (int)((vv / d.s2) % d.s1); S = d.s1; }
         else { idx = (int)(vv / ((int64_t)d.s2 * d.s1)); S = d.s0; }
-        r[k] = (r[k] - p0[k]) + lin_coord(idx, S);
-      }
-    }
-    store_str<VEC>(on + (int64_t)c * V, na, r);
-    if (disp_out) {
-      // voxel coordinates of the VEC strided outputs: one 32-bit division for the first, carries for the rest
-      unsigned vx, vy, vz;
-      if (((d.s2 & (d.s2 - 1)) | (d.s1 & (d.s1 - 1))) == 0) {   // powers of two (uniform branch): shifts and masks
-        const int l2 = 31 - __builtin_clz((unsigned)d.s2), l1 = 31 - __builtin_clz((unsigned)d.s1);
-        vx = (unsigned)v & (unsigned)(d.s2 - 1);
-        vy = ((unsigned)v >> l2) & (unsigned)(d.s1 - 1);
-        vz = (unsigned)v >> (l2 + l1);
-      } else {
-        const unsigned vr = (unsigned)v / (unsigned)d.s2;
-        vx = (unsigned)v - vr * (unsigned)d.s2;
-        vz = vr / (unsigned)d.s1;
-        vy = vr - vz * (unsigned)d.s1;
-      }
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        if (k < na) dmax = fmaxf(dmax, voxel_displacement(r[k], c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0),
-                                                          (int)(c == 0 ? vx : (c == 1 ? vy : vz))));
-        vx += kBlock;
-        while (vx >= (unsigned)d.s2) { vx -= (unsigned)d.s2; if (++vy >= (unsigned)d.s1) { vy = 0; ++vz; } }
+        r[c][k] = (r[c][k] - p0[k]) + lin_coord(idx, S);
       }
     }
   }
-  if (disp_out) wave_max_to_slots(dmax, disp_out);
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) store_str<VEC>(on + (int64_t)c * V, na, r[c]);
+  if (disp_out) {
+    // voxel coordinates of the VEC strided outputs: one 32-bit division for the first, carries for the rest
+    unsigned vx, vy, vz;
+    if (((d.s2 & (d.s2 - 1)) | (d.s1 & (d.s1 - 1))) == 0) {   // powers of two (uniform branch): shifts and masks
+      const int l2 = 31 - __builtin_clz((unsigned)d.s2), l1 = 31 - __builtin_clz((unsigned)d.s1);
+      vx = (unsigned)v & (unsigned)(d.s2 - 1);
+      vy = ((unsigned)v >> l2) & (unsigned)(d.s1 - 1);
+      vz = (unsigned)v >> (l2 + l1);
+    } else {
+      const unsigned vr = (unsigned)v / (unsigned)d.s2;
+      vx = (unsigned)v - vr * (unsigned)d.s2;
+      vz = vr / (unsigned)d.s1;
+      vy = vr - vz * (unsigned)d.s1;
+    }
+    float dmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if (k < na) {
+        dmax = fmaxf(dmax, fmaxf(voxel_displacement(r[0][k], d.s2, (int)vx), voxel_displacement(r[1][k], d.s1, (int)vy)));
+        if (DIM == 3) dmax = fmaxf(dmax, voxel_displacement(r[DIM - 1][k], d.s0, (int)vz));
+      }
+      vx += kBlock;
+      while (vx >= (unsigned)d.s2) { vx -= (unsigned)d.s2; if (++vy >= (unsigned)d.s1) { vy = 0; ++vz; } }
+    }
+    wave_max_to_slots(dmax, disp_out);
+  }
 }
 
 // gphi must be zero-initialised by the caller (scatter target).

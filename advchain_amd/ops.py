@@ -5,6 +5,7 @@ PyTorch / CPU fallback -- a CPU tensor or a missing library raises.  PyTorch is 
 memory (``torch.empty``), the current stream and the autograd tape only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -20,7 +21,15 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    # torch.cuda.current_stream() builds a Stream object through five Python layers (~10 us; ~300 calls per solver
+    # call): ask the C layer for the raw handle of the current stream of the current device instead
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -60,7 +69,7 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
 
 
 DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
-ADAPTIVE_HALO = True   # measure the displacement in forward and size the backward halos from it
+ADAPTIVE_HALO = os.environ.get("ADVCHAIN_NO_ADAPTIVE_HALO") is None   # measure the displacement in forward and size the backward halos from it
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 
 
