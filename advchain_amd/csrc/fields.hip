@@ -11,7 +11,7 @@
 //   advchain_axpy / advchain_scale <- adv_noise.py:81-84 and gradient scaling
 //   advchain_sumsq_partial / advchain_norm_axpy <- unit_normalize + ascent update,
 //                                     adv_transformation_base.py:151-155, adv_noise.py:56-63 etc.
-#include "common.h"
+#include "sampler_common.h"
 
 namespace advchain {
 
@@ -122,7 +122,7 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
 // (64 slot accumulators) for the 3D step-count rule.  grid = (i1 chunks, S0, planes).
 __global__ void __launch_bounds__(kBlock)
 k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTables T, Dims full, int C,
-                int add_identity, float scale, float* __restrict__ sumsq) {
+                int add_identity, float scale, float* __restrict__ sumsq, float* __restrict__ disp_out) {
   __shared__ float lds[kTpMaxLds];
   __shared__ float smem[4];
   const int plane = blockIdx.z, i0 = blockIdx.y;
@@ -131,14 +131,18 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
   const int V = (int)full.voxels();
   const int c = plane % C;  // channel 0 = x <-> s2, 1 = y <-> s1, 2 = z <-> s0
   float sq[1] = {0.f};
+  float dmax = 0.f;
+  const float to_vox = fabsf(scale) * 0.5f * (float)((c == 0 ? full.s2 : (c == 1 ? full.s1 : full.s0)) - 1);
   tp_rows(coef + (int64_t)plane * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, float val) {
     sq[0] += val * val;
+    dmax = fmaxf(dmax, fabsf(val));
     if (out) {
       float base = 0.f;
       if (add_identity) base = c == 0 ? lin_coord(x, full.s2) : (c == 1 ? lin_coord(i1, full.s1) : lin_coord(i0, full.s0));
       out[(int64_t)plane * V + ((int64_t)i0 * full.s1 + i1) * full.s2 + x] = base + scale * val;
     }
   });
+  if (disp_out) wave_max_to_slots(fminf(dmax * to_vox, 1.0e9f), disp_out);   // displacement of base + scale * val, in voxels
   if (sumsq) {
     block_sum<1>(sq, smem);
     if (threadIdx.x == 0) atomic_add_f32(sumsq + (blockIdx.x + blockIdx.y * 3u + blockIdx.z * 7u) % kSumSlots, sq[0]);
@@ -558,7 +562,7 @@ extern "C" {
 
 int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
                            const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
-                           float scale, float* sumsq, void* stream) {
+                           float scale, float* sumsq, float* disp_out, void* stream) {
   ADVCHAIN_CHECK_ARG(coef && itab && ftab && (out || sumsq), "tp_interp_fwd: null pointer");
   ADVCHAIN_CHECK_ARG(planes >= 0 && planes < 65536 && C >= 1 && S[0] < 65536, "tp_interp_fwd: bad planes/C");
   BandTables T;
@@ -569,7 +573,7 @@ int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, c
   ADVCHAIN_CHECK_ARG(tp_geom(full.s2).ROWS * T.a[2].g <= kTpMaxLds, "tp_interp_fwd: coefficient row too long");
   dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), (unsigned)full.s0, (unsigned)planes);
   hipLaunchKernelGGL(k_tp_interp_fwd, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
-                     add_identity, scale, sumsq);
+                     add_identity, scale, sumsq, disp_out);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -159,7 +159,7 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
     return cur
 
 
-def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True, sumsq=None):
+def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True, sumsq=None, disp_out=None):
     planes = coef.shape[0] * coef.shape[1]
     out = None
     if want_out:
@@ -168,7 +168,8 @@ def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True,
     _lib.check(_lib.load().advchain_tp_interp_fwd(_ptr(coef), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
                                                   _lib.dims_array(tables.S), _lib.dims_array(tables.g),
                                                   _lib.dims_array(tables.B), planes, C, tables.ndim,
-                                                  int(add_identity), float(scale), _ptr(sumsq), _stream()),
+                                                  int(add_identity), float(scale), _ptr(sumsq), _ptr(disp_out),
+                                                  _stream()),
                "tp_interp_fwd")
     return out
 
@@ -250,7 +251,7 @@ def grid_displacement(grid):
     and then the prediction)."""
     hit = getattr(grid, "_advchain_disp", None)
     if hit is None or hit[2] != grid._version:
-        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version]
+        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0]
         grid._advchain_disp = hit
     return hit
 
@@ -259,7 +260,7 @@ def warp_halo(entry, d):
     """Displacement bound for the backward of a warp from the measured value (one 4-byte read-back per grid);
     negative = exact (see squaring_halo)."""
     if entry[1] is None:
-        entry[1] = float(entry[0].values()[0])
+        entry[1] = float(entry[0].values()[entry[3]])
     est = entry[1]
     if not est == est:
         return 0
@@ -472,20 +473,20 @@ class _DemonsField(torch.autograd.Function):
             while norm / (2.0 ** n) > 0.5:
                 n += 1
         inv = 1.0 / (2.0 ** n)
-        phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv)]
-        # row m of `disp`: max-slots for the displacement of phis[m] (row 0 from its own pass, the others written by
-        # the squaring that produces them) -- the backward reads them back once and sizes every step exactly
-        disp = torch.zeros(n, DISP_SLOTS, device=vel.device, dtype=torch.float32) if ADAPTIVE_HALO else None
-        if disp is not None:
-            _lib.check(_lib.load().advchain_max_displacement(_ptr(phis[0]), _ptr(disp), phis[0].shape[0], d,
-                                                             _lib.dims_array(phis[0].shape[2:]), _stream()),
-                       "max_displacement")
+        # row m of `disp`: max-slots for the displacement of phis[m], written by the kernel that produces it; row n: the
+        # sampling positions `pos`, which bound the returned grid (clipping to [-1,1] and the normalised Gaussian only
+        # shrink a displacement).  Read back once (asynchronously): the backward sizes every step exactly from it.
+        disp = torch.zeros(n + 1, DISP_SLOTS, device=vel.device, dtype=torch.float32) if ADAPTIVE_HALO else None
+        row = (lambda m: None) if disp is None else (lambda m: disp[m])
+        phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))]
         for i in range(n - 1):
-            phis.append(raw_compose_self_fwd(phis[-1], disp_out=None if disp is None else disp[i + 1]))
-        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1)
+            phis.append(raw_compose_self_fwd(phis[-1], disp_out=row(i + 1)))
+        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1, disp_out=row(n))
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
-        ctx.disp = None if disp is None else _Readback(disp.max(dim=1).values)   # one read-back for the whole chain
+        ctx.disp = None if disp is None else _Readback(disp.max(dim=1).values)
+        global _LAST_FIELD_BOUND
+        _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
         return q
@@ -517,8 +518,18 @@ class _DemonsField(torch.autograd.Function):
         return gvel, None, None, None, None
 
 
+_LAST_FIELD_BOUND = None
+
+
 def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
-    return _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq)
+    global _LAST_FIELD_BOUND
+    _LAST_FIELD_BOUND = None
+    q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq)
+    if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
+        rb, idx = _LAST_FIELD_BOUND
+        q._advchain_disp = [rb, None, q._version, idx]
+        _LAST_FIELD_BOUND = None
+    return q
 
 
 class _Consistency(torch.autograd.Function):

@@ -131,10 +131,12 @@ int advchain_affine_theta_bwd(const float* param, const float* cfg_host, float p
  *           adv_morph.py:464, fused with 'basegrid += duv/2^n' (adv_morph.py:111,129-130) when
  *           add_identity != 0, and with torch.norm(duv_interval) (adv_morph.py:160) when
  *           sumsq != NULL (64 partial accumulators: sum(sumsq[0..63]) += sum(interp^2); caller zeroes them).
- * coef (planes, g0,g1,g2) -> out (planes, S0,S1,S2) = identity? + scale * interp.               */
+ * coef (planes, g0,g1,g2) -> out (planes, S0,S1,S2) = identity? + scale * interp.
+ * disp_out (may be NULL): ADVCHAIN_DISP_SLOTS floats, max-accumulates |scale * interp| in voxels, i.e. the displacement
+ * of the field written when add_identity != 0 (see advchain_compose_self_fwd).                          */
 int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
                            const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
-                           float scale, float* sumsq, void* stream);
+                           float scale, float* sumsq, float* disp_out, void* stream);
 /* adjoint along one axis: in (outer, S_axis, inner) -> out (outer, g_axis, inner),
  * out = W_axis^T ((in - in2) * scale); in2 may be NULL.
  * replaces: upsample_{bi,tri}linear backward / conv_transpose backward w.r.t. its input.        */
