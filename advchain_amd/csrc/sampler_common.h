@@ -107,7 +107,8 @@ constexpr int kDispSlots = 4096;
 __device__ __forceinline__ void wave_max_to_slots(float m, float* __restrict__ slots) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  float* p = slots + ((blockIdx.x + blockIdx.y * gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kDispSlots;
+  const unsigned blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* p = slots + (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kDispSlots;
   // fire and forget (no read-before: a dependent load would keep every wave alive for another memory round trip)
   if ((threadIdx.x & 63) == __builtin_ffsll(__builtin_amdgcn_ballot_w64(true)) - 1 && m > 0.f)
     atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(m));
