@@ -324,7 +324,7 @@ __device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v,
 
 // Which voxel a thread of the affine kernels handles.  A wave normally covers a 64-voxel line along x; under rotation
 // that line crosses ~64 |dy/dx| rows of the input and every gather instruction touches up to 64 cache lines (measured
-// at 20 degrees: 3D C=4 forward 103 -> 252 us).  When the line would cross more than 12 rows the wave covers an 8 x 8
+// at 20 degrees: 3D C=4 forward 103 -> 252 us).  When the line would cross more than 7 rows the wave covers an 8 x 8
 // (x, y) patch instead (~11 row segments; 252 -> 162 us); for near-axis-aligned maps the line stays (the patch costs
 // ~15 % there).  Decided per sample from theta, no host involvement.  Launch with affine_grid_blocks().
 constexpr int kPatch = 8;
@@ -336,8 +336,8 @@ __host__ __device__ inline int64_t affine_waves(const Dims& d) {
 static inline int affine_grid_blocks(const Dims& d) { return (int)((affine_waves(d) + kBlock / 64 - 1) / (kBlock / 64)); }
 
 // `slope` = rows (and slices) of the gathered tensor crossed per voxel step along x of the iterated one
-__device__ __forceinline__ int64_t mapped_thread_voxel(float slope, const Dims& d) {
-  const bool patch = 64.f * slope > 12.f && d.s1 >= kPatch && d.s2 >= kPatch;
+__device__ __forceinline__ int64_t mapped_thread_voxel(float slope, const Dims& d, float thr = 7.f) {
+  const bool patch = 64.f * slope > thr && d.s1 >= kPatch && d.s2 >= kPatch;
   const int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (!patch) {
@@ -353,17 +353,17 @@ __device__ __forceinline__ int64_t mapped_thread_voxel(float slope, const Dims& 
 }
 
 template <int DIM>
-__device__ __forceinline__ int64_t affine_thread_voxel(const Theta<DIM>& th, const Dims& d) {
+__device__ __forceinline__ int64_t affine_thread_voxel(const Theta<DIM>& th, const Dims& d, float thr = 7.f) {
   const float den = (float)max(d.s2 - 1, 1);
   float rows = fabsf(th.m[1][0]) * (float)(d.s1 - 1) / den;
   if (DIM == 3) rows += fabsf(th.m[DIM - 1][0]) * (float)(d.s0 - 1) / den;
-  return mapped_thread_voxel(rows, d);
+  return mapped_thread_voxel(rows, d, thr);
 }
 
 template <int DIM, int INTERP, int PAD>
 __global__ void __launch_bounds__(kBlock)
 k_affine_warp_fwd(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, int C,
-                  Dims d) {
+                  Dims d, float thr) {
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
   Theta<DIM> th;
@@ -371,7 +371,7 @@ k_affine_warp_fwd(const float* __restrict__ in, const float* __restrict__ theta,
   for (int r = 0; r < DIM; ++r)
 #pragma unroll
     for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * DIM * (DIM + 1) + r * (DIM + 1) + c];
-  const int64_t v = affine_thread_voxel<DIM>(th, d);
+  const int64_t v = affine_thread_voxel<DIM>(th, d, thr);
   if (v < 0) return;
   float bx, by, bz, gx, gy, gz;
   affine_position<DIM>(th, v, d, bx, by, bz, gx, gy, gz);
@@ -847,13 +847,14 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "affine_warp_fwd: per-sample volume too large");
   dim3 g(affine_grid_blocks(d), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
+  static const float thr = getenv("ADVCHAIN_PATCH_THR") ? (float)atof(getenv("ADVCHAIN_PATCH_THR")) : 7.f;   // tuning knob (break-even measured at ~6 degrees)
   DISPATCH_PAD(padding, {
     if (ndim == 3) {
-      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
-      else hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d, thr);
+      else hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d, thr);
     } else {
-      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
-      else hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d);
+      if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d, thr);
+      else hipLaunchKernelGGL((k_affine_warp_fwd<2, INTERP_NEAREST, PAD>), g, b, 0, st, in, theta, out, (int)C, d, thr);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();
