@@ -24,7 +24,7 @@ template <int DIM, int PAD, int C, bool SELF>
 __global__ void __launch_bounds__(kBlock)
 k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
                const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode,
-               float* __restrict__ disp_out) {
+               float* __restrict__ disp_out, int dbg) {
   extern __shared__ float lds[];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -43,7 +43,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const float* inn = in + (int64_t)n * C * V;
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
   const int rows = C * rd * rh;
-  for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
+  for (int e = threadIdx.x; e < rows * rw4 && !(dbg & 2); e += kBlock) {
     const int q = e % rw4;
     const int r = e / rw4;
     const int ly = r % rh;
@@ -54,39 +54,33 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
     *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
   }
   __syncthreads();
-  // ---- compute: each thread owns quads of 4 consecutive x
-  const int tq = tc.t2 >> 2;                       // quads per tile row
-  const int nquads = tc.t0 * tc.t1 * tq;
+  // ---- compute: lane <-> x (one wave per output row): neighbouring lanes read neighbouring LDS words -- with
+  // 4 consecutive x per thread the taps of a wave sat 4 words apart and every LDS read was a 4-way bank conflict
   const float* gn = SELF ? nullptr : grid + (int64_t)n * DIM * V;
   float* on = out + (int64_t)n * C * V;
   float dmax = 0.f;
-  for (int qi = threadIdx.x; qi < nquads; qi += kBlock) {
-    const int qx = qi % tq;
-    const int r = qi / tq;
-    const int ly = r % tc.t1;
-    const int lz = r / tc.t1;
-    const int sx = x0 + 4 * qx, sy = y0 + ly, sz = z0 + lz;
-    if (sx >= d.s2 || sy >= d.s1 || sz >= d.s0) continue;
-    const int s = (sz * d.s1 + sy) * d.s2 + sx;
-    float g[3][4];
-    if (SELF) {
-      const int lo = ((sz - rz0) * rh + (sy - ry0)) * rw + (sx - rx0);
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) {
-        const float4 v = *reinterpret_cast<const float4*>(lds + a * plane + lo);
-        g[a][0] = v.x; g[a][1] = v.y; g[a][2] = v.z; g[a][3] = v.w;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nrows = tc.t0 * tc.t1;
+  for (int xb = 0; xb < tc.t2; xb += 64) {
+    const int sx = x0 + xb + lane;
+    const bool xin = (xb + lane < tc.t2) && sx < d.s2;
+    for (int r = wave; r < nrows; r += kBlock / 64) {
+      const int ly = r % tc.t1, lz = r / tc.t1;
+      const int sy = y0 + ly, sz = z0 + lz;
+      if (sy >= d.s1 || sz >= d.s0) continue;     // wave-uniform
+      if (!xin) continue;
+      const int s = (sz * d.s1 + sy) * d.s2 + sx;
+      float gx, gy, gz = 0.f;
+      if (SELF) {
+        const int lo = ((sz - rz0) * rh + (sy - ry0)) * rw + (sx - rx0);
+        gx = lds[lo];
+        gy = lds[plane + lo];
+        if (DIM == 3) gz = lds[2 * plane + lo];
+      } else {
+        gx = gn[s];
+        gy = gn[(int64_t)V + s];
+        if (DIM == 3) gz = gn[2 * (int64_t)V + s];
       }
-    } else {
-#pragma unroll
-      for (int a = 0; a < DIM; ++a) {
-        const float4 v = *reinterpret_cast<const float4*>(gn + (int64_t)a * V + s);
-        g[a][0] = v.x; g[a][1] = v.y; g[a][2] = v.z; g[a][3] = v.w;
-      }
-    }
-    float res[C][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float gx = g[0][k], gy = g[1][k], gz = DIM == 3 ? g[DIM - 1][k] : 0.f;
       if (clamp_grid) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
       Taps<DIM, PAD> t;
       t.build(gx, gy, gz, d);
@@ -96,7 +90,8 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
       const int cz0 = DIM == 3 ? max(t.z.i0, 0) : 0, cz1 = DIM == 3 ? min(t.z.i0 + 1, d.s0 - 1) : 0;
       const bool staged = (cx0 >= rx0) && (cx1 < rx1) && (cy0 >= ry0) && (cy1 < ry1) && (cz0 >= rz0) && (cz1 < rz1) &&
                           (cx0 <= cx1) && (cy0 <= cy1) && (cz0 <= cz1);
-      if (staged) {
+      float res[C];
+      if (staged && !(dbg & 1)) {
         const int ox[2] = {cx0 - rx0, cx1 - rx0};
         const int oy[2] = {(cy0 - ry0) * rw, (cy1 - ry0) * rw};
         const int oz[2] = {(cz0 - rz0) * rh * rw, (cz1 - rz0) * rh * rw};
@@ -117,31 +112,24 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
               for (int cx = 0; cx < 2; ++cx) acc += p[oz[cz] + oy[cy] + ox[cx]] * w[(cz * 2 + cy) * 2 + cx];
-          res[c][k] = acc;
+          res[c] = acc;
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) res[c][k] = sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
+        for (int c = 0; c < C; ++c) res[c] = (dbg & 1) ? gx : sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
       }
-    }
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float4 o = make_float4(res[c][0], res[c][1], res[c][2], res[c][3]);
-      if (SELF && final_mode == 1) {
-        // (sample - phi0) + identity   (adv_morph.py:143,176 + 474,483)
-        const float4 p0 = *reinterpret_cast<const float4*>(phi0 + ((int64_t)n * DIM + c) * V + s);
-        float id[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          id[k] = c == 0 ? lin_coord(sx + k, d.s2) : (c == 1 ? lin_coord(sy, d.s1) : lin_coord(sz, d.s0));
-        o = make_float4((o.x - p0.x) + id[0], (o.y - p0.y) + id[1], (o.z - p0.z) + id[2], (o.w - p0.w) + id[3]);
-      }
-      *reinterpret_cast<float4*>(on + (int64_t)c * V + s) = o;
-      if (SELF && disp_out) {   // displacement of the composed field (the next squaring's input), for its backward
-        const int Sa = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
-        const int sa = c == 0 ? sx : (c == 1 ? sy : sz);
-        dmax = fmaxf(fmaxf(dmax, voxel_displacement(o.x, Sa, sa)), voxel_displacement(o.y, Sa, sa + (c == 0 ? 1 : 0)));
-        dmax = fmaxf(fmaxf(dmax, voxel_displacement(o.z, Sa, sa + (c == 0 ? 2 : 0))), voxel_displacement(o.w, Sa, sa + (c == 0 ? 3 : 0)));
+      for (int c = 0; c < C; ++c) {
+        float o = res[c];
+        if (SELF && final_mode == 1) {
+          // (sample - phi0) + identity   (adv_morph.py:143,176 + 474,483)
+          const float p0 = phi0[((int64_t)n * DIM + c) * V + s];
+          o = (o - p0) + (c == 0 ? lin_coord(sx, d.s2) : (c == 1 ? lin_coord(sy, d.s1) : lin_coord(sz, d.s0)));
+        }
+        on[(int64_t)c * V + s] = o;
+        if (SELF && disp_out) {   // displacement of the composed field (the next squaring's input), for its backward
+          dmax = fmaxf(dmax, voxel_displacement(o, c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0), c == 0 ? sx : (c == 1 ? sy : sz)));
+        }
       }
     }
   }
@@ -187,7 +175,8 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
 template <int DIM, int PAD, bool SELF>
 static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const float* in, const float* grid, float* out,
                             const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode, float* disp_out) {
-#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out)
+  static const int dbg = getenv("ADVCHAIN_GTDBG") ? atoi(getenv("ADVCHAIN_GTDBG")) : 0;  // tuning knob
+#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out, dbg)
   switch (C) {
     case 1: if constexpr (!SELF) { LAUNCH(1); return true; } return false;
     case 2: if constexpr (!SELF || DIM == 2) { LAUNCH(2); return true; } return false;
