@@ -133,7 +133,7 @@ def squaring_halo(disp, d):
     if disp < 0.999:
         return -1
     if d == 3:
-        return 2                 # measured: wider 3D halos cost more than the overflow list saves
+        return 2 if disp < 1.999 else (3 if disp < 2.999 else 4)
     if disp < 1.999:
         return -2
     if disp < 3.999:
@@ -265,7 +265,7 @@ def warp_halo(entry, d):
     if not est == est:
         return 0
     if d == 3:
-        return -1 if est < 0.999 else 2
+        return -1 if est < 0.999 else (2 if est < 1.999 else (3 if est < 2.999 else 4))
     if est < 1.999:
         return -2
     if est < 3.999:
