@@ -95,6 +95,12 @@ class AdvBias(AdvTransformBase):
 
     def _build_tables(self):
         """Per-axis (image_size x n_control_points) map = linear-upsample o B-spline-synthesis-and-crop."""
+        key = ("bias", self._dim, tuple(int(c) for c in self.cp_grid[2:]), tuple(int(s) for s in self._stride), int(self.order),
+               tuple(int(c) for c in self._crop_start), tuple(int(c) for c in self._crop_end),
+               tuple(int(s) for s in self._image_size))
+        return bands.cached_tables(key, self.device, self._build_tables_uncached)
+
+    def _build_tables_uncached(self):
         variant = '2d' if self._dim == 2 else '3d'
         mats, lows = [], []
         for a in range(self._dim):

@@ -295,7 +295,7 @@ class ComposeAdversarialTransformSolver(object):
                 if self.debug:
                     print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
                 self.last_inner_dist = value.detach()
-                if torch.isnan(value) or torch.isinf(value):
+                if not bool(torch.isfinite(value)):     # NaN/inf guard (adv_compose_solver.py:343): one read-back, not two
                     dist = 0
                 else:
                     self._backward_to_transforms(dist, optimize_flags)

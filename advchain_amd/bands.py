@@ -118,7 +118,28 @@ class BandTables(object):
         return self.S[3 - self.ndim:]
 
 
+_TABLE_CACHE = {}
+
+
+def cached_tables(key, device, build):
+    """Band tables are a pure function of the geometry: build (and upload) them once per (geometry, device) -- the
+    transforms re-initialise their parameters on every solver call, and each upload is a synchronous host-to-device
+    copy that drains the launch queue."""
+    k = (key, str(device))
+    t = _TABLE_CACHE.get(k)
+    if t is None:
+        if len(_TABLE_CACHE) > 64:
+            _TABLE_CACHE.clear()
+        t = _TABLE_CACHE[k] = build()
+    return t
+
+
 def upsample_tables(low_dims, full_dims, device, scale_factors=None):
+    key = ("upsample", tuple(low_dims), tuple(full_dims), None if scale_factors is None else tuple(scale_factors))
+    return cached_tables(key, device, lambda: _upsample_tables(low_dims, full_dims, device, scale_factors))
+
+
+def _upsample_tables(low_dims, full_dims, device, scale_factors=None):
     mats = []
     for a, (l, f) in enumerate(zip(low_dims, full_dims)):
         sf = None if scale_factors is None else scale_factors[a]

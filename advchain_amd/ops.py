@@ -532,6 +532,21 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     return q
 
 
+_COEF_CACHE = {}
+
+
+def _coef_vector(coef, device):
+    # the normalisers are constants of (shape, weights): upload once -- a host-to-device copy per loss evaluation is a
+    # synchronous hipMemcpy that drains the launch queue
+    key = (tuple(coef), str(device))
+    v = _COEF_CACHE.get(key)
+    if v is None:
+        if len(_COEF_CACHE) > 256:
+            _COEF_CACHE.clear()
+        v = _COEF_CACHE[key] = torch.tensor(coef, device=device, dtype=torch.float32)
+    return v
+
+
 class _Consistency(torch.autograd.Function):
     """c_mse * S0 + c_a * SA + c_b * SB  with  S0 = sum((P m - T m)^2), SA/SB = masked edge energies
     (advchain/common/loss.py:55-79,102-220).  Differentiable w.r.t. the prediction logits only."""
@@ -559,8 +574,7 @@ class _Consistency(torch.autograd.Function):
         ctx.cfg = (coef, mch)
         sums = slots.sum(dim=1)
         ctx.mark_non_differentiable(sums)
-        cvec = torch.tensor(coef, device=pred.device, dtype=torch.float32)
-        return torch.dot(sums, cvec), sums
+        return torch.dot(sums, _coef_vector(coef, pred.device)), sums
 
     @staticmethod
     def backward(ctx, gloss, _gsums):
