@@ -87,8 +87,11 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
   const int g2 = A2.g;
   const int s0 = A0.start[i0];
   const float* w0 = A0.w + i0 * A0.B;
-  for (int base = i1_begin; base < i1_end; base += gm.ROWS) {
-    for (int e = threadIdx.x; e < gm.ROWS * g2; e += kBlock) {
+  // rows blended per phase: as many as the LDS buffer holds (with 4 rows per phase a workgroup paid two barriers and a
+  // dependent start[] -> coef[] load chain per 4 rows: 52 us for a 50 MB write at 4x3x128x128x64)
+  const int RPP = max(gm.ROWS, min(kTpChunk, kTpMaxLds / max(g2, 1)) / gm.ROWS * gm.ROWS);
+  for (int base = i1_begin; base < i1_end; base += RPP) {
+    for (int e = threadIdx.x; e < RPP * g2; e += kBlock) {
       const int r = e / g2, k = e - r * g2;
       const int i1 = base + r;
       float acc = 0.f;
@@ -104,13 +107,20 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
       lds[e] = acc;
     }
     __syncthreads();
-    const int i1 = base + ry;
-    if (i1 < i1_end) {
-      for (int x = tx; x < full.s2; x += gm.XT) {
-        const int s2 = A2.start[x];
-        const float* w2 = A2.w + x * A2.B;
+    // x outer: the band of an output column (start, <= 8 weights) is loaded once and kept in registers for all rows
+    // (per-row table loads were a dependent global-load chain in the inner loop)
+    for (int x = tx; x < full.s2; x += gm.XT) {
+      const int s2 = A2.start[x];
+      float w2[kBandMax];
+#pragma unroll
+      for (int c = 0; c < kBandMax; ++c) w2[c] = c < A2.B ? A2.w[x * A2.B + c] : 0.f;
+      for (int r = ry; r < RPP; r += gm.ROWS) {
+        const int i1 = base + r;
+        if (i1 >= i1_end) break;
         float val = 0.f;
-        for (int c = 0; c < A2.B; ++c) val += w2[c] * lds[ry * g2 + s2 + c];
+#pragma unroll
+        for (int c = 0; c < kBandMax; ++c)
+          if (c < A2.B) val += w2[c] * lds[r * g2 + s2 + c];
         epi(i1, x, val);
       }
     }
