@@ -411,7 +411,7 @@ k_gauss_axis(const float* __restrict__ in, float* __restrict__ out, const float*
 template <int PRE, int POST, int AXIS>
 __global__ void __launch_bounds__(kBlock)
 k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, int64_t total4,
-                Dims d, int C, GaussW gw, float scale) {
+                Dims d, int C, GaussW gw, float scale, int row_in_wave) {
   const int64_t t4 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t4 >= total4) return;
   const int64_t t = t4 * 4;
@@ -433,7 +433,27 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
     return x;
   };
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (AXIS == 2) {
+  if (AXIS == 2 && row_in_wave) {
+    // a row (S2/4 lanes) never straddles a wave and no lane is idle: the neighbouring quads come from the neighbouring
+    // lanes (whole-wave DPP shifts) instead of two more 16-byte loads and eight more prologue evaluations per lane
+    const float4 q = *reinterpret_cast<const float4*>(in + t);
+    float win[12];
+    win[4] = pre(q.x, idx[0], idx[1], idx[2]);
+    win[5] = pre(q.y, idx[0], idx[1], idx[2] + 1);
+    win[6] = pre(q.z, idx[0], idx[1], idx[2] + 2);
+    win[7] = pre(q.w, idx[0], idx[1], idx[2] + 3);
+    const bool first = idx[2] == 0, last = idx[2] + 4 >= d.s2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float pv = lane_prev_f(win[4 + k]), nx = lane_next_f(win[4 + k]);
+      win[k] = first ? 0.f : pv;
+      win[8 + k] = last ? 0.f : nx;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[o] += gw.w[k] * win[o + k];
+  } else if (AXIS == 2) {
     float win[12];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -672,12 +692,13 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
   const bool v4 = (d.s2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                                        reinterpret_cast<uintptr_t>(aux)) & 15) == 0;
   dim3 grid(advchain_blocks(v4 ? total / 4 : total, kBlock));
+  const int riw = (v4 && d.s2 >= 4 && 64 % (d.s2 / 4) == 0 && (total / 4) % 64 == 0) ? 1 : 0;   // x rows aligned to waves
 #define GA(PRE, POST)                                                                                                     \
   do {                                                                                                                    \
     if (!v4) hipLaunchKernelGGL((k_gauss_axis<PRE, POST>), grid, blk, 0, st, in, out, aux, total, d, (int)C, axis, gw, scale); \
-    else if (axis == 2) hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 2>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale); \
-    else if (axis == 1) hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 1>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale); \
-    else hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 0>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale); \
+    else if (axis == 2) hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 2>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale, riw); \
+    else if (axis == 1) hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 1>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale, 0); \
+    else hipLaunchKernelGGL((k_gauss_axis_v4<PRE, POST, 0>), grid, blk, 0, st, in, out, aux, total / 4, d, (int)C, gw, scale, 0); \
   } while (0)
   switch (pre * 3 + post) {
     case 0: GA(0, 0); break;
