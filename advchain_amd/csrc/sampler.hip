@@ -570,14 +570,15 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
       }
       const int xl = (int)ceilf(lo), xh = (int)floorf(hi);
       for (int vx = xl; vx <= xh; ++vx) {
+        // the sample's position with the forward's arithmetic; its weight on voxel u in tent form
+        // max(0, 1 - |x - u|) (equal to the corner weight (i0 + 1) - x or x - i0 whichever cell x is in, so no floor,
+        // no validity flags: a third of the instructions of a full tap build)
         float bx, by, bz, gx, gy, gz;
         affine_position_xyz<DIM>(th, vx, vy, vz, d, bx, by, bz, gx, gy, gz);
-        Taps<DIM, PAD_ZEROS> tp;
-        tp.build(gx, gy, gz, d);
-        const int dx = ux - tp.x.i0, dy = uy - tp.y.i0, dz = DIM == 3 ? uz - tp.z.i0 : 0;
-        if ((unsigned)dx > 1u || (unsigned)dy > 1u || (unsigned)dz > 1u) continue;
-        float w = tp.wx(dx) * tp.wy(dy);
-        if (DIM == 3) w *= tp.wz(dz);
+        const float px = ((gx + 1.f) * 0.5f) * (float)(d.s2 - 1), py = ((gy + 1.f) * 0.5f) * (float)(d.s1 - 1);
+        float w = fmaxf(0.f, 1.f - fabsf(px - (float)ux)) * fmaxf(0.f, 1.f - fabsf(py - (float)uy));
+        if (DIM == 3) w *= fmaxf(0.f, 1.f - fabsf(((gz + 1.f) * 0.5f) * (float)(d.s0 - 1) - (float)uz));
+        if (!(w > 0.f)) continue;
         const int v = (vz * d.s1 + vy) * d.s2 + vx;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
