@@ -100,8 +100,7 @@ template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 __global__ void __launch_bounds__(NT)
 k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                  float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int wide, int flags,
-                 float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap,
-                 int dbg) {
+                 float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap) {
   using G = GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>;
   constexpr int RY = G::RY, ROWS = G::ROWS, NW = G::NW, RPW = G::RPW;
   constexpr int OG = DIM, OI = DIM + C;   // first grad_out / input channel in LDS
@@ -134,7 +133,7 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
     const int sy = ry0 + r % RY, sz = rz0 + r / RY;
     const int x = rx0 + 4 * q;
     float o[DIM][4], g[C][4], vin[G::STAGE_IN ? C : 1][4];
-    const bool inside = !(dbg & 8) && sy >= 0 && sy < d.s1 && sz >= 0 && sz < d.s0 && x >= 0 && x < d.s2;
+    const bool inside = sy >= 0 && sy < d.s1 && sz >= 0 && sz < d.s0 && x >= 0 && x < d.s2;
     if (inside) {
       const int s = (sz * d.s1 + sy) * d.s2 + x;
 #pragma unroll
@@ -203,7 +202,7 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
 
     // ---- phase A: coordinate-path gradient of the sample at this output position
     float gg[3] = {0.f, 0.f, 0.f};
-    if ((SELF || GG) && xowned && !(dbg & 1)) {
+    if ((SELF || GG) && xowned) {
       const int sc[3] = {sx, uy, uz};
       float w1[3] = {0.f, 0.f, 0.f}, mult[3] = {0.f, 0.f, 0.f};
       int i0[3] = {0, 0, 0};
@@ -296,7 +295,6 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int k = 0; k < 2 * H + 1; ++k) acc[c][k] = 0.f;
-    if (!(dbg & 4))
 #pragma unroll
     for (int dz = (DIM == 3 ? -H : 0); dz <= (DIM == 3 ? H : 0); ++dz)
 #pragma unroll
@@ -439,7 +437,6 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
   int2* list = reinterpret_cast<int2*>(ws + 4);
   const int64_t cap64 = N * d.voxels();
   const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
-  static const int dbg = getenv("ADVCHAIN_GDBG") ? atoi(getenv("ADVCHAIN_GDBG")) : 0;  // tuning knob
   const bool border = padding == PAD_BORDER;
   const int flags = ((border || clamp_grid) ? kClip : 0) | (border ? kBorder : 0) | (clamp_grid ? kClampGrid : 0);
   auto kern = k_adjoint_gather<DIM, C, H, SELF, GG, TZ, TY, NT>;
@@ -452,12 +449,12 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
     // the caller guarantees the displacement bound (measured): no sample can be irregular, so there is no overflow
     // list to reset or drain and the whole step is this one launch
     hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid,
-                       d, n1, n2, wide, flags, (float*)nullptr, (int*)nullptr, (int2*)nullptr, 0, dbg);
+                       d, n1, n2, wide, flags, (float*)nullptr, (int*)nullptr, (int2*)nullptr, 0);
     return;
   }
   hipLaunchKernelGGL(k_gather_prepare, dim3(1), dim3(1), 0, st, ws, chain);
   hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
-                     n1, n2, wide, flags, amax_out, cnt, list, cap, dbg);
+                     n1, n2, wide, flags, amax_out, cnt, list, cap);
   if (border) hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_BORDER>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,
                                  clamp_grid, cnt, list, cap, amax_out);
   else hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_ZEROS>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,

@@ -24,7 +24,7 @@ template <int DIM, int PAD, int C, bool SELF>
 __global__ void __launch_bounds__(kBlock)
 k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
                const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode,
-               float* __restrict__ disp_out, int dbg) {
+               float* __restrict__ disp_out) {
   extern __shared__ float lds[];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -43,7 +43,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const float* inn = in + (int64_t)n * C * V;
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
   const int rows = C * rd * rh;
-  for (int e = threadIdx.x; e < rows * rw4 && !(dbg & 2); e += kBlock) {
+  for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
     const int q = e % rw4;
     const int r = e / rw4;
     const int ly = r % rh;
@@ -91,7 +91,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
       const bool staged = (cx0 >= rx0) && (cx1 < rx1) && (cy0 >= ry0) && (cy1 < ry1) && (cz0 >= rz0) && (cz1 < rz1) &&
                           (cx0 <= cx1) && (cy0 <= cy1) && (cz0 <= cz1);
       float res[C];
-      if (staged && !(dbg & 1)) {
+      if (staged) {
         const int ox[2] = {cx0 - rx0, cx1 - rx0};
         const int oy[2] = {(cy0 - ry0) * rw, (cy1 - ry0) * rw};
         const int oz[2] = {(cz0 - rz0) * rh * rw, (cz1 - rz0) * rh * rw};
@@ -116,7 +116,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) res[c] = (dbg & 1) ? gx : sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
+        for (int c = 0; c < C; ++c) res[c] = sample_linear<DIM, PAD>(inn + (int64_t)c * V, t, d);
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -175,8 +175,7 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
 template <int DIM, int PAD, bool SELF>
 static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const float* in, const float* grid, float* out,
                             const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode, float* disp_out) {
-  static const int dbg = getenv("ADVCHAIN_GTDBG") ? atoi(getenv("ADVCHAIN_GTDBG")) : 0;  // tuning knob
-#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out, dbg)
+#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out)
   switch (C) {
     case 1: if constexpr (!SELF) { LAUNCH(1); return true; } return false;
     case 2: if constexpr (!SELF || DIM == 2) { LAUNCH(2); return true; } return false;

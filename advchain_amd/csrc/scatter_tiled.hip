@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(NT)
 k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                float* __restrict__ gin, float* __restrict__ ggrid, Dims d, TileCfg tc, int clamp_grid,
                const float* __restrict__ absmax_in, float* __restrict__ absmax_out, int* __restrict__ ovf_count,
-               int2* __restrict__ ovf_list, int ovf_cap, int dbg) {
+               int2* __restrict__ ovf_list, int ovf_cap) {
   extern __shared__ long long acc[];
   constexpr int NW = NT / 64;
   const int V = (int)d.voxels();
@@ -194,7 +194,7 @@ k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, con
                 const int lo = ((uz - z0) * tc.t1 + (uy - y0)) * tc.t2 + (ux - x0);
                 const float w = t.w(cz, cy, cx) * scale;
 #pragma unroll
-                for (int c = 0; c < C; ++c) if (!(dbg & 1)) lds_add_fixed(acc + c * tvox + lo, w * cur.go[c]);
+                for (int c = 0; c < C; ++c) lds_add_fixed(acc + c * tvox + lo, w * cur.go[c]);
               } else if (owned && !deposit_handled(sz, sy, sx, uz, uy, ux, tc)) {
                 overflow = true;
               }
@@ -202,7 +202,7 @@ k_scatter_rows(const float* __restrict__ gout, const float* __restrict__ in, con
           }
     }
     if (owned) {
-      if ((SELF || NEED_GGRID) && !(dbg & 2)) {
+      if (SELF || NEED_GGRID) {
         float ax = 0.f, ay = 0.f, az = 0.f, dummy = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c)
@@ -343,7 +343,6 @@ template <int DIM, int PAD, int C>
 static void launch_rows(bool self, bool need_ggrid, dim3 g, size_t lds, hipStream_t st, const float* gout,
                         const float* in, const float* grid, float* gin, float* ggrid, Dims d, TileCfg tc,
                         int clamp_grid, const float* amax_in, float* amax_out, int* cnt, int2* list, int cap) {
-  static const int dbg = getenv("ADVCHAIN_DBG") ? atoi(getenv("ADVCHAIN_DBG")) : 0;  // tuning knob
   // > 48 KiB of LDS leaves <= 3 workgroups per CU: use 8 waves per workgroup to keep the CU busy
   const bool big = lds > 40960, huge = lds > 65536;
 #define LAUNCH(SELF_, GG_, NT_)                                                                                      \
@@ -351,7 +350,7 @@ static void launch_rows(bool self, bool need_ggrid, dim3 g, size_t lds, hipStrea
     auto kern = k_scatter_rows<DIM, PAD, C, SELF_, GG_, NT_>;                                                        \
     if (huge) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kern, g, dim3(NT_), lds, st, gout, in, grid, gin, ggrid, d, tc, clamp_grid, amax_in, amax_out, \
-                       cnt, list, cap, dbg);                                                                         \
+                       cnt, list, cap);                                                                              \
   } while (0)
   if (self) {
     if constexpr (C == DIM) { if (huge) LAUNCH(true, false, 1024); else if (big) LAUNCH(true, false, 512); else LAUNCH(true, false, 256); }
