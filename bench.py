@@ -287,7 +287,7 @@ def cpu_baseline(wl, name):
     torch.set_num_threads(cores)
     sd = len(wl["dims"])
     if sd == 2:
-        batch, n_iter = min(wl["batch"], 8), wl["n_iter"]
+        batch, n_iter = min(wl["batch"], 32), wl["n_iter"]   # ~10 s of CPU work at cfg-2
     else:
         batch, n_iter = 1, 1
     cls = {"noise": O.OracleNoise, "bias": O.OracleBias, "morph": O.OracleMorph, "affine": O.OracleAffine}
