@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import Fixture, make_model, maxdiff
+from tests.helpers import Fixture, make_model, maxdiff, rand, smooth_data
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -243,3 +243,65 @@ def test_third_party_transform_plugin():
     data = torch.rand(*ds, device=DEV)
     loss = solver.adversarial_training(data=data, model=model, n_iter=2)
     assert torch.isfinite(loss) and float(t.param.abs().max()) > 0
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+def test_padding_modes_and_get_adv_data(sd):
+    """'lowest' / numeric image padding of AdvMorph and AdvAffine (adv_morph.py:542-557, adv_affine.py:299-313), label
+    warping with nearest interpolation, and the data-generation entry get_adv_data (adv_compose_solver.py:435-463,
+    n_iter=0: no optimisation) against the oracle with the same parameters.  The reference subtracts the per-sample
+    minimum as an (N, 1) tensor from (N, C, ...) data, which only broadcasts for N == 1: 'lowest' is exercised at N = 1
+    and must raise, like the reference, at N = 2."""
+    from oracle import advchain_oracle as O
+    from advchain_amd.augmentor import AdvAffine, AdvMorph, ComposeAdversarialTransformSolver
+    dims = (24, 32) if sd == 2 else (8, 12, 16)
+
+    def cfgs(N):
+        ds = [N, 1] + list(dims)
+        mcfg = dict(epsilon=1.5, data_size=ds, vector_size=[max(2, s // 8) for s in dims])
+        acfg = (dict(rot=30 / 180., scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=ds) if sd == 2 else
+                dict(rot_x=0.05, rot_y=0.05, rot_z=0.05, scale_x=0.1, scale_y=0.1, scale_z=0.1, shift_x=0.1, shift_y=0.1,
+                     shift_z=0.1, data_size=ds))
+        return mcfg, acfg
+
+    for pad, N in (("lowest", 1), (0.25, 2)):
+        mcfg, acfg = cfgs(N)
+        data = smooth_data(N, 1, dims, 5) + 0.3          # minimum well above 0: 'lowest' differs from 'zeros'
+        pm = O.unit_normalize(rand((N, sd) + tuple(mcfg["vector_size"]), 6))
+        pa = 0.7 * rand((N, 5 if sd == 2 else 9), 7)
+        om, oa = O.OracleMorph(sd, mcfg, image_padding_mode=pad), O.OracleAffine(sd, acfg, image_padding_mode=pad)
+        gm = AdvMorph(spatial_dims=sd, config_dict=mcfg, image_padding_mode=pad, device=DEV)
+        ga = AdvAffine(spatial_dims=sd, config_dict=acfg, image_padding_mode=pad, device=DEV)
+        for o, g, p in ((om, gm, pm), (oa, ga, pa)):
+            o.init_parameters(); g.init_parameters()
+            o.param = p.clone(); g.set_parameters(p.to(DEV))
+            o.train(); g.train()      # the training-mode paths apply epsilon * param, as in the solver's inner loop
+            for interp in ("bilinear", "nearest"):
+                ref = o.forward(data, interp=interp)
+                out = g.forward(data.to(DEV), interp=interp).cpu()
+                if interp == "nearest":   # a sample on a rounding tie may pick the other neighbour
+                    assert float((out - ref).abs().gt(1e-5).float().mean()) < 5e-3, (pad, type(g).__name__)
+                else:
+                    assert maxdiff(out, ref) < 5e-5, (pad, type(g).__name__)
+            assert maxdiff(g.backward(data.to(DEV), interp="bilinear").cpu(), o.backward(data, interp="bilinear")) < 5e-5
+    # the reference's (N, 1) broadcast: an error for N = 2 (unless a spatial size happens to equal N)
+    mcfg, acfg = cfgs(2)
+    gm = AdvMorph(spatial_dims=sd, config_dict=mcfg, image_padding_mode="lowest", device=DEV)
+    gm.init_parameters()
+    with pytest.raises(RuntimeError):
+        gm.forward(torch.rand(2, 1, *dims, device=DEV))
+    # data generation: warped image and correspondingly warped prediction with freshly drawn parameters, no optimisation
+    model = make_model(sd)
+    data = smooth_data(2, 1, dims, 5)
+    gm = AdvMorph(spatial_dims=sd, config_dict=mcfg, device=DEV)
+    ga = AdvAffine(spatial_dims=sd, config_dict=acfg, device=DEV)
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=[gm, ga])
+    torch.manual_seed(3)
+    adv, lab = solver.get_adv_data(data.to(DEV), model.to(DEV), n_iter=0)
+    om, oa = O.OracleMorph(sd, mcfg), O.OracleAffine(sd, acfg)
+    om.init_parameters(); oa.init_parameters()
+    om.param, oa.param = gm.param.detach().cpu(), ga.param.detach().cpu()
+    ref_adv = oa.forward(om.forward(data))
+    ref_lab = oa.forward(om.forward(model.cpu()(data)))
+    assert maxdiff(adv.cpu(), ref_adv) < 5e-5
+    assert maxdiff(lab.cpu(), ref_lab.detach()) < 1e-4
