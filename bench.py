@@ -251,23 +251,29 @@ def grid_sample3d_roofline(device, reps=20):
     for _ in range(3):
         out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
         ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
+    # average launch duration: `reps` launches back to back between two events on the launch stream (one event pair
+    # per single launch would add the ~5 us launch gap of an empty queue to a 25-60 us kernel)
+    from advchain_amd import _lib
+    lib = _lib.load()
+    gin = torch.empty_like(x)
+    ggrid = torch.empty_like(q)
+    out = torch.empty_like(x)
+    ws = ops._scatter_workspace(4, dims, device)
+    da = _lib.dims_array(dims)
     ef = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tf = tb = 0.0
+    torch.cuda.synchronize()
+    ef[0].record()
     for _ in range(reps):
-        gin = torch.empty_like(x)
-        ggrid = torch.empty_like(q)
-        ws = ops._scatter_workspace(4, dims, device)
-        ef[0].record()
-        out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
-        ef[1].record()
-        from advchain_amd import _lib
-        _lib.check(_lib.load().advchain_grid_sample_bwd(ops._ptr(go), ops._ptr(x), ops._ptr(q), ops._ptr(gin),
-                                                        ops._ptr(ggrid), ops._ptr(ws), 4, 1, 3, _lib.dims_array(dims),
-                                                        _lib.dims_array(dims), 0, 0, 1, halo, ops._stream()), "bwd")
-        ef[2].record()
-        torch.cuda.synchronize()
-        tf += ef[0].elapsed_time(ef[1]) * 1e-3
-        tb += ef[1].elapsed_time(ef[2]) * 1e-3
+        _lib.check(lib.advchain_grid_sample_fwd(ops._ptr(x), ops._ptr(q), ops._ptr(out), 4, 1, 3, da, da, 0, 0, 1,
+                                                ops._stream()), "fwd")
+    ef[1].record()
+    for _ in range(reps):
+        _lib.check(lib.advchain_grid_sample_bwd(ops._ptr(go), ops._ptr(x), ops._ptr(q), ops._ptr(gin), ops._ptr(ggrid),
+                                                ops._ptr(ws), 4, 1, 3, da, da, 0, 0, 1, halo, ops._stream()), "bwd")
+    ef[2].record()
+    torch.cuda.synchronize()
+    tf = ef[0].elapsed_time(ef[1]) * 1e-3
+    tb = ef[1].elapsed_time(ef[2]) * 1e-3
     tf, tb = tf / reps, tb / reps
     nv = 4 * 128 * 128 * 64
     bf, bb = 20 * nv, 36 * nv
