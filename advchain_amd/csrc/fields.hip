@@ -506,6 +506,44 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small planes (the low-resolution velocity grids: 16 x 16, 8 x 8 x 32 ...): all axes in ONE launch, one workgroup
+// per plane, ping-pong in LDS.  The per-axis launches above take 5-16 us each on such planes (a few dozen
+// workgroups, nine dependent loads per thread): 2-3 launches per field and direction, ~60 per solver call.
+// Same tap order and zero padding as the per-axis kernels.  pre: 0 | 1 (x * scale); no post.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGaussSmallMax = 4096;   // voxels per plane: 2 x 16 KiB of LDS
+
+__global__ void __launch_bounds__(kBlock)
+k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int ndim, GaussW gw, float scale) {
+  __shared__ float buf[2][kGaussSmallMax];
+  const int V = (int)d.voxels();
+  const float* src = in + (int64_t)blockIdx.x * V;
+  for (int i = threadIdx.x; i < V; i += kBlock) buf[0][i] = src[i] * scale;
+  __syncthreads();
+  const int S[3] = {d.s0, d.s1, d.s2};
+  const int stride[3] = {d.s1 * d.s2, d.s2, 1};
+  int cur = 0;
+  for (int pass = 0; pass < ndim; ++pass) {
+    const int axis = 2 - pass;              // innermost first, like advchain_gauss_axis is called
+    const int Sa = S[axis], st = stride[axis];
+    for (int i = threadIdx.x; i < V; i += kBlock) {
+      const int ia = (i / st) % Sa;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = -4; k <= 4; ++k) {
+        const int j = ia + k;
+        if (j >= 0 && j < Sa) acc += gw.w[k + 4] * buf[cur][i + k * st];
+      }
+      buf[cur ^ 1][i] = acc;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* dst = out + (int64_t)blockIdx.x * V;
+  for (int i = threadIdx.x; i < V; i += kBlock) dst[i] = buf[cur][i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // streaming elementwise
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -712,6 +750,24 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
     default: GA(2, 2); break;
   }
 #undef GA
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// All axes of a small plane in one launch (planes of at most 4096 voxels); pre = 0 | 1, no epilogue.
+int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                         const float* weights9, int pre, float scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && in != out && weights9, "gauss_small: null/aliased pointer");
+  ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_small: bad dims");
+  ADVCHAIN_CHECK_ARG(pre == 0 || pre == 1, "gauss_small: pre must be 0 or 1");
+  const Dims d = fmake_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() <= kGaussSmallMax, "gauss_small: plane larger than 4096 voxels");
+  ADVCHAIN_CHECK_ARG(planes >= 0 && planes < (1ll << 31), "gauss_small: bad plane count");
+  if (planes == 0 || d.voxels() == 0) return ADVCHAIN_OK;
+  GaussW gw;
+  for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
+  hipLaunchKernelGGL(k_gauss_small, dim3((unsigned)planes), dim3(kBlock), 0, (hipStream_t)stream, in, out, d, ndim, gw,
+                     pre == 1 ? scale : 1.f);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

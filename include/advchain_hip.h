@@ -170,6 +170,11 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
                         const int64_t* dims, int axis, const float* weights9_host, int pre, int post, float scale,
                         void* stream);
 
+/* all axes of the same Gaussian in ONE launch for small planes (<= 4096 voxels: the low-resolution velocity grids,
+ * adv_morph.py:462-463); pre = 0 | 1 (x * scale), no epilogue; same arithmetic as the per-axis calls.              */
+int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                         const float* weights9_host, int pre, float scale, void* stream);
+
 /* ---- streaming / per-sample normalisation ----------------------------------------------
  * replaces: data + eps*param adv_noise.py:81-84 (x may be NULL: out = a*y).                     */
 int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n, void* stream);

@@ -150,6 +150,27 @@ def test_compose_self(dims, scatter_path):
     assert maxdiff(fin.cpu(), (ref.detach() - phi0) + O.identity_grid(2, dims)) < TOL
 
 
+@pytest.mark.parametrize("dims", [(16, 16), (12, 20), (8, 8, 32), (5, 7, 9)])
+def test_gauss_small_planes_match_the_per_axis_passes(dims):
+    """advchain_gauss_small (all axes in one launch, planes <= 4096 voxels) against the per-axis kernels and the
+    oracle's 9^d Gaussian (adv_morph.py:377-452)."""
+    from oracle import advchain_oracle as O
+    from advchain_amd import _lib
+    ops = _ops()
+    d = len(dims)
+    x = rand((3, d) + dims, 61)
+    fused = ops.raw_gauss(x.to(DEV), d, pre=1, scale=1.5)              # small plane: the fused kernel
+    lib = _lib.load()
+    cur = x.to(DEV)
+    for i, ax in enumerate([2, 1, 0][:d]):                              # the per-axis entry, explicitly
+        out = torch.empty_like(cur)
+        _lib.check(lib.advchain_gauss_axis(ops._ptr(cur), ops._ptr(out), None, 3 * d, d, d, _lib.dims_array(dims), ax,
+                                           ops._GAUSS9, 1 if i == 0 else 0, 0, 1.5 if i == 0 else 1.0, ops._stream()), "gauss_axis")
+        cur = out
+    assert maxdiff(fused.cpu(), cur.cpu()) < 1e-6
+    assert maxdiff(fused.cpu(), O.gaussian_smooth(1.5 * x)) < 2e-6
+
+
 @pytest.mark.parametrize("dims", [(20, 28), (64, 256), (8, 12, 16), (16, 24, 64)])
 def test_displacement_measurements(dims):
     """advchain_max_displacement and the disp_out slots of advchain_compose_self_fwd report max |position - voxel|."""
