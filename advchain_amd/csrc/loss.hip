@@ -71,6 +71,64 @@ k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, co
   if (threadIdx.x == 0) atomic_add_f32(sums + sum_slot(), acc[0]);
 }
 
+// K known at compile time, V % 4 == 0: 4 voxels per thread with 16-byte loads and stores, every input read once
+// (the generic kernel above re-reads its 2K inputs three times with 4-byte loads: 36 vector-memory instructions per
+// voxel-wave at K = 4, against 4.25 here -- these streaming kernels are bound by that count).
+template <int K>
+__global__ void __launch_bounds__(kBlock)
+k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
+                  float* __restrict__ P, float* __restrict__ D, float* __restrict__ sums, int V, int mask_ch,
+                  int ref_is_prob) {
+  __shared__ float smem[4];
+  const int n = blockIdx.y;
+  const int v = (blockIdx.x * kBlock + threadIdx.x) * 4;
+  float acc[1] = {0.f};
+  if (v < V) {
+    float p[K][4], r[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(pred + ((int64_t)n * K + k) * V + v);
+      const float4 b = *reinterpret_cast<const float4*>(ref + ((int64_t)n * K + k) * V + v);
+      p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w;
+      r[k][0] = b.x; r[k][1] = b.y; r[k][2] = b.z; r[k][3] = b.w;
+    }
+    float m1[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mask && mask_ch == 1) {
+      const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+      m1[0] = mm.x; m1[1] = mm.y; m1[2] = mm.z; m1[3] = mm.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float mp = -INFINITY, mr = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { mp = fmaxf(mp, p[k][q]); mr = fmaxf(mr, r[k][q]); }
+      float sp = 0.f, sr = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { sp += expf(p[k][q] - mp); sr += expf(r[k][q] - mr); }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float pp = expf(p[k][q] - mp) / sp;
+        const float tt = ref_is_prob ? r[k][q] : expf(r[k][q] - mr) / sr;
+        p[k][q] = pp;
+        r[k][q] = pp - tt;          // D
+        const float tq = tt;
+        float m = m1[q];
+        if (mask && mask_ch > 1) m = mask[((int64_t)n * mask_ch + k) * V + v + q];
+        const float e = pp * m - tq * m;
+        acc[0] += e * e;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = ((int64_t)n * K + k) * V + v;
+      *reinterpret_cast<float4*>(P + o) = make_float4(p[k][0], p[k][1], p[k][2], p[k][3]);
+      *reinterpret_cast<float4*>(D + o) = make_float4(r[k][0], r[k][1], r[k][2], r[k][3]);
+    }
+  }
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) atomic_add_f32(sums + sum_slot(), acc[0]);
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(kBlock)
 k_edge_fwd(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ R,
@@ -517,7 +575,19 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
   const int V = (int)d.voxels();
   dim3 g(advchain_blocks(V, kBlock), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_softmax_diff, g, b, 0, st, pred, ref, mask, P, D, sums, (int)K, V, mask_channels, ref_is_prob);
+  const bool al16 = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(mask) |
+                      reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(D)) & 15) == 0;
+  if (V % 4 == 0 && al16 && K >= 2 && K <= 5) {
+    dim3 g4(advchain_blocks(V / 4, kBlock), (unsigned)N);
+    switch (K) {
+      case 2: hipLaunchKernelGGL(k_softmax_diff_v4<2>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
+      case 3: hipLaunchKernelGGL(k_softmax_diff_v4<3>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
+      case 4: hipLaunchKernelGGL(k_softmax_diff_v4<4>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
+      default: hipLaunchKernelGGL(k_softmax_diff_v4<5>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
+    }
+  } else {
+    hipLaunchKernelGGL(k_softmax_diff, g, b, 0, st, pred, ref, mask, P, D, sums, (int)K, V, mask_channels, ref_is_prob);
+  }
   if (want_edges && K > 1) {
     const bool rows = (d.s2 % 64) == 0;   // lane <-> x with whole waves per row: DPP neighbour exchange
     if (ndim == 3) {
