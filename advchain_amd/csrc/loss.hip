@@ -512,16 +512,251 @@ k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D
 using namespace advchain;
 
 
+// ---------------------------------------------------------------------------------------------
+// 16-byte form of the marching kernels (S2 % 4 == 0 and S2/4 divides 64): a lane owns 4 consecutive x, a group of
+// S2/4 lanes one row, a wave 64/(S2/4) independent strips.  The x neighbours of a quad's ends come from the
+// neighbouring lanes (whole-wave DPP shifts, zero across a row end = the zero padding of the convolution).  Same
+// arithmetic per voxel as the scalar march; a quarter of its vector-memory instructions.
+// ---------------------------------------------------------------------------------------------
+struct Quad { float v[4]; };
+
+// rows (i0 +- 1, j1) folded over z and x for the 4 voxels of this lane: zs = h along x, zd = hp along x
+template <int DIM>
+__device__ __forceinline__ void fold_row4(const float* __restrict__ p, int i0, int j1, int x, bool first, bool last,
+                                          const Dims& d, Quad& zs, Quad& zd) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { zs.v[q] = 0.f; zd.v[q] = 0.f; }
+#pragma unroll
+  for (int a0 = (DIM == 3 ? 0 : 1); a0 < (DIM == 3 ? 3 : 2); ++a0) {
+    const int j0 = i0 + a0 - 1;
+    const bool in = (j0 >= 0) && (j0 < d.s0) && (j1 >= 0) && (j1 < d.s1);
+    const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1);
+    float4 c = *reinterpret_cast<const float4*>(p + ((int64_t)c0 * d.s1 + c1) * d.s2 + x);
+    if (!in) c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float pw = lane_prev_f(c.w), nx = lane_next_f(c.x);
+    const float l[4] = {first ? 0.f : pw, c.x, c.y, c.z};
+    const float r[4] = {c.y, c.z, c.w, last ? 0.f : nx};
+    const float cc[4] = {c.x, c.y, c.z, c.w};
+    const float w = DIM == 3 ? hsm(a0) : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      zs.v[q] += w * (l[q] + 2.f * cc[q] + r[q]);
+      zd.v[q] += w * (l[q] - r[q]);
+    }
+  }
+}
+
+// strip of this lane group; every lane stays active (DPP), `ok` masks the stores
+__device__ __forceinline__ void strip_decode4(const Dims& d, int mlen, int& i0, int& y0, int& x, bool& first, bool& last,
+                                              bool& ok) {
+  const int lpr = d.s2 >> 2;                     // lanes per row
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / lpr, xq = lane - grp * lpr;
+  const int ny = (d.s1 + mlen - 1) / mlen;
+  const int strip = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / lpr) + grp;
+  ok = strip < ny * d.s0;
+  const int sc = ok ? strip : 0;
+  y0 = (sc % ny) * mlen;
+  i0 = sc / ny;
+  x = 4 * xq;
+  first = xq == 0;
+  last = xq == lpr - 1;
+}
+
+template <int DIM, int K>
+__global__ void __launch_bounds__(kBlock)
+k_edge_fwd_march4(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ R,
+                  float* __restrict__ sums, Dims d, int mask_ch, int mlen) {
+  __shared__ float smem[8];
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  float acc[2] = {0.f, 0.f};
+  int i0, y0, x;
+  bool first, last, ok;
+  strip_decode4(d, mlen, i0, y0, x, first, last, ok);
+  Quad zs[K - 1][3], zd[K - 1][3];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    const float* Dk = D + ((int64_t)n * K + k) * V;
+    fold_row4<DIM>(Dk, i0, y0 - 1, x, first, last, d, zs[k - 1][0], zd[k - 1][0]);
+    fold_row4<DIM>(Dk, i0, y0, x, first, last, d, zs[k - 1][1], zd[k - 1][1]);
+  }
+  const int y1 = min(y0 + mlen, d.s1);
+  for (int i1 = y0; i1 < y1; ++i1) {
+    const int v = (i0 * d.s1 + i1) * d.s2 + x;
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mask) {
+      const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * mask_ch * V + v);
+      m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+    }
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      const float* Dk = D + ((int64_t)n * K + k) * V;
+      fold_row4<DIM>(Dk, i0, i1 + 1, x, first, last, d, zs[k - 1][2], zd[k - 1][2]);
+      float ra[4], rb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float ga, gb;
+        if (DIM == 2) {
+          ga = zd[k - 1][0].v[q] + 2.f * zd[k - 1][1].v[q] + zd[k - 1][2].v[q];
+          gb = zs[k - 1][0].v[q] - zs[k - 1][2].v[q];
+        } else {
+          ga = zs[k - 1][0].v[q] - zs[k - 1][2].v[q];
+          gb = zd[k - 1][0].v[q] + 2.f * zd[k - 1][1].v[q] + zd[k - 1][2].v[q];
+        }
+        const float ea = ga * m[q], eb = gb * m[q];
+        if (ok) { acc[0] += ea * ea; acc[1] += eb * eb; }
+        ra[q] = 2.f * m[q] * m[q] * ga;
+        rb[q] = 2.f * m[q] * m[q] * gb;
+      }
+      if (R && ok) {
+        *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+        *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+      }
+      zs[k - 1][0] = zs[k - 1][1]; zs[k - 1][1] = zs[k - 1][2];
+      zd[k - 1][0] = zd[k - 1][1]; zd[k - 1][1] = zd[k - 1][2];
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + kSumSlots + sum_slot(), acc[0]);
+    atomic_add_f32(sums + 2 * kSumSlots + sum_slot(), acc[1]);
+  }
+}
+
+template <int DIM, int K>
+__global__ void __launch_bounds__(kBlock)
+k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
+                         const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
+                         float c_mse, float c_a, float c_b, Dims d, int mask_ch, int mlen) {
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  int i0, y0, x;
+  bool first, last, ok;
+  strip_decode4(d, mlen, i0, y0, x, first, last, ok);
+  const float gs = gscale ? gscale[0] : 1.f;
+  Quad za[K - 1][3], zb[K - 1][3];
+  auto fold = [&](int k, int j1, Quad& a, Quad& b) {
+    const float* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
+    Quad as, ad, bs, bd;
+    fold_row4<DIM>(Ra, i0, j1, x, first, last, d, as, ad);
+    fold_row4<DIM>(Ra + V, i0, j1, x, first, last, d, bs, bd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a.v[q] = DIM == 3 ? as.v[q] : -ad.v[q];
+      b.v[q] = DIM == 3 ? -bd.v[q] : bs.v[q];
+    }
+  };
+  if (R) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      fold(k, y0 - 1, za[k - 1][0], zb[k - 1][0]);
+      fold(k, y0, za[k - 1][1], zb[k - 1][1]);
+    }
+  }
+  const int y1 = min(y0 + mlen, d.s1);
+  for (int i1 = y0; i1 < y1; ++i1) {
+    const int v = (i0 * d.s1 + i1) * d.s2 + x;
+    float gp[K][4], pk[K][4];
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    float m1[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mask && mask_ch == 1) {
+      const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+      m1[0] = mm.x; m1[1] = mm.y; m1[2] = mm.z; m1[3] = mm.w;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = ((int64_t)n * K + k) * V + v;
+      float m[4] = {m1[0], m1[1], m1[2], m1[3]};
+      if (mask && mask_ch > 1) {
+        const float4 mm = *reinterpret_cast<const float4*>(mask + ((int64_t)n * mask_ch + k) * V + v);
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+      }
+      const float4 dd = *reinterpret_cast<const float4*>(D + o);
+      const float4 pp = *reinterpret_cast<const float4*>(P + o);
+      const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+      pk[k][0] = pp.x; pk[k][1] = pp.y; pk[k][2] = pp.z; pk[k][3] = pp.w;
+      if (k >= 1 && R) fold(k, i1 + 1, za[k - 1][2], zb[k - 1][2]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float g = c_mse * 2.f * m[q] * m[q] * dv[q];
+        if (k >= 1 && R) {
+          float sa, sb;
+          if (DIM == 2) {
+            sa = za[k - 1][0].v[q] + 2.f * za[k - 1][1].v[q] + za[k - 1][2].v[q];
+            sb = zb[k - 1][2].v[q] - zb[k - 1][0].v[q];
+          } else {
+            sa = za[k - 1][2].v[q] - za[k - 1][0].v[q];
+            sb = zb[k - 1][0].v[q] + 2.f * zb[k - 1][1].v[q] + zb[k - 1][2].v[q];
+          }
+          g += c_a * sa + c_b * sb;
+        }
+        g *= gs;
+        gp[k][q] = g;
+        dot[q] += g * pk[k][q];
+      }
+      if (k >= 1 && R) {
+        za[k - 1][0] = za[k - 1][1]; za[k - 1][1] = za[k - 1][2];
+        zb[k - 1][0] = zb[k - 1][1]; zb[k - 1][1] = zb[k - 1][2];
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) =
+            make_float4(pk[k][0] * (gp[k][0] - dot[0]), pk[k][1] * (gp[k][1] - dot[1]), pk[k][2] * (gp[k][2] - dot[2]),
+                        pk[k][3] * (gp[k][3] - dot[3]));
+    }
+  }
+}
+
 static inline dim3 march_grid(const Dims& d, int64_t N) {
   const int strips = (d.s2 >> 6) * ((d.s1 + kMarch - 1) / kMarch) * d.s0;
   return dim3((unsigned)((strips + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)N);
 }
 static const bool g_no_march = getenv("ADVCHAIN_NO_MARCH") != nullptr;   // A/B knob
+static const bool g_no_march4 = getenv("ADVCHAIN_NO_MARCH4") != nullptr;   // A/B knob
+
+static inline bool march4_ok(const Dims& d, const void* a, const void* b, const void* c, const void* e) {
+  if (g_no_march4 || d.s2 % 4 != 0) return false;
+  const int lpr = d.s2 / 4;
+  if (lpr > 64 || 64 % lpr != 0) return false;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                       reinterpret_cast<uintptr_t>(e);
+  return (al & 15) == 0;
+}
+// rows marched per strip: as long as possible (each strip re-reads 2 halo rows) while the launch still has ~1024 waves
+// (measured: 8 rows beat 4 at 2048 waves, 3D 84 vs 92 us; 2D 1024 waves: 8 and 4 rows equal)
+static inline int march4_len(const Dims& d, int64_t N) {
+  static const int forced = getenv("ADVCHAIN_MARCH4_LEN") ? atoi(getenv("ADVCHAIN_MARCH4_LEN")) : 0;   // tuning knob
+  if (forced > 0) return forced;
+  const int groups_per_wave = 64 / (d.s2 / 4);
+  for (int m = kMarch; m > 2; m /= 2)
+    if (N * d.s0 * ((d.s1 + m - 1) / m) / groups_per_wave >= 1024) return m;
+  return 2;
+}
+static inline dim3 march4_grid(const Dims& d, int64_t N, int mlen) {
+  const int strips = ((d.s1 + mlen - 1) / mlen) * d.s0;
+  const int per_block = (kBlock / 64) * (64 / (d.s2 / 4));
+  return dim3((unsigned)((strips + per_block - 1) / per_block), (unsigned)N);
+}
 
 template <int DIM>
 static bool launch_edge_march(int64_t K, int64_t N, const Dims& d, hipStream_t st, const float* D, const float* mask,
-                              float* R, float* sums, int mask_ch) {
+                              float* R, float* sums, int mask_ch, bool rows) {
   if (g_no_march) return false;
+  if (march4_ok(d, D, mask, R, nullptr)) {
+    const int mlen = march4_len(d, N);
+    const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
+    switch (K) {
+      case 2: hipLaunchKernelGGL((k_edge_fwd_march4<DIM, 2>), g4, b4, 0, st, D, mask, R, sums, d, mask_ch, mlen); return true;
+      case 3: hipLaunchKernelGGL((k_edge_fwd_march4<DIM, 3>), g4, b4, 0, st, D, mask, R, sums, d, mask_ch, mlen); return true;
+      case 4: hipLaunchKernelGGL((k_edge_fwd_march4<DIM, 4>), g4, b4, 0, st, D, mask, R, sums, d, mask_ch, mlen); return true;
+      case 5: hipLaunchKernelGGL((k_edge_fwd_march4<DIM, 5>), g4, b4, 0, st, D, mask, R, sums, d, mask_ch, mlen); return true;
+      default: break;
+    }
+  }
+  if (!rows) return false;   // the scalar march needs whole waves per row (S2 % 64 == 0)
   const dim3 g = march_grid(d, N), b(kBlock);
   switch (K) {
     case 2: hipLaunchKernelGGL((k_edge_fwd_march<DIM, 2>), g, b, 0, st, D, mask, R, sums, d, mask_ch); return true;
@@ -535,8 +770,19 @@ static bool launch_edge_march(int64_t K, int64_t N, const Dims& d, hipStream_t s
 template <int DIM>
 static bool launch_bwd_march(int64_t K, int64_t N, const Dims& d, hipStream_t st, const float* P, const float* D,
                              const float* R, const float* mask, const float* gscale, float* gpred, float c_mse,
-                             float c_a, float c_b, int mask_ch) {
+                             float c_a, float c_b, int mask_ch, bool rows) {
   if (g_no_march) return false;
+  if (march4_ok(d, P, D, R, mask) && (reinterpret_cast<uintptr_t>(gpred) & 15) == 0) {
+    const int mlen = march4_len(d, N);
+    const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
+    switch (K) {
+      case 2: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 2>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
+      case 3: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 3>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
+      case 4: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 4>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
+      default: break;   // K = 5: the scalar march (register budget)
+    }
+  }
+  if (!rows) return false;   // the scalar march needs whole waves per row (S2 % 64 == 0)
   const dim3 g = march_grid(d, N), b(kBlock);
   switch (K) {
     case 2: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 2>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
@@ -591,11 +837,11 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
   if (want_edges && K > 1) {
     const bool rows = (d.s2 % 64) == 0;   // lane <-> x with whole waves per row: DPP neighbour exchange
     if (ndim == 3) {
-      if (rows && mask_channels <= 1 && launch_edge_march<3>(K, N, d, st, D, mask, R, sums, mask_channels)) {}
+      if (mask_channels <= 1 && launch_edge_march<3>(K, N, d, st, D, mask, R, sums, mask_channels, rows)) {}
       else if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
       else hipLaunchKernelGGL(k_edge_fwd<3>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
     } else {
-      if (rows && mask_channels <= 1 && launch_edge_march<2>(K, N, d, st, D, mask, R, sums, mask_channels)) {}
+      if (mask_channels <= 1 && launch_edge_march<2>(K, N, d, st, D, mask, R, sums, mask_channels, rows)) {}
       else if (rows) hipLaunchKernelGGL(k_edge_fwd_rows<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
       else hipLaunchKernelGGL(k_edge_fwd<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
     }
@@ -618,11 +864,11 @@ int advchain_consistency_bwd(const float* P, const float* D, const float* R, con
   hipStream_t st = (hipStream_t)stream;
   const bool rows = (d.s2 % 64) == 0;
   if (ndim == 3) {
-    if (rows && launch_bwd_march<3>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels)) {}
+    if (launch_bwd_march<3>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows)) {}
     else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
     else hipLaunchKernelGGL(k_consistency_bwd<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
   } else {
-    if (rows && launch_bwd_march<2>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels)) {}
+    if (launch_bwd_march<2>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows)) {}
     else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
     else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
   }
