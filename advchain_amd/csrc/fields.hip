@@ -76,20 +76,26 @@ __host__ __device__ inline TpGeom tp_geom(int S2) {
   return g;
 }
 
-template <class Epi>
+// VEC = 4 (S2 % 4 == 0, 16-byte aligned planes): a thread produces 4 consecutive x and hands them to the epilogue
+// together, which then moves 16 bytes per lane (these epilogues are pure streaming: their time is their number of
+// vector-memory instructions).  epi(i1, x, val) with val = float[VEC].
+template <int VEC, class Epi>
 __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const BandTables& T, const Dims& full, int i0,
                                         int i1_begin, int i1_end, float* lds, Epi&& epi) {
   const BandAxis& A0 = T.a[0];
   const BandAxis& A1 = T.a[1];
   const BandAxis& A2 = T.a[2];
-  const TpGeom gm = tp_geom(full.s2);
-  const int tx = threadIdx.x % gm.XT, ry = threadIdx.x / gm.XT;
+  const int ncol = full.s2 / VEC;                          // column groups per row
+  int XT = 64;                                             // threads along x: one wave per row, or fewer for short rows
+  if (VEC > 1) { XT = 1; while (XT < ncol && XT < 64) XT *= 2; }
+  const int ROWS = kBlock / XT;
+  const int tx = threadIdx.x % XT, ry = threadIdx.x / XT;
   const int g2 = A2.g;
   const int s0 = A0.start[i0];
   const float* w0 = A0.w + i0 * A0.B;
   // rows blended per phase: as many as the LDS buffer holds (with 4 rows per phase a workgroup paid two barriers and a
   // dependent start[] -> coef[] load chain per 4 rows: 52 us for a 50 MB write at 4x3x128x128x64)
-  const int RPP = max(gm.ROWS, min(kTpChunk, kTpMaxLds / max(g2, 1)) / gm.ROWS * gm.ROWS);
+  const int RPP = max(1, min(kTpChunk, kTpMaxLds / max(g2, 1)));
   for (int base = i1_begin; base < i1_end; base += RPP) {
     for (int e = threadIdx.x; e < RPP * g2; e += kBlock) {
       const int r = e / g2, k = e - r * g2;
@@ -107,21 +113,30 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
       lds[e] = acc;
     }
     __syncthreads();
-    // x outer: the band of an output column (start, <= 8 weights) is loaded once and kept in registers for all rows
-    // (per-row table loads were a dependent global-load chain in the inner loop)
-    for (int x = tx; x < full.s2; x += gm.XT) {
-      const int s2 = A2.start[x];
-      float w2[kBandMax];
+    // x outer: the bands of the thread's output columns (start, <= 8 weights each) are loaded once and kept in
+    // registers for all rows (per-row table loads were a dependent global-load chain in the inner loop)
+    for (int xg = tx; xg < ncol; xg += XT) {
+      int s2[VEC];
+      float w2[VEC][kBandMax];
 #pragma unroll
-      for (int c = 0; c < kBandMax; ++c) w2[c] = c < A2.B ? A2.w[x * A2.B + c] : 0.f;
-      for (int r = ry; r < RPP; r += gm.ROWS) {
+      for (int q = 0; q < VEC; ++q) {
+        s2[q] = A2.start[xg * VEC + q];
+#pragma unroll
+        for (int c = 0; c < kBandMax; ++c) w2[q][c] = c < A2.B ? A2.w[(xg * VEC + q) * A2.B + c] : 0.f;
+      }
+      for (int r = ry; r < RPP; r += ROWS) {
         const int i1 = base + r;
         if (i1 >= i1_end) break;
-        float val = 0.f;
+        float val[VEC];
 #pragma unroll
-        for (int c = 0; c < kBandMax; ++c)
-          if (c < A2.B) val += w2[c] * lds[r * g2 + s2 + c];
-        epi(i1, x, val);
+        for (int q = 0; q < VEC; ++q) {
+          float v = 0.f;
+#pragma unroll
+          for (int c = 0; c < kBandMax; ++c)
+            if (c < A2.B) v += w2[q][c] * lds[r * g2 + s2[q] + c];
+          val[q] = v;
+        }
+        epi(i1, xg * VEC, val);
       }
     }
     __syncthreads();
@@ -130,6 +145,7 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
 
 // out[plane][v] = (add_identity ? identity_coord(channel) : 0) + scale * interp ; optional sum of interp^2
 // (64 slot accumulators) for the 3D step-count rule.  grid = (i1 chunks, S0, planes).
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTables T, Dims full, int C,
                 int add_identity, float scale, float* __restrict__ sumsq, float* __restrict__ disp_out) {
@@ -143,14 +159,17 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
   float sq[1] = {0.f};
   float dmax = 0.f;
   const float to_vox = fabsf(scale) * 0.5f * (float)((c == 0 ? full.s2 : (c == 1 ? full.s1 : full.s0)) - 1);
-  tp_rows(coef + (int64_t)plane * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, float val) {
-    sq[0] += val * val;
-    dmax = fmaxf(dmax, fabsf(val));
-    if (out) {
+  tp_rows<VEC>(coef + (int64_t)plane * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, const float (&val)[VEC]) {
+    float o[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      sq[0] += val[q] * val[q];
+      dmax = fmaxf(dmax, fabsf(val[q]));
       float base = 0.f;
-      if (add_identity) base = c == 0 ? lin_coord(x, full.s2) : (c == 1 ? lin_coord(i1, full.s1) : lin_coord(i0, full.s0));
-      out[(int64_t)plane * V + ((int64_t)i0 * full.s1 + i1) * full.s2 + x] = base + scale * val;
+      if (add_identity) base = c == 0 ? lin_coord(x + q, full.s2) : (c == 1 ? lin_coord(i1, full.s1) : lin_coord(i0, full.s0));
+      o[q] = base + scale * val[q];
     }
+    if (out) store_vec<VEC>(out + (int64_t)plane * V + ((int64_t)i0 * full.s1 + i1) * full.s2 + x, o);
   });
   if (disp_out) wave_max_to_slots(fminf(dmax * to_vox, 1.0e9f), disp_out);   // displacement of base + scale * val, in voxels
   if (sumsq) {
@@ -295,6 +314,7 @@ __device__ __forceinline__ float bias_value(float L, int use_log, float eps, flo
 }
 
 // grid = (i1 chunks, S0, N)
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_bias_fwd(const float* __restrict__ cp, const float* __restrict__ data, float* __restrict__ out,
            float* __restrict__ field, BandTables T, Dims full, int C, float eps, int use_log, float cp_scale) {
@@ -303,22 +323,31 @@ k_bias_fwd(const float* __restrict__ cp, const float* __restrict__ data, float* 
   const int i1b = blockIdx.x * kTpChunk, i1e = min(i1b + kTpChunk, full.s1);
   const int64_t G = (int64_t)T.a[0].g * T.a[1].g * T.a[2].g;
   const int V = (int)full.voxels();
-  tp_rows(cp + (int64_t)n * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, float val) {
+  tp_rows<VEC>(cp + (int64_t)n * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, const float (&val)[VEC]) {
     const int v = (i0 * full.s1 + i1) * full.s2 + x;
-    float e;
-    bool pass;
-    const float b = bias_value(cp_scale * val, use_log, eps, e, pass);
-    field[(int64_t)n * V + v] = b;
+    float b[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float e;
+      bool pass;
+      b[q] = bias_value(cp_scale * val[q], use_log, eps, e, pass);
+    }
+    store_vec<VEC>(field + (int64_t)n * V + v, b);
     if (data) {
       for (int c = 0; c < C; ++c) {
         const int64_t o = ((int64_t)n * C + c) * V + v;
-        out[o] = b * data[o];
+        float dv[VEC];
+        load_vec<VEC>(data + o, dv);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) dv[q] *= b[q];
+        store_vec<VEC>(out + o, dv);
       }
     }
   });
 }
 
 // gL = dLoss/dL (full res, one channel); gdata optional.  grid = (i1 chunks, S0, N)
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_bias_bwd(const float* __restrict__ cp, const float* __restrict__ data, const float* __restrict__ gout,
            float* __restrict__ gL, float* __restrict__ gdata, BandTables T, Dims full, int C, float eps, int use_log,
@@ -328,19 +357,30 @@ k_bias_bwd(const float* __restrict__ cp, const float* __restrict__ data, const f
   const int i1b = blockIdx.x * kTpChunk, i1e = min(i1b + kTpChunk, full.s1);
   const int64_t G = (int64_t)T.a[0].g * T.a[1].g * T.a[2].g;
   const int V = (int)full.voxels();
-  tp_rows(cp + (int64_t)n * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, float val) {
+  tp_rows<VEC>(cp + (int64_t)n * G, T, full, i0, i1b, i1e, lds, [&](int i1, int x, const float (&val)[VEC]) {
     const int v = (i0 * full.s1 + i1) * full.s2 + x;
-    float e;
-    bool pass;
-    const float b = bias_value(cp_scale * val, use_log, eps, e, pass);
-    float sgo = 0.f;
+    float b[VEC], e[VEC], sgo[VEC];
+    bool pass[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      b[q] = bias_value(cp_scale * val[q], use_log, eps, e[q], pass[q]);
+      sgo[q] = 0.f;
+    }
     for (int c = 0; c < C; ++c) {
       const int64_t o = ((int64_t)n * C + c) * V + v;
-      const float go = gout[o];
-      sgo += go * data[o];
-      if (gdata) gdata[o] = go * b;
+      float go[VEC], dv[VEC];
+      load_vec<VEC>(gout + o, go);
+      load_vec<VEC>(data + o, dv);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) { sgo[q] += go[q] * dv[q]; go[q] *= b[q]; }
+      if (gdata) store_vec<VEC>(gdata + o, go);
     }
-    if (gL) gL[(int64_t)n * V + v] = pass ? sgo * (use_log ? e : 1.f) * cp_scale : 0.f;
+    if (gL) {
+      float gl[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) gl[q] = pass[q] ? sgo[q] * (use_log ? e[q] : 1.f) * cp_scale : 0.f;
+      store_vec<VEC>(gL + (int64_t)n * V + v, gl);
+    }
   });
 }
 
@@ -638,10 +678,15 @@ int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, c
   if (planes == 0) return ADVCHAIN_OK;
   Dims full{(int)S[0], (int)S[1], (int)S[2]};
   ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "tp_interp_fwd: volume too large");
-  ADVCHAIN_CHECK_ARG(tp_geom(full.s2).ROWS * T.a[2].g <= kTpMaxLds, "tp_interp_fwd: coefficient row too long");
+  ADVCHAIN_CHECK_ARG(T.a[2].g <= kTpMaxLds, "tp_interp_fwd: coefficient row too long");
   dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), (unsigned)full.s0, (unsigned)planes);
-  hipLaunchKernelGGL(k_tp_interp_fwd, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
-                     add_identity, scale, sumsq, disp_out);
+  // short rows (S2 < 128) leave a thread only two rows to amortise the bands of its 4 columns: measured slower (3D 53 -> 61 us)
+  if (full.s2 % 4 == 0 && full.s2 >= 128 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_tp_interp_fwd<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
+                       add_identity, scale, sumsq, disp_out);
+  else
+    hipLaunchKernelGGL(k_tp_interp_fwd<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
+                       add_identity, scale, sumsq, disp_out);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
@@ -684,10 +729,14 @@ int advchain_bias_field_fwd(const float* cp, const float* data, float* out, floa
   if (N == 0) return ADVCHAIN_OK;
   Dims full{(int)S[0], (int)S[1], (int)S[2]};
   ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "bias_field_fwd: volume too large");
-  ADVCHAIN_CHECK_ARG(tp_geom(full.s2).ROWS * T.a[2].g <= kTpMaxLds, "bias_field_fwd: too many control points per row");
+  ADVCHAIN_CHECK_ARG(T.a[2].g <= kTpMaxLds, "bias_field_fwd: too many control points per row");
   dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), (unsigned)full.s0, (unsigned)N);
-  hipLaunchKernelGGL(k_bias_fwd, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, out, field, T, full, (int)C, eps,
-                     use_log, cp_scale);
+  if (full.s2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(field)) & 15) == 0)
+    hipLaunchKernelGGL(k_bias_fwd<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, out, field, T, full, (int)C, eps,
+                       use_log, cp_scale);
+  else
+    hipLaunchKernelGGL(k_bias_fwd<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, out, field, T, full, (int)C, eps,
+                       use_log, cp_scale);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
@@ -703,10 +752,15 @@ int advchain_bias_field_bwd(const float* cp, const float* data, const float* gra
   if (N == 0) return ADVCHAIN_OK;
   Dims full{(int)S[0], (int)S[1], (int)S[2]};
   ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "bias_field_bwd: volume too large");
-  ADVCHAIN_CHECK_ARG(tp_geom(full.s2).ROWS * T.a[2].g <= kTpMaxLds, "bias_field_bwd: too many control points per row");
+  ADVCHAIN_CHECK_ARG(T.a[2].g <= kTpMaxLds, "bias_field_bwd: too many control points per row");
   dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), (unsigned)full.s0, (unsigned)N);
-  hipLaunchKernelGGL(k_bias_bwd, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, grad_out, grad_L, grad_data, T,
-                     full, (int)C, eps, use_log, cp_scale);
+  if (full.s2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(grad_out) |
+                            reinterpret_cast<uintptr_t>(grad_L) | reinterpret_cast<uintptr_t>(grad_data)) & 15) == 0)
+    hipLaunchKernelGGL(k_bias_bwd<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, grad_out, grad_L, grad_data, T,
+                       full, (int)C, eps, use_log, cp_scale);
+  else
+    hipLaunchKernelGGL(k_bias_bwd<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, cp, data, grad_out, grad_L, grad_data, T,
+                       full, (int)C, eps, use_log, cp_scale);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
