@@ -145,3 +145,54 @@ def test_whole_solver_call_at_full_size(name):
             assert float((norms - 1).abs().max()) < 1e-4
         if t.get_name() == "bias":
             assert float(t.param.max()) <= t.high + 1e-6 and float(t.param.min()) >= t.low - 1e-6
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+def test_one_ascent_step_matches_the_oracle_at_realistic_size(sd):
+    """One whole adversarial_training call (one ascent step + the final consistency pass) at the bench resolution
+    (2D 256 x 256, 3D 64 x 64 x 32; small batches so the CPU oracle finishes in seconds), same initial parameters on
+    both sides: the large-size kernel paths (window scatter, gather form, tiled scatter, marching loss) against the
+    oracle itself, not only through properties.  Bias parameters keep clear of the clip threshold, and the composite
+    gradient tolerance is the interpolation-kink one of tests/test_ops_gpu.py."""
+    from oracle import advchain_oracle as O
+    from advchain_amd.augmentor import AdvAffine, AdvBias, AdvMorph, AdvNoise, ComposeAdversarialTransformSolver
+    from tests.helpers import make_model, rand, smooth_data
+    if sd == 2:
+        N, dims = 4, (256, 256)
+        names = ["noise", "bias", "morph", "affine"]
+    else:
+        N, dims = 1, (64, 64, 32)
+        names = ["bias", "morph", "affine"]
+    import bench
+    specs = bench.transform_configs(dims, N, names)
+    data = smooth_data(N, 1, dims, 11)
+    ocls = {"noise": O.OracleNoise, "bias": O.OracleBias, "morph": O.OracleMorph, "affine": O.OracleAffine}
+    gcls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
+    ochain = [ocls[nm](sd, cfg) for nm, cfg in specs]
+    gchain = [gcls[nm](spatial_dims=sd, config_dict=cfg, device=DEV) for nm, cfg in specs]
+    for i, ((nm, cfg), o, g) in enumerate(zip(specs, ochain, gchain)):
+        o.init_parameters()
+        g.init_parameters()
+        shape = tuple(o.param.shape)
+        if nm == "bias":
+            p = 0.1 * rand(shape, 200 + i)          # |log field| well inside log(1 +- eps): no clip sub-gradient flips
+        elif nm == "affine":
+            p = 0.6 * rand(shape, 200 + i)
+        else:
+            p = O.unit_normalize(rand(shape, 200 + i))
+        o.param = p.clone()
+        g.set_parameters(p.to(DEV))
+    model = make_model(sd)
+    osolver = O.OracleSolver(ochain)
+    oloss = osolver.adversarial_training(data=data, model=model, n_iter=1, lazy_load=True, step_sizes=1)
+    gsolver = ComposeAdversarialTransformSolver(chain_of_transforms=gchain)
+    gloss = gsolver.adversarial_training(data=data.to(DEV), model=make_model(sd, device=DEV), n_iter=1, lazy_load=True,
+                                         step_sizes=1)
+    # step-0 distance (before any update): pure forward parity
+    d0 = osolver.trace[0]["dist"]
+    assert abs(float(gsolver.last_inner_dist) - d0) < 1e-7 + 1e-4 * abs(d0)
+    for nm_cfg, o, g in zip(specs, ochain, gchain):
+        ref = o.param.detach()
+        tol = 2e-3 if nm_cfg[0] in ("morph", "noise") else 2e-4     # unit-normalised gradients through image warps: kink tolerance
+        assert float((g.param.detach().cpu() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), nm_cfg[0]
+    assert abs(float(gloss) - float(oloss)) < 1e-6 + 2e-3 * abs(float(oloss)), (float(gloss), float(oloss))
