@@ -189,7 +189,12 @@ def run_gpu(args, wl, rank, world, device):
             breakdown = {k.replace("advchain_", ""): round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
         else:
             step()
-    # timed region: exactly K steps between barrier+sync; only the dominant entry point carries events
+    # timed region: exactly K steps between barrier+sync; only the dominant entry point carries events.  The cyclic
+    # garbage collector is parked for it, as timeit does: one generation-2 pass (~40-60 ms with torch loaded) would
+    # otherwise land inside a 20-step run at random and move the result by 15 %.
+    import gc
+    gc.collect()
+    gc.disable()
     lib.records = []
     sync()
     t0 = time.perf_counter()
@@ -198,6 +203,7 @@ def run_gpu(args, wl, rank, world, device):
             step()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     roof = None
     if dominant and lib.records:
         durs, bts = [], []
