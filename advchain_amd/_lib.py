@@ -64,7 +64,8 @@ class _Lib(object):
         self._raw[name] = fn
         setattr(self, name, fn)
 
-    def timed(self, names=None):
+    def timed(self, names=None, every=1):
+        """Event pairs (on the current stream) around the chosen entry points; `every` = k samples one call in k."""
         import contextlib
         import torch
 
@@ -75,7 +76,12 @@ class _Lib(object):
             for n in chosen:
                 raw = self._raw[n]
 
-                def wrapped(*a, _raw=raw, _n=n):
+                count = [0]
+
+                def wrapped(*a, _raw=raw, _n=n, _count=count):
+                    _count[0] += 1
+                    if _count[0] % every:
+                        return _raw(*a)
                     e0 = torch.cuda.Event(enable_timing=True)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e0.record()
