@@ -513,8 +513,8 @@ using namespace advchain;
 
 
 // ---------------------------------------------------------------------------------------------
-// 16-byte form of the marching kernels (S2 % 4 == 0 and S2/4 divides 64): a lane owns 4 consecutive x, a group of
-// S2/4 lanes one row, a wave 64/(S2/4) independent strips.  The x neighbours of a quad's ends come from the
+// 16-byte form of the marching kernels (S2 % 4 == 0, S2 <= 256): a lane owns 4 consecutive x, a group of S2/4 lanes
+// one row, a wave floor(64/(S2/4)) independent strips.  The x neighbours of a quad's ends come from the
 // neighbouring lanes (whole-wave DPP shifts, zero across a row end = the zero padding of the convolution).  Same
 // arithmetic per voxel as the scalar march; a quarter of its vector-memory instructions.
 // ---------------------------------------------------------------------------------------------
@@ -550,11 +550,12 @@ __device__ __forceinline__ void fold_row4(const float* __restrict__ p, int i0, i
 __device__ __forceinline__ void strip_decode4(const Dims& d, int mlen, int& i0, int& y0, int& x, bool& first, bool& last,
                                               bool& ok) {
   const int lpr = d.s2 >> 2;                     // lanes per row
+  const int gpw = 64 / lpr;                      // row groups per wave; lanes beyond gpw * lpr idle (but stay active: DPP)
   const int lane = threadIdx.x & 63;
   const int grp = lane / lpr, xq = lane - grp * lpr;
   const int ny = (d.s1 + mlen - 1) / mlen;
-  const int strip = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / lpr) + grp;
-  ok = strip < ny * d.s0;
+  const int strip = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * gpw + grp;
+  ok = grp < gpw && strip < ny * d.s0;
   const int sc = ok ? strip : 0;
   y0 = (sc % ny) * mlen;
   i0 = sc / ny;
@@ -720,7 +721,7 @@ static const bool g_no_march4 = getenv("ADVCHAIN_NO_MARCH4") != nullptr;   // A/
 static inline bool march4_ok(const Dims& d, const void* a, const void* b, const void* c, const void* e) {
   if (g_no_march4 || d.s2 % 4 != 0) return false;
   const int lpr = d.s2 / 4;
-  if (lpr > 64 || 64 % lpr != 0) return false;
+  if (lpr > 64 || lpr < 1) return false;       // a row must fit one wave; rows need not divide it (idle tail lanes)
   const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
                        reinterpret_cast<uintptr_t>(e);
   return (al & 15) == 0;

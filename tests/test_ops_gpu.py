@@ -532,9 +532,11 @@ def test_consistency_loss_golden():
                 assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, k
 
 
-@pytest.mark.parametrize("dims", [(12, 64), (9, 128), (5, 6, 64), (3, 4, 128)])
+@pytest.mark.parametrize("dims", [(12, 64), (9, 128), (5, 6, 64), (3, 4, 128), (7, 9, 80), (11, 20), (13, 100), (4, 5, 36),
+                                  (6, 252)])
 def test_consistency_loss_row_kernels(dims):
-    """S2 % 64 == 0 selects the row/DPP stencil kernels (not reached by the G5 fixture shapes): vs the CPU oracle."""
+    """S2 % 4 == 0 selects the marching row/DPP stencil kernels (not reached by the G5 fixture shapes), including rows
+    that do not divide a wave (80 = cfg-5: 3 rows of 20 lanes + 4 idle lanes): vs the CPU oracle."""
     from advchain_amd.common.loss import calc_segmentation_consistency
     from oracle import advchain_oracle as O
     pred = rand((2, 4) + dims, 301) * 2
