@@ -621,7 +621,7 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
 // scatter_window.hip
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                   hipStream_t st);
+                                   int halo, int32_t* workspace, hipStream_t st);
 
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
@@ -763,7 +763,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
                                                        clamp_grid, workspace, halo, (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
     const int rw = advchain_scatter_window_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                                  clamp_grid, (hipStream_t)stream);   // 2D: source-tiled window scatter
+                                                  clamp_grid, halo, nullptr, (hipStream_t)stream);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                          clamp_grid, workspace, 0, halo, (hipStream_t)stream);
@@ -817,7 +817,7 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
                                                        (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
     const int rw = advchain_scatter_window_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER,
-                                                  0, (hipStream_t)stream);            // 2D: source-tiled window scatter
+                                                  0, halo, workspace, (hipStream_t)stream);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
                                          workspace, chain, halo, (hipStream_t)stream);

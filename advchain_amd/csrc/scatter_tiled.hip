@@ -72,8 +72,10 @@ __device__ __forceinline__ float block_max(float m, float* smem) {
   return m;
 }
 
-// |x|_max of a buffer -> *out (caller zeroes *out)
-__global__ void __launch_bounds__(kBlock) k_absmax(const float* __restrict__ x, int64_t n, float* __restrict__ out, int vec) {
+// |x|_max of a buffer -> *out (caller zeroes *out).  `needed` (optional): skip the pass when *needed == 0.
+__global__ void __launch_bounds__(kBlock) k_absmax(const float* __restrict__ x, int64_t n, float* __restrict__ out, int vec,
+                                                   const int* __restrict__ needed) {
+  if (needed && *needed == 0) return;
   float m = 0.f;
   const int64_t n4 = vec ? (n >> 2) : 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
@@ -86,11 +88,13 @@ __global__ void __launch_bounds__(kBlock) k_absmax(const float* __restrict__ x, 
   if (threadIdx.x == 0 && m > 0.f) atomic_max_abs(out, m);
 }
 
-// workspace header: [0] overflow counter, [1] pad, [2] max|grad_out|, [3] max|result|
+// workspace header: [0] overflow counter, [1] "max|grad_out| still to be computed", [2] max|grad_out|, [3] max|result|
+// ([3] == -1: the previous launch of the chain was one that does not track it -- the window scatter)
 __global__ void k_scatter_prepare(int32_t* ws, int chain) {
-  if (chain) ws[2] = ws[3]; else ws[2] = 0;
+  const bool have = chain && ws[3] != -1;
+  ws[2] = have ? ws[3] : 0;
+  ws[1] = have ? 0 : 1;
   ws[0] = 0;
-  ws[1] = 0;
   ws[3] = 0;
 }
 
@@ -318,7 +322,7 @@ static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   }
   if (halo_hint > 0) {
     tc.h1 = tc.h2 = halo_hint;
-    if (ndim == 3) tc.h0 = halo_hint;
+    if (ndim == 3) tc.h0 = tc.h1 = tc.h2 = halo_hint > 4 ? 4 : halo_hint;   // wider 3D halos cost more than the overflow list
   }
   if (d.s2 <= 64) {
     tc.t2 = d.s2;  // the whole row: no x-halo needed
@@ -381,7 +385,8 @@ static bool launch_rows_c(int C, bool self, bool need_ggrid, dim3 g, size_t lds,
 // workspace (int32): [0] overflow counter, [1] pad, [2] max|grad_out| (float), [3] max|result| (float),
 //                    [4..] (n, s) overflow pairs.
 // chain = 0: max|grad_out| is computed here (one streaming pass over grad_out);
-// chain = 1: the previous launch on this workspace produced grad_out and left max|grad_out| in [3].
+// chain = 1: the previous launch on this workspace produced grad_out and left max|grad_out| in [3]
+//            (or -1 there if it was a kernel that does not track it: then the pass runs after all).
 // Returns ADVCHAIN_ERR_UNSUPPORTED when C is outside 1..4 (caller falls back to the global-atomic kernels).
 int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                   float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
@@ -395,13 +400,14 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
   const int64_t cap64 = N * V;
   const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
   hipLaunchKernelGGL(k_scatter_prepare, dim3(1), dim3(1), 0, st, workspace, chain);   // header reset in one launch
-  if (!chain) {
+  {
+    // chain: the pass runs only if the previous launch left no max behind (decided on the device: header [1])
     const int64_t total = N * C * V;
     int blocks = (int)((total / 4 + kBlock - 1) / kBlock);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(kBlock), 0, st, gout, total, amax,
-                       (int)((reinterpret_cast<uintptr_t>(gout) & 15) == 0));
+                       (int)((reinterpret_cast<uintptr_t>(gout) & 15) == 0), chain ? workspace + 1 : (const int*)nullptr);
   }
   dim3 g((unsigned)(tc.n0 * tc.n1 * tc.n2), (unsigned)N);
   const size_t lds = (size_t)C * tc.t0 * tc.t1 * tc.t2 * sizeof(long long);

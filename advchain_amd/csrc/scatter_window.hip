@@ -1,4 +1,4 @@
-// Source-tiled window scatter for the 2D sampler backward with LARGE displacements (gfx950).
+// Source-tiled window scatter for the sampler backward with LARGE displacements (gfx950): 2D, and 3D above 4 voxels.
 //
 // The owner-computes tiles of scatter_tiled.hip walk a halo as wide as the largest displacement: at cfg-2 the fields
 // reach 70 px, the halo is 16 px, every sample is processed by 4 owners and what lands beyond the halo goes through
@@ -149,32 +149,208 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3D form, used above the displacement the owner-computes tiles cover without an overflow list (their halo is
+// at most 4 voxels: at cfg-5 the image-warp backward spent 1.1 ms draining the list on top of a 1.3 ms kernel).
+// Tile of 4 x 8 x 32 samples (4 per thread along z); the bounding box pass keeps no taps (they are rebuilt from the
+// L1/L2-resident grid in the deposit pass: 4 x 3 axis taps per thread would not fit the register budget).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWin3Z = 4, kWin3Y = 8, kWin3X = 32;
+constexpr int kWin3Cells = 12288;        // 48 KiB of LDS: 3 workgroups per CU
+
+template <int PAD, int C, bool SELF, bool GG>
+__global__ void __launch_bounds__(kBlock)
+k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid) {
+  __shared__ int win[kWin3Cells];
+  __shared__ int red[7][kBlock / 64];
+  constexpr int DIM = 3;
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  int b = blockIdx.x;
+  const int tx = b % n2; b /= n2;
+  const int ty = b % n1, tz = b / n1;
+  const int sx = tx * kWin3X + (threadIdx.x & 31), sy = ty * kWin3Y + (threadIdx.x >> 5);
+  const bool col_live = sx < d.s2 && sy < d.s1;
+  const float* gn = grid + (int64_t)n * DIM * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  const float* inn = in + (int64_t)n * C * V;
+  float* ginn = gin + (int64_t)n * C * V;
+
+  // ---- 1. bounding box of the valid corners, max |grad_out|
+  int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
+  float gmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < kWin3Z; ++j) {
+    const int sz = tz * kWin3Z + j;
+    const bool live = col_live && sz < d.s0;
+    const int s = live ? (sz * d.s1 + sy) * d.s2 + sx : 0;
+    float g[3] = {gn[s], gn[V + s], gn[2 * V + s]};
+    if (clamp_grid) { g[0] = clamp_unit(g[0]); g[1] = clamp_unit(g[1]); g[2] = clamp_unit(g[2]); }
+    Taps<DIM, PAD> t;
+    t.build(g[0], g[1], g[2], d);
+#pragma unroll
+    for (int c = 0; c < C; ++c) gmax = fmaxf(gmax, live ? fabsf(gon[(int64_t)c * V + s]) : 0.f);
+    if (live) {
+      const AxisTap* ax[3] = {&t.x, &t.y, &t.z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (ax[a]->v0 || ax[a]->v1) {
+          lo[a] = min(lo[a], ax[a]->i0 + (ax[a]->v0 ? 0 : 1));
+          hi[a] = max(hi[a], ax[a]->i0 + (ax[a]->v1 ? 1 : 0));
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], o, 64));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], o, 64));
+    }
+    gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    red[6][wave] = __float_as_int(gmax);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], red[a][w]); hi[a] = max(hi[a], red[3 + a][w]); }
+    gmax = fmaxf(gmax, __int_as_float(red[6][w]));
+  }
+  // window = box capped to the LDS budget (keeps the low corner; what falls outside uses global atomics)
+  constexpr int cells_per_ch = kWin3Cells / C;
+  int ww = min(max(hi[0] - lo[0] + 1, 0), 64), wh = max(hi[1] - lo[1] + 1, 0), wd = max(hi[2] - lo[2] + 1, 0);
+  if (ww > 0 && wh > cells_per_ch / ww) wh = cells_per_ch / ww;
+  if (ww * wh > 0 && wd > cells_per_ch / (ww * wh)) wd = cells_per_ch / (ww * wh);
+  const int plane = ww * wh, cells = plane * wd;
+  for (int i = threadIdx.x; i < C * cells; i += kBlock) win[i] = 0;
+  const float scale = gmax > 0.f ? 1048576.f / gmax : 0.f;   // 2^20
+  __syncthreads();
+
+  // ---- 2. deposits
+#pragma unroll 2
+  for (int j = 0; j < kWin3Z; ++j) {
+    const int sz = tz * kWin3Z + j;
+    if (!(col_live && sz < d.s0)) continue;
+    const int s = (sz * d.s1 + sy) * d.s2 + sx;
+    float g[3] = {gn[s], gn[V + s], gn[2 * V + s]};
+    bool pass[3] = {true, true, true};
+    if (clamp_grid) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { pass[a] = g[a] >= -1.f && g[a] <= 1.f; g[a] = clamp_unit(g[a]); }
+    }
+    Taps<DIM, PAD> t;
+    t.build(g[0], g[1], g[2], d);
+    float go[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) go[c] = gon[(int64_t)c * V + s];
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          if (!t.ok(cz, cy, cx)) continue;
+          const int ux = t.x.i0 + cx, uy = t.y.i0 + cy, uz = t.z.i0 + cz;
+          const float w = t.w(cz, cy, cx);
+          const int wx = ux - lo[0], wy = uy - lo[1], wz = uz - lo[2];
+          if (wx >= 0 && wx < ww && wy >= 0 && wy < wh && wz >= 0 && wz < wd) {
+            const float ws = w * scale;
+            int* cell = win + wz * plane + wy * ww + wx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c]));
+          } else {
+            float* dst = ginn + (uz * d.s1 + uy) * d.s2 + ux;
+#pragma unroll
+            for (int c = 0; c < C; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[c]);
+          }
+        }
+    if (SELF || GG) {
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, go[c], t, d, ax, ay, az);
+      const float ggx = pass[0] ? t.x.mult * ax : 0.f, ggy = pass[1] ? t.y.mult * ay : 0.f,
+                  ggz = pass[2] ? t.z.mult * az : 0.f;
+      if (SELF) {
+        if (ggx != 0.f) atomic_add_f32(ginn + s, ggx);
+        if (ggy != 0.f) atomic_add_f32(ginn + V + s, ggy);
+        if (ggz != 0.f) atomic_add_f32(ginn + 2 * (int64_t)V + s, ggz);
+      } else {
+        float* gg = ggrid + (int64_t)n * DIM * V + s;
+        gg[0] = ggx;
+        gg[V] = ggy;
+        gg[2 * (int64_t)V] = ggz;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. flush: a wave per window row (lane <-> x: runs of consecutive addresses, one division per row)
+  const float inv = gmax * (1.f / 1048576.f);
+  const int lane = threadIdx.x & 63, rows = C * wd * wh;
+  for (int r = wave; r < rows; r += kBlock / 64) {
+    if (lane >= ww) continue;
+    const int a = win[r * ww + lane];
+    if (a == 0) continue;
+    const int c = r / (wd * wh), q = r - c * (wd * wh);
+    const int wz = q / wh, wy = q - wz * wh;
+    atomic_add_f32(ginn + (int64_t)c * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + lane), (float)a * inv);
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
 
-// 2D only.  grad_in (and, for SELF, the same tensor) is zero-filled here.  Returns ADVCHAIN_ERR_UNSUPPORTED for shapes
-// the kernel does not cover (the caller keeps the owner-computes tiles).
+// grad_in (and, for SELF, the same tensor) is zero-filled here.  2D: every displacement the gather form does not take.
+// 3D: only from the displacement hint |halo| >= ADVCHAIN_WINDOW3D_MIN_HALO up (below it the owner-computes tiles win).
+// A chained workspace is told that this launch left no max|result| behind (header [3] = -1: see scatter_tiled.hip).
+// Returns ADVCHAIN_ERR_UNSUPPORTED for what the kernels do not cover (the caller keeps the owner-computes tiles).
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                   hipStream_t st) {
+                                   int halo, int32_t* workspace, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
-  if (off || ndim != 2 || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (self ? C != 2 : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
-  const int n2 = (d.s2 + kWinT - 1) / kWinT, n1 = (d.s1 + kWinT - 1) / kWinT;
+  static const int min3 = getenv("ADVCHAIN_WINDOW3D_MIN_HALO") ? atoi(getenv("ADVCHAIN_WINDOW3D_MIN_HALO")) : 5;
+  if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (ndim == 3 && (halo < 0 ? -halo : halo) < min3) return ADVCHAIN_ERR_UNSUPPORTED;
   (void)hipMemsetAsync(gin, 0, sizeof(float) * N * C * d.voxels(), st);
-  dim3 g((unsigned)(n1 * n2), (unsigned)N), b(kBlock);
+  if (workspace) (void)hipMemsetAsync(workspace + 3, 0xFF, sizeof(int32_t), st);
   const bool gg = ggrid != nullptr;
-#define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid)
+  dim3 b(kBlock);
 #define GO_PAD(C_, SELF_, GG_) \
   do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, SELF_, GG_); else GO(PAD_ZEROS, C_, SELF_, GG_); } while (0)
-  if (self) GO(PAD_BORDER, 2, true, false);
-  else if (C == 1) { if (gg) GO_PAD(1, false, true); else GO_PAD(1, false, false); }
-  else if (C == 2) { if (gg) GO_PAD(2, false, true); else GO_PAD(2, false, false); }
-  else { if (gg) GO_PAD(4, false, true); else GO_PAD(4, false, false); }
-#undef GO_PAD
+#define GO_ALL(CS_) \
+  do { \
+    if (self) GO(PAD_BORDER, CS_, true, false); \
+    else if (C == 1) { if (gg) GO_PAD(1, false, true); else GO_PAD(1, false, false); } \
+    else if (C == 2) { if (gg) GO_PAD(2, false, true); else GO_PAD(2, false, false); } \
+    else { if (gg) GO_PAD(4, false, true); else GO_PAD(4, false, false); } \
+  } while (0)
+  if (ndim == 2) {
+    const int n2 = (d.s2 + kWinT - 1) / kWinT, n1 = (d.s1 + kWinT - 1) / kWinT;
+    dim3 g((unsigned)(n1 * n2), (unsigned)N);
+#define GO(PAD_, C_, SELF_, GG_) \
+  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid)
+    GO_ALL(2);
 #undef GO
+  } else {
+    const int n2 = (d.s2 + kWin3X - 1) / kWin3X, n1 = (d.s1 + kWin3Y - 1) / kWin3Y, n0 = (d.s0 + kWin3Z - 1) / kWin3Z;
+    dim3 g((unsigned)(n0 * n1 * n2), (unsigned)N);
+#define GO(PAD_, C_, SELF_, GG_) \
+  hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid)
+    GO_ALL(3);
+#undef GO
+  }
+#undef GO_ALL
+#undef GO_PAD
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

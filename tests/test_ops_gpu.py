@@ -256,6 +256,61 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
         assert torch.equal(g1, g1s)
 
 
+def _smooth_field(dims, amp_vox, seed):
+    """identity + a smooth displacement of up to ~amp_vox voxels (low-resolution noise, upsampled)."""
+    from oracle import advchain_oracle as O
+    d = len(dims)
+    low = rand((2, d) + tuple(max(2, s // 8) for s in dims), seed)
+    up = F.interpolate(low, size=dims, mode="trilinear" if d == 3 else "bilinear", align_corners=True)
+    up = up / up.abs().max()
+    scale = torch.tensor([2.0 * amp_vox / (dims[d - 1 - a] - 1) for a in range(d)]).view(1, d, *([1] * d))
+    return (O.identity_grid(2, dims) + up * scale).contiguous()
+
+
+@pytest.mark.parametrize("dims", [(8, 12, 16), (9, 18, 64), (13, 21, 80), (20, 30, 44)])
+@pytest.mark.parametrize("amp_vox,halo", [(1.7, 8), (4.5, 8), (9.0, 8)])
+def test_window_scatter_3d(dims, amp_vox, halo):
+    """3D sampler backward with a displacement hint beyond the owner-computes tiles (> 4 voxels): the source-tiled
+    window scatter (scatter_window.hip), smooth fields of 1.7 / 4.5 / 9 voxels (the last stretches the windows past the LDS budget on
+    small volumes: global-atomic tail).  Self-composition (value + coordinate path, then a chained owner-computes step
+    that has to find out on the device that no max|grad| was left behind) and image warps (C = 1, 2, 4, both paddings,
+    clamped grid, with and without grad_grid) against autograd through F.grid_sample."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = 3
+    phi = _smooth_field(dims, amp_vox, 61)
+    w = rand((2, d) + dims, 62)
+    p = phi.clone().requires_grad_(True)
+    (O.compose_fields(p, p) * w).sum().backward()
+    pd = phi.to(DEV)
+    ws = ops._scatter_workspace(2, dims, DEV)
+    g1 = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=halo)
+    assert maxdiff(g1.cpu(), p.grad) < 5e-5 * max(1.0, float(p.grad.abs().max()))
+    g2 = ops.raw_compose_self_bwd(g1, pd, ws, chain=True, halo=0)          # owner-computes tiles after a window launch
+    p2 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p2, p2) * p.grad).sum().backward()
+    assert maxdiff(g2.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
+    g3 = ops.raw_compose_self_bwd(g2, pd, ws, chain=True, halo=0)          # ... and a regular chained step after that
+    p3 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p3, p3) * p2.grad).sum().backward()
+    assert maxdiff(g3.cpu(), p3.grad) < 5e-4 * max(1.0, float(p3.grad.abs().max()))
+    for C in (1, 2, 4):
+        for pad, clamp in (("zeros", True), ("zeros", False), ("border", False)):
+            grid = (phi * 1.02).contiguous()
+            inp, wv = rand((2, C) + dims, 63 + C), rand((2, C) + dims, 73 + C)
+            a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+            gp = torch.clamp(g, -1, 1) if clamp else g
+            ref = F.grid_sample(a, gp.permute(0, 2, 3, 4, 1), padding_mode=pad, align_corners=True)
+            (ref * wv).sum().backward()
+            gin, ggrid = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, True, halo)
+            assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max())), (C, pad, clamp)
+            assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max())), (C, pad, clamp)
+            gin2, none = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, False, halo)
+            assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4)])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
 def test_affine_warp(dims, C, pad):
