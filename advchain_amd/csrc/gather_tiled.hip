@@ -54,21 +54,25 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
     *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
   }
   __syncthreads();
-  // ---- compute: lane <-> x (one wave per output row): neighbouring lanes read neighbouring LDS words -- with
-  // 4 consecutive x per thread the taps of a wave sat 4 words apart and every LDS read was a 4-way bank conflict
+  // ---- compute: lanes run along x and wrap to the next row of the tile (neighbouring lanes read neighbouring LDS
+  // words -- with 4 consecutive x per thread the taps of a wave sat 4 words apart and every LDS read was a 4-way
+  // bank conflict; with one wave per row a row of 80 voxels left 48 of 128 lanes idle)
   const float* gn = SELF ? nullptr : grid + (int64_t)n * DIM * V;
   float* on = out + (int64_t)n * C * V;
   float dmax = 0.f;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nrows = tc.t0 * tc.t1;
-  for (int xb = 0; xb < tc.t2; xb += 64) {
-    const int sx = x0 + xb + lane;
-    const bool xin = (xb + lane < tc.t2) && sx < d.s2;
-    for (int r = wave; r < nrows; r += kBlock / 64) {
-      const int ly = r % tc.t1, lz = r / tc.t1;
-      const int sy = y0 + ly, sz = z0 + lz;
-      if (sy >= d.s1 || sz >= d.s0) continue;     // wave-uniform
-      if (!xin) continue;
+  const int tw = min(tc.t2, d.s2 - x0), th = min(tc.t1, d.s1 - y0), td = min(tc.t0, d.s0 - z0);   // clipped tile
+  const int items = tw * th * td;
+  const int step_r = kBlock / tw, step_x = kBlock - step_r * tw;
+  int lx, ly, lz;
+  {
+    const int r = threadIdx.x / tw;
+    lx = threadIdx.x - r * tw;
+    lz = r / th;
+    ly = r - lz * th;
+  }
+  for (int i = threadIdx.x; i < items; i += kBlock) {
+    {
+      const int sx = x0 + lx, sy = y0 + ly, sz = z0 + lz;
       const int s = (sz * d.s1 + sy) * d.s2 + sx;
       float gx, gy, gz = 0.f;
       if (SELF) {
@@ -132,6 +136,10 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
         }
       }
     }
+    lx += step_x;
+    ly += step_r;
+    if (lx >= tw) { lx -= tw; ++ly; }
+    while (ly >= th) { ly -= th; ++lz; }
   }
   if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
 }
@@ -153,7 +161,7 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
   static const int t1_2 = getenv("ADVCHAIN_GTILE_T1_2D") ? atoi(getenv("ADVCHAIN_GTILE_T1_2D")) : 16;
   if (ndim == 3) { tc.t0 = t0_3; tc.t1 = t1_3; tc.h0 = tc.h1 = h; }
   else { tc.t0 = 1; tc.t1 = t1_2; tc.h0 = 0; tc.h1 = h; }
-  if (d.s2 <= 64) { tc.t2 = d.s2; tc.h2 = 0; }
+  if (d.s2 <= 96) { tc.t2 = d.s2; tc.h2 = 0; }     // whole rows: no x halo
   else { tc.t2 = 64; tc.h2 = (h + 3) / 4 * 4; }
   if (tc.t1 > d.s1) tc.t1 = d.s1;
   if (tc.t0 > d.s0) tc.t0 = d.s0;
