@@ -52,6 +52,7 @@ struct XSpread {
 constexpr int kClip = 1;        // sampling positions are clipped to [0, S-1] (border padding and/or clamp_grid)
 constexpr int kBorder = 2;      // border padding: zero coordinate gradient AT and beyond the border (else: beyond only)
 constexpr int kClampGrid = 4;   // the caller asked for clamp(grid, -1, 1) (only the fallback path needs to know)
+constexpr int kUnaligned = 8;   // rows are not 16-byte aligned (S2 % 4 != 0 or a misaligned base): stage with dword loads
 
 template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 struct GatherCfg {
@@ -136,13 +137,30 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
     const bool inside = sy >= 0 && sy < d.s1 && sz >= 0 && sz < d.s0 && x >= 0 && x < d.s2;
     if (inside) {
       const int s = (sz * d.s1 + sy) * d.s2 + x;
+      if (!(flags & kUnaligned)) {
 #pragma unroll
-      for (int a = 0; a < DIM; ++a) load_vec<4>(gn + (int64_t)a * V + s, o[a]);
+        for (int a = 0; a < DIM; ++a) load_vec<4>(gn + (int64_t)a * V + s, o[a]);
 #pragma unroll
-      for (int c = 0; c < C; ++c) load_vec<4>(gon + (int64_t)c * V + s, g[c]);
-      if (G::STAGE_IN) {
+        for (int c = 0; c < C; ++c) load_vec<4>(gon + (int64_t)c * V + s, g[c]);
+        if (G::STAGE_IN) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) load_vec<4>(inn + (int64_t)c * V + s, vin[c]);
+          for (int c = 0; c < C; ++c) load_vec<4>(inn + (int64_t)c * V + s, vin[c]);
+        }
+      } else {
+        // the last quad of a row may be partial: what lies beyond the row is the next row's, staged as zeros
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool in_row = x + k < d.s2;
+          const int sk = in_row ? s + k : s;
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) o[a][k] = gn[(int64_t)a * V + sk];
+#pragma unroll
+          for (int c = 0; c < C; ++c) g[c][k] = in_row ? gon[(int64_t)c * V + sk] : 0.f;
+          if (G::STAGE_IN) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) vin[c][k] = in_row ? inn[(int64_t)c * V + sk] : 0.f;
+          }
+        }
       }
       const int sc[3] = {x, sy, sz};
 #pragma unroll
@@ -438,7 +456,11 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
   const int64_t cap64 = N * d.voxels();
   const int cap = cap64 > 0x7fffffff ? 0x7fffffff : (int)cap64;
   const bool border = padding == PAD_BORDER;
-  const int flags = ((border || clamp_grid) ? kClip : 0) | (border ? kBorder : 0) | (clamp_grid ? kClampGrid : 0);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(grid) |
+                       (GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>::STAGE_IN ? reinterpret_cast<uintptr_t>(in) : 0);
+  const bool unaligned = (d.s2 & 3) != 0 || (al & 15) != 0;
+  const int flags = ((border || clamp_grid) ? kClip : 0) | (border ? kBorder : 0) | (clamp_grid ? kClampGrid : 0) |
+                    (unaligned ? kUnaligned : 0);
   auto kern = k_adjoint_gather<DIM, C, H, SELF, GG, TZ, TY, NT>;
   static bool attr_set = false;
   if (G::LDS > 65536 && !attr_set) {
@@ -461,11 +483,8 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
                           clamp_grid, cnt, list, cap, amax_out);
 }
 
-static bool gather_shape_ok(const Dims& d, const void* a, const void* b, const void* c) {
-  if (d.s2 % 4 != 0 || d.s2 < 8) return false;
-  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
-  return (al & 15) == 0;
-}
+// rows that are not 16-byte aligned are staged with dword loads (launch_gather: kUnaligned)
+static bool gather_shape_ok(const Dims& d) { return d.s2 >= 8; }
 
 // Self-composition backward in gather form.  `halo` is the caller's displacement bound in voxels; shapes or bounds the
 // gather form does not cover return ADVCHAIN_ERR_UNSUPPORTED (the caller uses the LDS-tiled scatter).
@@ -475,7 +494,7 @@ int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, flo
   static const bool off = getenv("ADVCHAIN_NO_ADJOINT_GATHER") != nullptr;   // A/B knob
   const bool strict = halo < 0;     // negative: exact bound |halo|, guaranteed by the caller
   if (strict) halo = -halo;
-  if (off || !workspace || halo < 1 || !gather_shape_ok(d, gout, phi, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (off || !workspace || halo < 1 || !gather_shape_ok(d)) return ADVCHAIN_ERR_UNSUPPORTED;
 #define SELF_GO(DIM_, H_, TZ_, TY_, NT_) \
   launch_gather<DIM_, DIM_, H_, true, false, TZ_, TY_, NT_>(gout, phi, phi, gphi, nullptr, N, d, PAD_BORDER, 0, workspace, chain, strict, st)
   if (ndim == 3) {
@@ -500,7 +519,7 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
   const bool strict = halo < 0;     // negative: exact bound |halo|, guaranteed by the caller
   if (strict) halo = -halo;
   if (off || !workspace || halo < 1 || !gin || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (!gather_shape_ok(d, gout, grid, ggrid ? in : nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (!gather_shape_ok(d)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (C != 1 && C != 4) return ADVCHAIN_ERR_UNSUPPORTED;
 #define WARP_GO(DIM_, C_, H_, GG_, TZ_, TY_, NT_) \
   launch_gather<DIM_, C_, H_, false, GG_, TZ_, TY_, NT_>(gout, in, grid, gin, ggrid, N, d, padding, clamp_grid, workspace, 0, strict, st)

@@ -38,6 +38,11 @@ WORKLOADS = {
                  desc="3D 8x1x128x128x64 per GPU (64 over 8 GPUs), full chain, 5 adv steps"),
     "cfg5": dict(dims=(160, 160, 80), batch=4, chain=["morph"], n_iter=10, anatomy=True,
                  desc="3D 4x1x160x160x80 per GPU (8 over 2 GPUs), morph only (vector h/8), 10 adv steps, anatomy mask"),
+    # not BASELINE configs: shapes off the fast paths' alignment (innermost size not a multiple of 4), for profiling
+    "odd2d": dict(dims=(250, 250), batch=32, chain=["noise", "bias", "morph", "affine"], n_iter=5,
+                  desc="2D 32x1x250x250 (rows not a multiple of 4), full chain, 5 adv steps"),
+    "odd3d": dict(dims=(100, 100, 50), batch=4, chain=["bias", "morph", "affine"], n_iter=3,
+                  desc="3D 4x1x100x100x50 (rows not a multiple of 4), chain=[bias,morph,affine], 3 adv steps"),
 }
 
 

@@ -193,7 +193,8 @@ def test_displacement_measurements(dims):
     assert abs(float(slots.max()) - disp_of(out.cpu())) < 1e-3
 
 
-@pytest.mark.parametrize("dims", [(24, 40), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
+@pytest.mark.parametrize("dims", [(24, 40), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72), (21, 27), (7, 9, 50), (5, 6, 75),
+                                  (9, 250)])
 @pytest.mark.parametrize("C", [1, 4])
 @pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
 @pytest.mark.parametrize("amp", [0.004, 0.5])
@@ -222,13 +223,15 @@ def test_grid_sample_bwd_gather_form(dims, C, pad, clamp, amp):
             assert torch.equal(gin3, gin) and torch.equal(ggrid3, ggrid)
 
 
-@pytest.mark.parametrize("dims", [(20, 28), (40, 72), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72)])
+@pytest.mark.parametrize("dims", [(20, 28), (40, 72), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72), (21, 27), (7, 9, 50),
+                                  (5, 6, 75), (9, 250)])
 @pytest.mark.parametrize("halo", [1, 2])
 @pytest.mark.parametrize("amp", [0.005, 0.6])
 def test_compose_self_bwd_gather_form(dims, halo, amp):
     """advchain_compose_self_bwd with a displacement bound (`halo`) takes the gather-form adjoint (adjoint_gather.hip):
     same result as autograd through F.grid_sample(phi, phi) whether the bound holds (amp 0.005: below one voxel at every size here)
-    or not (amp 0.6: most samples exceed it and go through the overflow list), narrow and wide rows, chained calls."""
+    or not (amp 0.6: most samples exceed it and go through the overflow list), narrow and wide rows, rows that are not a
+    multiple of 4 voxels (dword staging), chained calls."""
     from oracle import advchain_oracle as O
     ops = _ops()
     d = len(dims)
