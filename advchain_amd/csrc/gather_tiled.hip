@@ -24,7 +24,7 @@ template <int DIM, int PAD, int C, bool SELF>
 __global__ void __launch_bounds__(kBlock)
 k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
                const float* __restrict__ phi0, Dims d, GTile tc, int clamp_grid, int final_mode,
-               float* __restrict__ disp_out) {
+               float* __restrict__ disp_out, int unaligned) {
   extern __shared__ float lds[];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -33,25 +33,45 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int ty = b % tc.n1;
   const int tz = b / tc.n1;
   const int x0 = tx * tc.t2, y0 = ty * tc.t1, z0 = tz * tc.t0;
-  // staged region, clipped to the volume (x bounds stay multiples of 4 because S2 % 4 == 0)
+  // staged region, clipped to the volume (rx0 is a multiple of 4; so is rx1 unless S2 is not: partial last quad)
   const int rx0 = max(x0 - tc.h2, 0), rx1 = min(x0 + tc.t2 + tc.h2, d.s2);
   const int ry0 = max(y0 - tc.h1, 0), ry1 = min(y0 + tc.t1 + tc.h1, d.s1);
   const int rz0 = max(z0 - tc.h0, 0), rz1 = min(z0 + tc.t0 + tc.h0, d.s0);
   const int rw = tc.rw, rh = ry1 - ry0, rd = rz1 - rz0;
-  const int rw4 = (rx1 - rx0) >> 2;
+  const int rw4 = (rx1 - rx0 + 3) >> 2;
   const int plane = rw * rh * rd;       // floats per staged channel
   const float* inn = in + (int64_t)n * C * V;
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
   const int rows = C * rd * rh;
-  for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
-    const int q = e % rw4;
-    const int r = e / rw4;
-    const int ly = r % rh;
-    const int r2 = r / rh;
-    const int lz = r2 % rd;
-    const int c = r2 / rd;
-    const float4 v = *reinterpret_cast<const float4*>(inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q);
-    *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+  if (!unaligned) {
+    for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
+      const int q = e % rw4;
+      const int r = e / rw4;
+      const int ly = r % rh;
+      const int r2 = r / rh;
+      const int lz = r2 % rd;
+      const int c = r2 / rd;
+      const float4 v = *reinterpret_cast<const float4*>(inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q);
+      *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+    }
+  } else {
+    // rows not 16-byte aligned (S2 % 4 != 0 or a misaligned base): dword loads, partial last quad padded with zeros
+    for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
+      const int q = e % rw4;
+      const int r = e / rw4;
+      const int ly = r % rh;
+      const int r2 = r / rh;
+      const int lz = r2 % rd;
+      const int c = r2 / rd;
+      const float* src = inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q;
+      const int left = rx1 - rx0 - 4 * q;
+      float4 v;
+      v.x = src[0];
+      v.y = left > 1 ? src[1] : 0.f;
+      v.z = left > 2 ? src[2] : 0.f;
+      v.w = left > 3 ? src[3] : 0.f;
+      *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+    }
   }
   __syncthreads();
   // ---- compute: lanes run along x and wrap to the next row of the tile (neighbouring lanes read neighbouring LDS
@@ -151,7 +171,7 @@ using namespace advchain;
 static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& tc) {
   static const int h3 = getenv("ADVCHAIN_GTILE_H3") ? atoi(getenv("ADVCHAIN_GTILE_H3")) : 1;   // tuning knobs
   static const int h2 = getenv("ADVCHAIN_GTILE_H2") ? atoi(getenv("ADVCHAIN_GTILE_H2")) : 8;
-  if (d.s2 % 4 != 0 || d.s2 < 8) return false;
+  if (d.s2 < 8) return false;
   static const bool tiles_2d = getenv("ADVCHAIN_GTILE_2D") != nullptr;
   if (ndim == 2 && !tiles_2d) return false;   // measured: in 2D (4 corners) the direct 4-chain gather kernels are faster
   int h = ndim == 3 ? h3 : h2;
@@ -166,14 +186,14 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
   if (tc.t1 > d.s1) tc.t1 = d.s1;
   if (tc.t0 > d.s0) tc.t0 = d.s0;
   auto bytes = [&]() {
-    return (int64_t)C * (tc.t0 + 2 * tc.h0) * (tc.t1 + 2 * tc.h1) * (tc.t2 + 2 * tc.h2) * 4;
+    return (int64_t)C * (tc.t0 + 2 * tc.h0) * (tc.t1 + 2 * tc.h1) * ((tc.t2 + 2 * tc.h2 + 3) / 4 * 4) * 4;
   };
   while (bytes() > 65536) {
     if (tc.t0 > 1) tc.t0 = (tc.t0 + 1) / 2;
     else if (tc.t1 > 2) tc.t1 = (tc.t1 + 1) / 2;
     else return false;
   }
-  tc.rw = tc.t2 + 2 * tc.h2;
+  tc.rw = (tc.t2 + 2 * tc.h2 + 3) / 4 * 4;
   tc.n2 = (d.s2 + tc.t2 - 1) / tc.t2;
   tc.n1 = (d.s1 + tc.t1 - 1) / tc.t1;
   tc.n0 = (d.s0 + tc.t0 - 1) / tc.t0;
@@ -182,8 +202,8 @@ static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& t
 
 template <int DIM, int PAD, bool SELF>
 static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const float* in, const float* grid, float* out,
-                            const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode, float* disp_out) {
-#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out)
+                            const float* phi0, Dims d, GTile tc, int clamp_grid, int final_mode, float* disp_out, int unaligned) {
+#define LAUNCH(C_) hipLaunchKernelGGL((k_sample_tiled<DIM, PAD, C_, SELF>), g, dim3(kBlock), lds, st, in, grid, out, phi0, d, tc, clamp_grid, final_mode, disp_out, unaligned)
   switch (C) {
     case 1: if constexpr (!SELF) { LAUNCH(1); return true; } return false;
     case 2: if constexpr (!SELF || DIM == 2) { LAUNCH(2); return true; } return false;
@@ -200,28 +220,26 @@ int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, 
                                  int halo, float* disp_out, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_GATHER_TILES") != nullptr;   // A/B knob
   if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
-  const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
-                       reinterpret_cast<uintptr_t>(grid) | reinterpret_cast<uintptr_t>(phi0);
-  if (al & 15) return ADVCHAIN_ERR_UNSUPPORTED;
+  const int unaligned = (reinterpret_cast<uintptr_t>(in) & 15) != 0 || (d.s2 & 3) != 0;   // only `in` is read 16 bytes at a time
   GTile tc;
   if (!choose_gtile(ndim, d, (int)C, halo, tc)) return ADVCHAIN_ERR_UNSUPPORTED;
   const size_t lds = (size_t)C * (tc.t0 + 2 * tc.h0) * (tc.t1 + 2 * tc.h1) * tc.rw * sizeof(float);
   dim3 g((unsigned)(tc.n0 * tc.n1 * tc.n2), (unsigned)N);
   bool ok = false;
   if (self) {
-    ok = ndim == 3 ? launch_sample_c<3, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out)
-                   : launch_sample_c<2, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out);
+    ok = ndim == 3 ? launch_sample_c<3, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out, unaligned)
+                   : launch_sample_c<2, PAD_BORDER, true>((int)C, g, lds, st, in, grid, out, phi0, d, tc, 0, final_mode, disp_out, unaligned);
   } else if (ndim == 3) {
     switch (padding) {
-      case PAD_ZEROS: ok = launch_sample_c<3, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
-      case PAD_BORDER: ok = launch_sample_c<3, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
-      default: ok = launch_sample_c<3, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      case PAD_ZEROS: ok = launch_sample_c<3, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
+      case PAD_BORDER: ok = launch_sample_c<3, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
+      default: ok = launch_sample_c<3, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
     }
   } else {
     switch (padding) {
-      case PAD_ZEROS: ok = launch_sample_c<2, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
-      case PAD_BORDER: ok = launch_sample_c<2, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
-      default: ok = launch_sample_c<2, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr); break;
+      case PAD_ZEROS: ok = launch_sample_c<2, PAD_ZEROS, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
+      case PAD_BORDER: ok = launch_sample_c<2, PAD_BORDER, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
+      default: ok = launch_sample_c<2, PAD_REFLECTION, false>((int)C, g, lds, st, in, grid, out, phi0, d, tc, clamp_grid, 0, nullptr, unaligned); break;
     }
   }
   if (!ok) return ADVCHAIN_ERR_UNSUPPORTED;

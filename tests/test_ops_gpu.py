@@ -88,7 +88,7 @@ def test_grid_sample_near_identity_tiles(scatter_path):
     """Near-identity warp on a volume spanning several tiles (+ displacements beyond the halo on a few voxels)."""
     from oracle import advchain_oracle as O
     ops = _ops()
-    for dims, C in (((20, 24, 72), 2), ((70, 150), 3)):
+    for dims, C in (((20, 24, 72), 2), ((70, 150), 3), ((9, 13, 50), 4), ((5, 8, 110), 1)):   # incl. rows not a multiple of 4
         d = len(dims)
         grid = O.identity_grid(2, dims) + 0.04 * rand((2, d) + dims, 81)
         grid.view(-1)[::97] += 0.5            # outliers: well beyond the halo
@@ -129,7 +129,7 @@ def test_grid_sample_clamp_grid_and_resample():
     assert maxdiff(g2.grad.cpu(), to_planar(g.grad)) < 5e-5
 
 
-@pytest.mark.parametrize("dims", [(20, 28), (19, 21), (8, 12, 16), (7, 9, 5)])
+@pytest.mark.parametrize("dims", [(20, 28), (19, 21), (8, 12, 16), (7, 9, 5), (7, 9, 50), (4, 6, 102)])
 def test_compose_self(dims, scatter_path):
     from oracle import advchain_oracle as O
     ops = _ops()
