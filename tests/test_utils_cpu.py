@@ -1,6 +1,8 @@
 """Model-side helpers of the reference's README usage (common/utils.py:114-212, common/layers.py:5-63): host logic only."""
 import random
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -52,3 +54,47 @@ def test_random_chain_is_a_shuffled_prefix_with_matching_sizes():
     assert len(seen) > 5
     assert random_chain(["only"]) == ["only"]
     assert random_chain(["only"], size_list=[7]) == (["only"], [7])
+
+
+def _write_nrrd(path, arr, encoding="raw", type_name=None, endian="little"):
+    import gzip
+    names = {"float32": "float", "int16": "short", "uint8": "unsigned char", "float64": "double"}
+    body = arr.astype(arr.dtype.newbyteorder("<" if endian == "little" else ">")).tobytes()
+    if encoding == "gzip":
+        body = gzip.compress(body)
+    head = ("NRRD0004\n# comment line\ntype: %s\ndimension: %d\nspace: left-posterior-superior\nsizes: %s\n"
+            "kinds: %s\nendian: %s\nencoding: %s\n\n") % (type_name or names[str(arr.dtype)], arr.ndim,
+                                                          " ".join(str(s) for s in arr.shape[::-1]),
+                                                          " ".join(["domain"] * arr.ndim), endian, encoding)
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii") + body)
+
+
+def test_nrrd_reader_and_image_loading(tmp_path):
+    """Caller utilities of the README usage (utils.py:13-96) without SimpleITK: NRRD (raw / gzip, both byte orders),
+    slice + centre crop + min-max rescale, per-sample intensity rescaling."""
+    from advchain_amd.common.utils import check_dir, load_image_label, read_nrrd, rescale_intensity
+    rng = np.random.default_rng(0)
+    vol = (rng.random((10, 27, 22)) * 900 - 100).astype(np.float32)          # [D, H, W] like the example volume (x fastest)
+    lab = (rng.random((10, 27, 22)) * 4).astype(np.int16)
+    _write_nrrd(tmp_path / "img.nrrd", vol)
+    _write_nrrd(tmp_path / "img_be.nrrd", vol, encoding="gzip", endian="big")
+    _write_nrrd(tmp_path / "lab.nrrd", lab, encoding="gzip")
+    a, hdr = read_nrrd(str(tmp_path / "img.nrrd"))
+    assert a.shape == (10, 27, 22) and a.dtype == np.float32 and np.array_equal(a, vol)
+    assert hdr["sizes"] == "22 27 10" and hdr["encoding"] == "raw"
+    assert np.array_equal(read_nrrd(str(tmp_path / "img_be.nrrd"))[0], vol)
+    assert np.array_equal(read_nrrd(str(tmp_path / "lab.nrrd"))[0], lab)
+    img, seg = load_image_label(str(tmp_path / "img.nrrd"), str(tmp_path / "lab.nrrd"), slice_id=5, crop_size=(16, 12))
+    ref = vol[5][5:21, 5:17]
+    assert img.shape == (16, 12) and np.allclose(img, (ref - ref.min()) / (ref.max() - ref.min() + 1e-10))
+    assert np.array_equal(seg, lab[5][5:21, 5:17])
+    stack = load_image_label(str(tmp_path / "img.nrrd"), slice_id=-1, crop_size=(16, 12))
+    assert stack.shape == (10, 16, 12) and float(stack.min()) == 0.0 and abs(float(stack.max()) - 1.0) < 1e-6
+    x = torch.rand(3, 2, 5, 7) * 40 - 7
+    y = rescale_intensity(x, 0, 1)
+    assert y.shape == x.shape and torch.allclose(y.amin(dim=(2, 3)), torch.zeros(3, 2)) and torch.allclose(y.amax(dim=(2, 3)), torch.ones(3, 2))
+    assert check_dir(str(tmp_path)) == 1 and check_dir(str(tmp_path / "new"), create=True) == -1 and check_dir(str(tmp_path / "new")) == 1
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.nrrd").write_bytes(b"not a volume")
+        read_nrrd(str(tmp_path / "bad.nrrd"))
