@@ -13,6 +13,8 @@
 
 namespace advchain {
 
+constexpr int kMaxStageRows = 256;   // rows of the staged region covered by the per-workgroup offset table
+
 struct GTile {
   int t0, t1, t2;   // output tile (z, y, x); t2 % 4 == 0
   int h0, h1, h2;   // halo; h2 % 4 == 0
@@ -42,35 +44,57 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int plane = rw * rh * rd;       // floats per staged channel
   const float* inn = in + (int64_t)n * C * V;
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
+  // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane.  Staged row R = (c * rd + lz) * rh + ly
+  // sits at lds + R * rw; its global offset comes from a table built once per workgroup, and a thread keeps its quad
+  // column: no integer division per staged quad (three of them were 31 % of this kernel's VALU instructions)
   const int rows = C * rd * rh;
-  if (!unaligned) {
-    for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
-      const int q = e % rw4;
-      const int r = e / rw4;
-      const int ly = r % rh;
-      const int r2 = r / rh;
-      const int lz = r2 % rd;
-      const int c = r2 / rd;
-      const float4 v = *reinterpret_cast<const float4*>(inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q);
-      *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+  __shared__ long long s_row[kMaxStageRows];
+  const bool table = rows <= kMaxStageRows;
+  if (table) {
+    for (int R = threadIdx.x; R < rows; R += kBlock) {
+      const int r2 = R / rh, ly = R - r2 * rh;
+      const int c = r2 / rd, lz = r2 - c * rd;
+      s_row[R] = (long long)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0;
+    }
+    __syncthreads();
+    const int rsub = threadIdx.x / rw4, q = threadIdx.x - rsub * rw4;
+    const int rstep = kBlock / rw4;
+    if (rsub < rstep) {
+      if (!unaligned) {
+        for (int R = rsub; R < rows; R += rstep)
+          *reinterpret_cast<float4*>(lds + R * rw + 4 * q) = *reinterpret_cast<const float4*>(inn + s_row[R] + 4 * q);
+      } else {
+        // rows not 16-byte aligned (S2 % 4 != 0 or a misaligned base): dword loads, partial last quad padded with zeros
+        const int left = rx1 - rx0 - 4 * q;
+        for (int R = rsub; R < rows; R += rstep) {
+          const float* src = inn + s_row[R] + 4 * q;
+          float4 v;
+          v.x = src[0];
+          v.y = left > 1 ? src[1] : 0.f;
+          v.z = left > 2 ? src[2] : 0.f;
+          v.w = left > 3 ? src[3] : 0.f;
+          *reinterpret_cast<float4*>(lds + R * rw + 4 * q) = v;
+        }
+      }
     }
   } else {
-    // rows not 16-byte aligned (S2 % 4 != 0 or a misaligned base): dword loads, partial last quad padded with zeros
     for (int e = threadIdx.x; e < rows * rw4; e += kBlock) {
       const int q = e % rw4;
-      const int r = e / rw4;
-      const int ly = r % rh;
-      const int r2 = r / rh;
-      const int lz = r2 % rd;
-      const int c = r2 / rd;
+      const int R = e / rw4;
+      const int r2 = R / rh, ly = R - r2 * rh;
+      const int c = r2 / rd, lz = r2 - c * rd;
       const float* src = inn + (int64_t)c * V + ((rz0 + lz) * d.s1 + (ry0 + ly)) * d.s2 + rx0 + 4 * q;
-      const int left = rx1 - rx0 - 4 * q;
+      const int left = unaligned ? rx1 - rx0 - 4 * q : 4;
       float4 v;
-      v.x = src[0];
-      v.y = left > 1 ? src[1] : 0.f;
-      v.z = left > 2 ? src[2] : 0.f;
-      v.w = left > 3 ? src[3] : 0.f;
-      *reinterpret_cast<float4*>(lds + c * plane + (lz * rh + ly) * rw + 4 * q) = v;
+      if (!unaligned) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        v.y = left > 1 ? src[1] : 0.f;
+        v.z = left > 2 ? src[2] : 0.f;
+        v.w = left > 3 ? src[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(lds + R * rw + 4 * q) = v;
     }
   }
   __syncthreads();
