@@ -27,8 +27,10 @@ constexpr int kWinCells = 8192;         // LDS window budget in cells (all chann
 template <int PAD, int C, bool SELF, bool GG>
 __global__ void __launch_bounds__(kBlock)
 k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
-                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n2, int clamp_grid) {
+                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n2, int clamp_grid,
+                   int32_t* __restrict__ ws) {
   __shared__ int win[kWinCells];
+  if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
   __shared__ int red[8][kBlock / 64];
   constexpr int DIM = 2;
   constexpr int SPT = kWinT * kWinT / kBlock;   // samples per thread (4)
@@ -161,8 +163,10 @@ constexpr int kWin3Cells = 12288;        // 48 KiB of LDS: 3 workgroups per CU
 template <int PAD, int C, bool SELF, bool GG>
 __global__ void __launch_bounds__(kBlock)
 k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
-                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid) {
+                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid,
+                   int32_t* __restrict__ ws) {
   __shared__ int win[kWin3Cells];
+  if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
   __shared__ int red[7][kBlock / 64];
   constexpr int DIM = 3;
   const int V = (int)d.voxels();
@@ -311,7 +315,8 @@ using namespace advchain;
 
 // grad_in (and, for SELF, the same tensor) is zero-filled here.  2D: every displacement the gather form does not take.
 // 3D: only from the displacement hint |halo| >= ADVCHAIN_WINDOW3D_MIN_HALO up (below it the owner-computes tiles win).
-// A chained workspace is told that this launch left no max|result| behind (header [3] = -1: see scatter_tiled.hip).
+// A chained workspace is told (by the kernel itself) that this launch left no max|result| behind (header [3] = -1:
+// see scatter_tiled.hip).
 // Returns ADVCHAIN_ERR_UNSUPPORTED for what the kernels do not cover (the caller keeps the owner-computes tiles).
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
@@ -322,7 +327,6 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (ndim == 3 && (halo < 0 ? -halo : halo) < min3) return ADVCHAIN_ERR_UNSUPPORTED;
   (void)hipMemsetAsync(gin, 0, sizeof(float) * N * C * d.voxels(), st);
-  if (workspace) (void)hipMemsetAsync(workspace + 3, 0xFF, sizeof(int32_t), st);
   const bool gg = ggrid != nullptr;
   dim3 b(kBlock);
 #define GO_PAD(C_, SELF_, GG_) \
@@ -338,14 +342,14 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
     const int n2 = (d.s2 + kWinT - 1) / kWinT, n1 = (d.s1 + kWinT - 1) / kWinT;
     dim3 g((unsigned)(n1 * n2), (unsigned)N);
 #define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid)
+  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid, workspace)
     GO_ALL(2);
 #undef GO
   } else {
     const int n2 = (d.s2 + kWin3X - 1) / kWin3X, n1 = (d.s1 + kWin3Y - 1) / kWin3Y, n0 = (d.s0 + kWin3Z - 1) / kWin3Z;
     dim3 g((unsigned)(n0 * n1 * n2), (unsigned)N);
 #define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid)
+  hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace)
     GO_ALL(3);
 #undef GO
   }
