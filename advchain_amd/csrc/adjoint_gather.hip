@@ -101,8 +101,11 @@ template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
 __global__ void __launch_bounds__(NT)
 k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                  float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int wide, int flags,
-                 float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap) {
+                 float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap,
+                 int32_t* __restrict__ untracked) {
   using G = GatherCfg<DIM, C, H, SELF, GG, TZ, TY, NT>;
+  // strict launches of a chain do not track max|result|: say so in the workspace header (see scatter_tiled.hip)
+  if (untracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) untracked[3] = -1;
   constexpr int RY = G::RY, ROWS = G::ROWS, NW = G::NW, RPW = G::RPW;
   constexpr int OG = DIM, OI = DIM + C;   // first grad_out / input channel in LDS
   // [CH][ROWS][64]: channels 0..DIM-1 hold o = unnormalize(grid) - s (unclipped offset of the sampling position from
@@ -471,12 +474,12 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
     // the caller guarantees the displacement bound (measured): no sample can be irregular, so there is no overflow
     // list to reset or drain and the whole step is this one launch
     hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid,
-                       d, n1, n2, wide, flags, (float*)nullptr, (int*)nullptr, (int2*)nullptr, 0);
+                       d, n1, n2, wide, flags, (float*)nullptr, (int*)nullptr, (int2*)nullptr, 0, SELF ? ws : (int32_t*)nullptr);
     return;
   }
   hipLaunchKernelGGL(k_gather_prepare, dim3(1), dim3(1), 0, st, ws, chain);
   hipLaunchKernelGGL(kern, dim3((unsigned)(n0 * n1 * n2), (unsigned)N), dim3(NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
-                     n1, n2, wide, flags, amax_out, cnt, list, cap);
+                     n1, n2, wide, flags, amax_out, cnt, list, cap, (int32_t*)nullptr);
   if (border) hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_BORDER>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,
                                  clamp_grid, cnt, list, cap, amax_out);
   else hipLaunchKernelGGL((k_gather_overflow<DIM, PAD_ZEROS>), dim3(16), dim3(kBlock), 0, st, gout, grid, gin, C, d,

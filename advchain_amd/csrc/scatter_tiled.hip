@@ -382,7 +382,8 @@ static bool launch_rows_c(int C, bool self, bool need_ggrid, dim3 g, size_t lds,
 }
 
 // Shared entry used by advchain_grid_sample_bwd / advchain_compose_self_bwd.
-// workspace (int32): [0] overflow counter, [1] pad, [2] max|grad_out| (float), [3] max|result| (float),
+// workspace (int32): [0] overflow counter, [1] flag "max|grad_out| still to be computed", [2] max|grad_out| (float),
+//                    [3] max|result| (float; the int -1 when the producing launch did not track it),
 //                    [4..] (n, s) overflow pairs.
 // chain = 0: max|grad_out| is computed here (one streaming pass over grad_out);
 // chain = 1: the previous launch on this workspace produced grad_out and left max|grad_out| in [3]

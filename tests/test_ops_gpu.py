@@ -257,6 +257,9 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
         # exact bound (negative halo): single launch without the overflow list, same numbers
         g1s = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-halo)
         assert torch.equal(g1, g1s)
+        # ... and a chained owner-computes step after it (the strict launch left no max|grad| behind: found on device)
+        g2s = ops.raw_compose_self_bwd(g1s, pd, ws, chain=True, halo=0)
+        assert maxdiff(g2s.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
 
 
 def _smooth_field(dims, amp_vox, seed):
