@@ -97,8 +97,9 @@ __device__ __forceinline__ void coord_grad_global(const float* __restrict__ inn,
 
 // SELF : in == grid == phi (C == DIM); gin receives value path + coordinate path      (advchain_compose_self_bwd)
 // !SELF: gin <- value path; GG: ggrid <- coordinate path (needs `in`, staged as well)  (advchain_grid_sample_bwd)
+// (3D: two 8-wave workgroups per CU = 4 waves per SIMD = at most 128 VGPRs)
 template <int DIM, int C, int H, bool SELF, bool GG, int TZ, int TY, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, (DIM == 3 && NT == 512) ? 4 : 1)
 k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                  float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int wide, int flags,
                  float* __restrict__ absmax_out, int* __restrict__ ovf_count, int2* __restrict__ ovf_list, int ovf_cap,
@@ -212,9 +213,13 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
   const float xlo = -(float)sx, xhi = (float)(d.s2 - 1 - sx);   // clip bounds of a sample in this lane, as offsets
   float* ginn = gin + (int64_t)n * C * V;
   float m = 0.f;
+  // 3D, H = 1: a wave owns two rows ADJACENT in y and runs phase B for both at once -- they share 6 of their 9
+  // neighbour rows each, so a staged row is read, clipped and given its x / z tents once for the pair
+  constexpr bool PAIR = DIM == 3 && H == 1 && RPW == 2 && TY % 2 == 0;
+  float ggs[PAIR ? 2 : 1][3];
 #pragma unroll
   for (int j = 0; j < RPW; ++j) {
-    const int o = wave + j * NW;
+    const int o = PAIR ? RPW * wave + j : wave + j * NW;
     const int ly = o % TY, lz = o / TY;
     const int uy = y0 + ly, uz = z0 + lz;
     if (uy >= d.s1 || uz >= d.s0) continue;   // wave-uniform
@@ -310,6 +315,10 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
       }
     }
 
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) ggs[j][a] = gg[a];
+    } else {
     // ---- phase B: gather the deposits of the (2H+1)^d neighbouring samples
     float acc[C][2 * H + 1];
 #pragma unroll
@@ -358,6 +367,74 @@ k_adjoint_gather(const float* __restrict__ gout, const float* __restrict__ in, c
       float* gq = ggrid + (int64_t)n * DIM * V + s;
 #pragma unroll
       for (int a = 0; a < DIM; ++a) gq[(int64_t)a * V] = gg[a];
+    }
+    }   // !PAIR
+  }
+  if constexpr (PAIR) {
+    const int o0 = RPW * wave;
+    const int ly0 = o0 % TY, lz = o0 / TY;
+    const int uy0 = y0 + ly0, uz = z0 + lz;
+    if (uy0 < d.s1 && uz < d.s0) {   // wave-uniform
+      const int rc0 = (lz + H) * RY + ly0 + H;
+      float acc[2][C][3];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[o][c][k] = 0.f;
+#pragma unroll
+      for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int yy = -1; yy <= 2; ++yy) {
+          // sample row (uz + dz, uy0 + yy): output row uy0 + o sits at offset (-dz, o - yy) from it
+          const int r = rc0 + dz * RY + yy;
+          float fx = lds[(0 * ROWS + r) * 64 + lane];
+          float fy = lds[(1 * ROWS + r) * 64 + lane];
+          float fz = lds[(2 * ROWS + r) * 64 + lane];
+          if (clip) {
+            fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
+            fy = __builtin_amdgcn_fmed3f(fy, -(float)(uy0 + yy), (float)(d.s1 - 1 - uy0 - yy));   // wave-uniform bounds
+            fz = __builtin_amdgcn_fmed3f(fz, -(float)(uz + dz), (float)(d.s0 - 1 - uz - dz));
+          }
+          const float wz = fmaxf(0.f, 1.f - fabsf(fz + (float)dz));
+          const float t[3] = {tent<-1>(fx), tent<0>(fx), tent<1>(fx)};
+          float g[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) g[c] = lds[((OG + c) * ROWS + r) * 64 + lane] * wz;
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            const int dy = yy - o;
+            if (dy < -1 || dy > 1) continue;   // compile time
+            const float wy = fmaxf(0.f, 1.f - fabsf(fy + (float)dy));
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const float a = g[c] * wy;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) acc[o][c][k] = fmaf(a, t[k], acc[o][c][k]);
+            }
+          }
+        }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (uy0 + o >= d.s1) continue;   // wave-uniform
+        const int s = (uz * d.s1 + uy0 + o) * d.s2 + sx;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float up = lane_prev_f(acc[o][c][2]) + acc[o][c][1];   // deposits on x + 1, folded into the owner
+          float v = up + lane_next_f(acc[o][c][0]);                   // deposits on x - 1
+          if (SELF) v += ggs[o][c < 3 ? c : 0];
+          if (xowned) {
+            ginn[(int64_t)c * V + s] = v;
+            m = fmaxf(m, fabsf(v));
+          }
+        }
+        if (!SELF && GG && xowned) {
+          float* gq = ggrid + (int64_t)n * DIM * V + s;
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) gq[(int64_t)a * V] = ggs[o][a];
+        }
+      }
     }
   }
   if (SELF && absmax_out) {
