@@ -42,6 +42,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int rw = tc.rw, rh = ry1 - ry0, rd = rz1 - rz0;
   const int rw4 = (rx1 - rx0 + 3) >> 2;
   const int plane = rw * rh * rd;       // floats per staged channel
+  const int rhw = rh * rw;
   const float* inn = in + (int64_t)n * C * V;
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane
   // ---- stage: C channels x rd x rh rows of (rx1-rx0) floats, 16 bytes per lane.  Staged row R = (c * rd + lz) * rh + ly
@@ -117,10 +118,10 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
   for (int i = threadIdx.x; i < items; i += kBlock) {
     {
       const int sx = x0 + lx, sy = y0 + ly, sz = z0 + lz;
-      const int s = (sz * d.s1 + sy) * d.s2 + sx;
+      const int s = __mul24(__mul24(sz, d.s1) + sy, d.s2) + sx;     // launcher: rows and row length below 2^23
       float gx, gy, gz = 0.f;
       if (SELF) {
-        const int lo = ((sz - rz0) * rh + (sy - ry0)) * rw + (sx - rx0);
+        const int lo = __mul24(sz - rz0, rhw) + __mul24(sy - ry0, rw) + (sx - rx0);
         gx = lds[lo];
         gy = lds[plane + lo];
         if (DIM == 3) gz = lds[2 * plane + lo];
@@ -140,16 +141,22 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
                           (cx0 <= cx1) && (cy0 <= cy1) && (cz0 <= cz1);
       float res[C];
       if (staged) {
+        // tile-local offsets: 24-bit multiplies (full rate; a 32-bit v_mul_lo costs four VALU slots)
         const int ox[2] = {cx0 - rx0, cx1 - rx0};
-        const int oy[2] = {(cy0 - ry0) * rw, (cy1 - ry0) * rw};
-        const int oz[2] = {(cz0 - rz0) * rh * rw, (cz1 - rz0) * rh * rw};
+        const int oy[2] = {__mul24(cy0 - ry0, rw), __mul24(cy1 - ry0, rw)};
+        const int oz[2] = {__mul24(cz0 - rz0, rhw), __mul24(cz1 - rz0, rhw)};
         float w[8];
 #pragma unroll
         for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
           for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx) w[(cz * 2 + cy) * 2 + cx] = t.ok(cz, cy, cx) ? t.w(cz, cy, cx) : 0.f;
+            for (int cx = 0; cx < 2; ++cx) {
+              // border padding: the coordinate is clipped into the volume, so a corner beyond it carries weight 0
+              // already (its index is clamped above): no validity select
+              const float wt = t.w(cz, cy, cx);
+              w[(cz * 2 + cy) * 2 + cx] = (PAD == PAD_BORDER || t.ok(cz, cy, cx)) ? wt : 0.f;
+            }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const float* p = lds + c * plane;
@@ -195,7 +202,7 @@ using namespace advchain;
 static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& tc) {
   static const int h3 = getenv("ADVCHAIN_GTILE_H3") ? atoi(getenv("ADVCHAIN_GTILE_H3")) : 1;   // tuning knobs
   static const int h2 = getenv("ADVCHAIN_GTILE_H2") ? atoi(getenv("ADVCHAIN_GTILE_H2")) : 8;
-  if (d.s2 < 8) return false;
+  if (d.s2 < 8 || d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return false;   // 24-bit index products
   static const bool tiles_2d = getenv("ADVCHAIN_GTILE_2D") != nullptr;
   if (ndim == 2 && !tiles_2d) return false;   // measured: in 2D (4 corners) the direct 4-chain gather kernels are faster
   int h = ndim == 3 ? h3 : h2;
