@@ -105,21 +105,26 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
     if (!live[j]) continue;
     const int sy = ty * kWinT + ly0 + 8 * j;
     const int s = sy * d.s2 + sx;
+    const int wx0 = t[j].x.i0 - bx0, wy0 = t[j].y.i0 - by0;
+    const int cell0 = __mul24(wy0, ww) + wx0;                          // corner (0,0); the others are +1, +ww away
+    const int vox0 = __mul24(t[j].y.i0, d.s2) + t[j].x.i0;
+    const bool inx[2] = {wx0 >= 0 && wx0 < ww, wx0 + 1 >= 0 && wx0 + 1 < ww};
+    const bool iny[2] = {wy0 >= 0 && wy0 < wh, wy0 + 1 >= 0 && wy0 + 1 < wh};
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
       for (int cx = 0; cx < 2; ++cx) {
         if (!t[j].ok(0, cy, cx)) continue;
-        const int ux = t[j].x.i0 + cx, uy = t[j].y.i0 + cy;
         const float w = t[j].w(0, cy, cx);
-        const int wx = ux - bx0, wy = uy - by0;
-        if (wx >= 0 && wx < ww && wy >= 0 && wy < wh) {
+        if (inx[cx] && iny[cy]) {
           const float ws = w * scale;
+          int* cell = win + cell0 + (cy ? ww : 0) + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(win + c * cells + wy * ww + wx, __float2int_rn(ws * go[j][c]));
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[j][c]));
         } else {
+          float* dst = ginn + vox0 + (cy ? d.s2 : 0) + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomic_add_f32(ginn + (int64_t)c * V + uy * d.s2 + ux, w * go[j][c]);
+          for (int c = 0; c < C; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[j][c]);
         }
       }
     if (SELF || GG) {
@@ -254,6 +259,15 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     float go[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) go[c] = gon[(int64_t)c * V + s];
+    // window cell / voxel of corner (0,0,0) once (24-bit multiplies: a 32-bit v_mul_lo costs four VALU slots); the
+    // other corners are +1, +ww, +plane away
+    const int wx0 = t.x.i0 - lo[0], wy0 = t.y.i0 - lo[1], wz0 = t.z.i0 - lo[2];
+    const int cell0 = __mul24(wz0, plane) + __mul24(wy0, ww) + wx0;
+    const int vox0 = __mul24(__mul24(t.z.i0, d.s1) + t.y.i0, d.s2) + t.x.i0;
+    const int rowv = d.s2, planev = __mul24(d.s1, d.s2);
+    const bool inx[2] = {wx0 >= 0 && wx0 < ww, wx0 + 1 >= 0 && wx0 + 1 < ww};
+    const bool iny[2] = {wy0 >= 0 && wy0 < wh, wy0 + 1 >= 0 && wy0 + 1 < wh};
+    const bool inz[2] = {wz0 >= 0 && wz0 < wd, wz0 + 1 >= 0 && wz0 + 1 < wd};
 #pragma unroll
     for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
@@ -261,16 +275,14 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 #pragma unroll
         for (int cx = 0; cx < 2; ++cx) {
           if (!t.ok(cz, cy, cx)) continue;
-          const int ux = t.x.i0 + cx, uy = t.y.i0 + cy, uz = t.z.i0 + cz;
           const float w = t.w(cz, cy, cx);
-          const int wx = ux - lo[0], wy = uy - lo[1], wz = uz - lo[2];
-          if (wx >= 0 && wx < ww && wy >= 0 && wy < wh && wz >= 0 && wz < wd) {
+          if (inx[cx] && iny[cy] && inz[cz]) {
             const float ws = w * scale;
-            int* cell = win + wz * plane + wy * ww + wx;
+            int* cell = win + cell0 + (cz ? plane : 0) + (cy ? ww : 0) + cx;
 #pragma unroll
             for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c]));
           } else {
-            float* dst = ginn + (uz * d.s1 + uy) * d.s2 + ux;
+            float* dst = ginn + vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx;
 #pragma unroll
             for (int c = 0; c < C; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[c]);
           }
@@ -324,6 +336,7 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
   static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
   static const int min3 = getenv("ADVCHAIN_WINDOW3D_MIN_HALO") ? atoi(getenv("ADVCHAIN_WINDOW3D_MIN_HALO")) : 5;
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return ADVCHAIN_ERR_UNSUPPORTED;   // 24-bit index products
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (ndim == 3 && (halo < 0 ? -halo : halo) < min3) return ADVCHAIN_ERR_UNSUPPORTED;
   (void)hipMemsetAsync(gin, 0, sizeof(float) * N * C * d.voxels(), st);
