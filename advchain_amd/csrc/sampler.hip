@@ -22,8 +22,12 @@ namespace advchain {
 // strided ownership: element k of a thread lives at p[k * kBlock]; `n` = number of valid elements
 template <int UNR>
 __device__ __forceinline__ void load_str(const float* __restrict__ p, int n, float (&r)[UNR]) {
+  // every load unconditional (a tail thread re-reads its own first element): conditional loads each get their own
+  // branch and `s_waitcnt vmcnt(0)`, i.e. one serial memory round trip per element
 #pragma unroll
-  for (int k = 0; k < UNR; ++k) r[k] = k < n ? p[k * kBlock] : 0.f;
+  for (int k = 0; k < UNR; ++k) r[k] = p[(k < n ? k : 0) * kBlock];
+#pragma unroll
+  for (int k = 0; k < UNR; ++k) r[k] = k < n ? r[k] : 0.f;
 }
 template <int UNR>
 __device__ __forceinline__ void store_str(float* __restrict__ p, int n, const float (&r)[UNR]) {

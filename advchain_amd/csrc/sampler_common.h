@@ -29,17 +29,46 @@ struct Taps {
   }
 };
 
+// Corner offsets with every index clamped into the volume: ALL corner loads of a sample are then issued
+// unconditionally and back to back, and an invalid corner's value is discarded by a select.  (With `if (ok) acc +=
+// in[off] * w` the compiler wraps every load in its own branch with an `s_waitcnt vmcnt(0)` inside: the 2D squaring
+// kernel made 32 SERIAL memory round trips per thread -- that, not instruction issue, was its "ceiling".)
+template <int DIM, int PAD>
+struct CornerOffsets {
+  int x[2], y[2], z[2];   // x index, y index * S2, z index * S1 * S2
+  __device__ __forceinline__ CornerOffsets(const Taps<DIM, PAD>& t, const Dims& d) {
+    x[0] = min(max(t.x.i0, 0), d.s2 - 1);
+    x[1] = min(max(t.x.i0 + 1, 0), d.s2 - 1);
+    y[0] = min(max(t.y.i0, 0), d.s1 - 1) * d.s2;
+    y[1] = min(max(t.y.i0 + 1, 0), d.s1 - 1) * d.s2;
+    if (DIM == 3) {
+      z[0] = min(max(t.z.i0, 0), d.s0 - 1) * (d.s1 * d.s2);
+      z[1] = min(max(t.z.i0 + 1, 0), d.s0 - 1) * (d.s1 * d.s2);
+    } else {
+      z[0] = z[1] = 0;
+    }
+  }
+  __device__ __forceinline__ int at(int cz, int cy, int cx) const { return z[cz] + y[cy] + x[cx]; }
+};
+
 template <int DIM, int PAD>
 __device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
+  const CornerOffsets<DIM, PAD> o(t, d);
+  float v[8];
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) v[(cz * 2 + cy) * 2 + cx] = in[o.at(cz, cy, cx)];
   float acc = 0.f;
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-      for (int cx = 0; cx < 2; ++cx) {
-        if (t.ok(cz, cy, cx)) acc += in[t.off(cz, cy, cx, d)] * t.w(cz, cy, cx);
-      }
+      for (int cx = 0; cx < 2; ++cx)   // a select, not a branch: control flow here would make the next sample's loads wait
+        acc = fmaf(t.ok(cz, cy, cx) ? v[(cz * 2 + cy) * 2 + cx] : 0.f, t.w(cz, cy, cx), acc);
   return acc;
 }
 
@@ -48,25 +77,36 @@ template <int DIM, int PAD, bool NEED_GIN, bool NEED_GGRID>
 __device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, float* __restrict__ gin, float go,
                                                   const Taps<DIM, PAD>& t, const Dims& d, float& ax, float& ay,
                                                   float& az) {
+  float v[8];
+  if (NEED_GGRID) {   // corner values first, unconditionally (see CornerOffsets)
+    const CornerOffsets<DIM, PAD> o(t, d);
+#pragma unroll
+    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) v[(cz * 2 + cy) * 2 + cx] = in[o.at(cz, cy, cx)];
+  }
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
       for (int cx = 0; cx < 2; ++cx) {
-        if (t.ok(cz, cy, cx)) {
-          const int o = t.off(cz, cy, cx, d);
-          if (NEED_GIN) atomic_add_f32(gin + o, t.w(cz, cy, cx) * go);
-          if (NEED_GGRID) {
-            const float val = in[o];
-            if (DIM == 3) {
-              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
-              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
-              az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
-            } else {
-              ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
-              ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
-            }
+        const bool ok = t.ok(cz, cy, cx);
+        if (NEED_GIN) {
+          if (ok) atomic_add_f32(gin + t.off(cz, cy, cx, d), t.w(cz, cy, cx) * go);
+        }
+        if (NEED_GGRID) {
+          // a select on the value, no branch: the loads of the next channel / sample must not wait behind control flow
+          const float val = ok ? v[(cz * 2 + cy) * 2 + cx] : 0.f;
+          if (DIM == 3) {
+            ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
+            ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
+            az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
+          } else {
+            ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
+            ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
           }
         }
       }
