@@ -420,20 +420,26 @@ k_gauss_axis(const float* __restrict__ in, float* __restrict__ out, const float*
   const int c = plane % C;
   const int caxis = 2 - c;  // the axis this channel's coordinate runs along
   const int ia = idx[axis];
+  // all nine taps are loaded unconditionally (index clamped into the row, the value discarded by a select): a load
+  // inside `if (in range)` gets its own branch and `s_waitcnt vmcnt(0)` -- nine serial memory round trips
+  float tap[9];
+#pragma unroll
+  for (int k = -4; k <= 4; ++k) {
+    const int jc = min(max(ia + k, 0), S[axis] - 1);
+    tap[k + 4] = in[t + (int64_t)(jc - ia) * stride];
+  }
   float acc = 0.f;
 #pragma unroll
   for (int k = -4; k <= 4; ++k) {
     const int j = ia + k;
-    if (j >= 0 && j < S[axis]) {
-      float x = in[t + (int64_t)k * stride];
-      if (PRE == 1) x *= scale;
-      if (PRE == 2) {
-        const int ci = (caxis == axis) ? j : idx[caxis];
-        float slope;
-        x = border_identity(x, S[caxis], slope) - lin_coord(ci, S[caxis]);
-      }
-      acc += gw.w[k + 4] * x;
+    float x = tap[k + 4];
+    if (PRE == 1) x *= scale;
+    if (PRE == 2) {
+      const int ci = (caxis == axis) ? j : idx[caxis];
+      float slope;
+      x = border_identity(x, S[caxis], slope) - lin_coord(ci, S[caxis]);
     }
+    acc += (j >= 0 && j < S[axis]) ? gw.w[k + 4] * x : 0.f;
   }
   if (POST == 1) acc += lin_coord(idx[caxis], S[caxis]);
   if (POST == 2) {
@@ -495,18 +501,20 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
       for (int k = 0; k < 9; ++k) acc[o] += gw.w[k] * win[o + k];
   } else if (AXIS == 2) {
     float win[12];
+    float4 qb[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {   // unconditional loads (a quad beyond the row re-reads the own quad and is discarded)
+      const int x0 = idx[2] + (b - 1) * 4;
+      qb[b] = *reinterpret_cast<const float4*>(in + t + ((x0 >= 0 && x0 < d.s2) ? (b - 1) * 4 : 0));
+    }
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       const int x0 = idx[2] + (b - 1) * 4;
-      if (x0 >= 0 && x0 < d.s2) {
-        const float4 q = *reinterpret_cast<const float4*>(in + t + (b - 1) * 4);
-        win[b * 4 + 0] = pre(q.x, idx[0], idx[1], x0);
-        win[b * 4 + 1] = pre(q.y, idx[0], idx[1], x0 + 1);
-        win[b * 4 + 2] = pre(q.z, idx[0], idx[1], x0 + 2);
-        win[b * 4 + 3] = pre(q.w, idx[0], idx[1], x0 + 3);
-      } else {
-        win[b * 4 + 0] = win[b * 4 + 1] = win[b * 4 + 2] = win[b * 4 + 3] = 0.f;
-      }
+      const bool inr = x0 >= 0 && x0 < d.s2;
+      win[b * 4 + 0] = inr ? pre(qb[b].x, idx[0], idx[1], x0) : 0.f;
+      win[b * 4 + 1] = inr ? pre(qb[b].y, idx[0], idx[1], x0 + 1) : 0.f;
+      win[b * 4 + 2] = inr ? pre(qb[b].z, idx[0], idx[1], x0 + 2) : 0.f;
+      win[b * 4 + 3] = inr ? pre(qb[b].w, idx[0], idx[1], x0 + 3) : 0.f;
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -515,17 +523,24 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
   } else {
     const int stride = AXIS == 1 ? d.s2 : d.s1 * d.s2;
     const int ia = idx[AXIS];
+    // nine unconditional 16-byte loads in flight together (row index clamped, out-of-range taps discarded by a select):
+    // inside `if (in range)` every load got its own branch and `s_waitcnt vmcnt(0)`
+    float4 q[9];
+#pragma unroll
+    for (int k = -4; k <= 4; ++k) {
+      const int jc = min(max(ia + k, 0), S[AXIS] - 1);
+      q[k + 4] = *reinterpret_cast<const float4*>(in + t + (int64_t)(jc - ia) * stride);
+    }
 #pragma unroll
     for (int k = -4; k <= 4; ++k) {
       const int j = ia + k;
-      if (j >= 0 && j < S[AXIS]) {
-        const float4 q = *reinterpret_cast<const float4*>(in + t + (int64_t)k * stride);
-        const int j0 = AXIS == 0 ? j : idx[0], j1 = AXIS == 1 ? j : idx[1];
-        acc[0] += gw.w[k + 4] * pre(q.x, j0, j1, idx[2]);
-        acc[1] += gw.w[k + 4] * pre(q.y, j0, j1, idx[2] + 1);
-        acc[2] += gw.w[k + 4] * pre(q.z, j0, j1, idx[2] + 2);
-        acc[3] += gw.w[k + 4] * pre(q.w, j0, j1, idx[2] + 3);
-      }
+      const bool inr = j >= 0 && j < S[AXIS];
+      const int j0 = AXIS == 0 ? j : idx[0], j1 = AXIS == 1 ? j : idx[1];
+      const float w = gw.w[k + 4];
+      acc[0] += inr ? w * pre(q[k + 4].x, j0, j1, idx[2]) : 0.f;
+      acc[1] += inr ? w * pre(q[k + 4].y, j0, j1, idx[2] + 1) : 0.f;
+      acc[2] += inr ? w * pre(q[k + 4].z, j0, j1, idx[2] + 2) : 0.f;
+      acc[3] += inr ? w * pre(q[k + 4].w, j0, j1, idx[2] + 3) : 0.f;
     }
   }
   if (POST == 1) {
