@@ -64,7 +64,8 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
     t[j].build(gx, gy, 0.f, d);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      go[j][c] = live[j] ? gon[(int64_t)c * V + s] : 0.f;
+      const float g = gon[(int64_t)c * V + s];     // unconditional (s = 0 for a dead sample): no branch around the load
+      go[j][c] = live[j] ? g : 0.f;
       gmax = fmaxf(gmax, fabsf(go[j][c]));
     }
     if (live[j]) {
@@ -99,6 +100,21 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
   const float scale = gmax > 0.f ? 1048576.f / gmax : 0.f;   // 2^20
   __syncthreads();
 
+  // ---- coordinate path of all four samples first: 4 x 4 x C corner loads in flight together, no control flow between
+  // them (a dead sample has grad_out 0 and valid addresses)
+  float cgx[SPT], cgy[SPT];
+  if (SELF || GG) {
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      float ax = 0.f, ay = 0.f, dummy = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, go[j][c], t[j], d, ax, ay, dummy);
+      cgx[j] = px[j] ? t[j].x.mult * ax : 0.f;
+      cgy[j] = py[j] ? t[j].y.mult * ay : 0.f;
+    }
+  }
+
   // ---- 2. deposits
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
@@ -128,11 +144,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
         }
       }
     if (SELF || GG) {
-      float ax = 0.f, ay = 0.f, dummy = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; ++c)
-        sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, go[j][c], t[j], d, ax, ay, dummy);
-      const float ggx = px[j] ? t[j].x.mult * ax : 0.f, ggy = py[j] ? t[j].y.mult * ay : 0.f;
+      const float ggx = cgx[j], ggy = cgy[j];
       if (SELF) {
         if (ggx != 0.f) atomic_add_f32(ginn + s, ggx);
         if (ggy != 0.f) atomic_add_f32(ginn + V + s, ggy);
