@@ -254,13 +254,24 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
   const float scale = gmax > 0.f ? 1048576.f / gmax : 0.f;   // 2^20
   __syncthreads();
 
-  // ---- 2. deposits
-#pragma unroll 2
+  // ---- 2. deposits.  Grid and grad_out of the four samples are requested up front (unconditionally: a dead sample
+  // reads voxel 0), so the loop below starts with its operands in flight instead of one memory round trip per sample.
+  float gpre[kWin3Z][3], gopre[kWin3Z][C];
+#pragma unroll
+  for (int j = 0; j < kWin3Z; ++j) {
+    const int sz = tz * kWin3Z + j;
+    const int s = (col_live && sz < d.s0) ? (sz * d.s1 + sy) * d.s2 + sx : 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gpre[j][a] = gn[(int64_t)a * V + s];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gopre[j][c] = gon[(int64_t)c * V + s];
+  }
+#pragma unroll
   for (int j = 0; j < kWin3Z; ++j) {
     const int sz = tz * kWin3Z + j;
     if (!(col_live && sz < d.s0)) continue;
     const int s = (sz * d.s1 + sy) * d.s2 + sx;
-    float g[3] = {gn[s], gn[V + s], gn[2 * V + s]};
+    float g[3] = {gpre[j][0], gpre[j][1], gpre[j][2]};
     bool pass[3] = {true, true, true};
     if (clamp_grid) {
 #pragma unroll
@@ -270,7 +281,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     t.build(g[0], g[1], g[2], d);
     float go[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) go[c] = gon[(int64_t)c * V + s];
+    for (int c = 0; c < C; ++c) go[c] = gopre[j][c];
     // window cell / voxel of corner (0,0,0) once (24-bit multiplies: a 32-bit v_mul_lo costs four VALU slots); the
     // other corners are +1, +ww, +plane away
     const int wx0 = t.x.i0 - lo[0], wy0 = t.y.i0 - lo[1], wz0 = t.z.i0 - lo[2];
