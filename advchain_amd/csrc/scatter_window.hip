@@ -1,4 +1,4 @@
-// Source-tiled window scatter for the sampler backward with LARGE displacements (gfx950): 2D, and 3D above 4 voxels.
+// Source-tiled window scatter for the sampler backward above the gather form's displacement bound (gfx950): 2D and 3D.
 //
 // The owner-computes tiles of scatter_tiled.hip walk a halo as wide as the largest displacement: at cfg-2 the fields
 // reach 70 px, the halo is 16 px, every sample is processed by 4 owners and what lands beyond the halo goes through
@@ -169,8 +169,9 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3D form, used above the displacement the owner-computes tiles cover without an overflow list (their halo is
-// at most 4 voxels: at cfg-5 the image-warp backward spent 1.1 ms draining the list on top of a 1.3 ms kernel).
+// 3D form.  At first it only paid above the 4-voxel halo of the owner-computes tiles (whose overflow list then explodes:
+// at cfg-5 an image-warp backward spent 1.1 ms draining it on top of a 1.3 ms kernel); with unconditional corner loads
+// it wins from one voxel up (4x128x128x64 self-composition: 207-216 us against 226-300 us for halo 2-4).
 // Tile of 4 x 8 x 32 samples (4 per thread along z); the bounding box pass keeps no taps (they are rebuilt from the
 // L1/L2-resident grid in the deposit pass: 4 x 3 axis taps per thread would not fit the register budget).
 // ---------------------------------------------------------------------------------------------
@@ -349,7 +350,8 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 using namespace advchain;
 
 // grad_in (and, for SELF, the same tensor) is zero-filled here.  2D: every displacement the gather form does not take.
-// 3D: only from the displacement hint |halo| >= ADVCHAIN_WINDOW3D_MIN_HALO up (below it the owner-computes tiles win).
+// 3D: from the displacement hint |halo| >= ADVCHAIN_WINDOW3D_MIN_HALO (default 2: everything above the gather form;
+// since the corner loads are issued unconditionally it beats the owner-computes tiles from one voxel up).
 // A chained workspace is told (by the kernel itself) that this launch left no max|result| behind (header [3] = -1:
 // see scatter_tiled.hip).
 // Returns ADVCHAIN_ERR_UNSUPPORTED for what the kernels do not cover (the caller keeps the owner-computes tiles).
@@ -357,7 +359,7 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                    int halo, int32_t* workspace, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
-  static const int min3 = getenv("ADVCHAIN_WINDOW3D_MIN_HALO") ? atoi(getenv("ADVCHAIN_WINDOW3D_MIN_HALO")) : 5;
+  static const int min3 = getenv("ADVCHAIN_WINDOW3D_MIN_HALO") ? atoi(getenv("ADVCHAIN_WINDOW3D_MIN_HALO")) : 2;
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return ADVCHAIN_ERR_UNSUPPORTED;   // 24-bit index products
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;

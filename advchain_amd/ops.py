@@ -132,7 +132,7 @@ def squaring_halo(disp, d):
         return 0                 # NaN field: nothing to tune
     if disp < 0.999:
         return -1
-    if d == 3:       # 2..4: halo of the owner-computes tiles; 8: beyond them (source-tiled window scatter)
+    if d == 3:       # >= 2: source-tiled window scatter (2..4 size the owner-computes tiles when that is switched off)
         return 2 if disp < 1.999 else (3 if disp < 2.999 else (4 if disp < 3.999 else 8))
     if disp < 1.999:
         return -2

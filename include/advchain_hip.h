@@ -58,7 +58,7 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
  * halo > 0: an upper bound on the displacement |sampling position - own voxel| in voxels (see
  * advchain_max_displacement) -- a performance hint only: small bounds (1 in 3D, <= 4 in 2D; C in {1,4}) select the
  * gather-form adjoint (no atomics), larger ones size the tile halo; samples beyond the bound stay correct through the
- * overflow list.  Bounds the tiles do not cover (2D: anything above the gather form; 3D: above 4 voxels) select the
+ * overflow list.  Bounds above the gather form (2D: any; 3D: hints >= 2, i.e. one voxel and more) select the
  * source-tiled window scatter (float atomics between tiles: summation order, ~1e-7 relative, varies run to run).
  * 0 = default tiles.  halo < 0: |halo| is exact (guaranteed by the caller): see advchain_compose_self_bwd.  */
 int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
@@ -86,8 +86,8 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * consecutive squarings), whose max|.| is already in the workspace -- saves one pass over grad_out.
  * halo > 0: an upper bound on |displacement| of phi in voxels -- a performance hint only: samples beyond it stay
  * correct through the overflow list (global atomics).  Small bounds (1 in 3D; 1..4 in 2D) select the gather-form
- * adjoint (no atomics, bit-reproducible); larger ones the LDS-tiled fixed-point scatter with that tile halo (3D, up
- * to 4 voxels) or the source-tiled window scatter (2D; 3D above 4 voxels; float atomics between tiles);
+ * adjoint (no atomics, bit-reproducible); larger ones the source-tiled window scatter (float atomics between tiles; the
+ * LDS-tiled fixed-point scatter remains for reflection padding, C = 3 image warps and ADVCHAIN_WINDOW3D_MIN_HALO);
  * 0 = default scatter tiles (halo 2 in 3D) / window scatter (2D).
  * halo < 0: |halo| is EXACT -- the caller guarantees no sample moves |halo| voxels or more on any axis (measured with
  * advchain_max_displacement / disp_out): the gather form then skips the overflow list and is a single launch; samples

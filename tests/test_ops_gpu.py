@@ -252,11 +252,15 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
     assert maxdiff(g2.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
     # deterministic
     g1b = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=halo)
+    windowed = d == 3 and halo >= 2      # 3D above one voxel: window scatter (float atomics between tiles: order-dependent)
+    if windowed:
+        assert maxdiff(g1, g1b) < 1e-5 * max(1.0, scale)
     if amp < 0.1:
-        assert torch.equal(g1, g1b)
+        if not windowed:
+            assert torch.equal(g1, g1b)
         # exact bound (negative halo): single launch without the overflow list, same numbers
         g1s = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-halo)
-        assert torch.equal(g1, g1s)
+        assert maxdiff(g1, g1s) < 1e-5 * max(1.0, scale) if windowed else torch.equal(g1, g1s)
         # ... and a chained owner-computes step after it (the strict launch left no max|grad| behind: found on device)
         g2s = ops.raw_compose_self_bwd(g1s, pd, ws, chain=True, halo=0)
         assert maxdiff(g2s.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
