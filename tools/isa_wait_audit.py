@@ -31,7 +31,7 @@ def audit(src):
                 continue
             if cur is None:
                 continue
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):      # (a kernel may contain several s_endpgm: early exits)
                 cur = None
                 continue
             if re.search(r"\b(global|buffer|flat)_load", line):
