@@ -15,11 +15,11 @@ import sys
 
 ENTRIES = {   # entry -> (regexes of the kernels an entry launch runs, regex of its MAIN kernel (one per launch))
     "advchain_grid_sample_bwd": ([r"k_scatter_rows<\d, \d, \d, false", r"k_scatter_overflow<\d, 0>", r"k_gather_overflow<\d, 0>",
-                                  r"k_adjoint_gather<\d, \d, \d, false", r"k_grid_sample_bwd<", r"k_scatter_window2d<\d, \d, false"],
-                                 r"k_scatter_rows<\d, \d, \d, false|k_adjoint_gather<\d, \d, \d, false|k_grid_sample_bwd<|k_scatter_window2d<\d, \d, false"),
+                                  r"k_adjoint_gather<\d, \d, \d, false", r"k_grid_sample_bwd<", r"k_scatter_window[23]d<\d, \d, false"],
+                                 r"k_scatter_rows<\d, \d, \d, false|k_adjoint_gather<\d, \d, \d, false|k_grid_sample_bwd<|k_scatter_window[23]d<\d, \d, false"),
     "advchain_compose_self_bwd": ([r"k_scatter_rows<\d, 1, \d, true", r"k_scatter_overflow<\d, 1>", r"k_gather_overflow<\d, 1>",
-                                   r"k_adjoint_gather<\d, \d, \d, true", r"k_compose_self_bwd<", r"k_scatter_window2d<\d, \d, true"],
-                                  r"k_scatter_rows<\d, 1, \d, true|k_adjoint_gather<\d, \d, \d, true|k_compose_self_bwd<|k_scatter_window2d<\d, \d, true"),
+                                   r"k_adjoint_gather<\d, \d, \d, true", r"k_compose_self_bwd<", r"k_scatter_window[23]d<\d, \d, true"],
+                                  r"k_scatter_rows<\d, 1, \d, true|k_adjoint_gather<\d, \d, \d, true|k_compose_self_bwd<|k_scatter_window[23]d<\d, \d, true"),
     "advchain_compose_self_fwd": ([r"k_compose_self_fwd<", r"k_sample_tiled<\d, 1, \d, true>"],
                                   r"k_compose_self_fwd<|k_sample_tiled<\d, 1, \d, true>"),
     "advchain_grid_sample_fwd": ([r"k_grid_sample_fwd<", r"k_sample_tiled<\d, \d, \d, false>"],
