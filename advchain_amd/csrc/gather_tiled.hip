@@ -131,6 +131,13 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
         if (DIM == 3) gz = gn[2 * (int64_t)V + s];
       }
       if (clamp_grid) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
+      // final mode: phi0 of all channels requested here, together (one memory round trip, overlapped with the taps;
+      // loaded where they are used they were three serial ones)
+      float p0v[C];
+      if (SELF && final_mode == 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) p0v[c] = phi0[((int64_t)n * DIM + c) * V + s];
+      }
       Taps<DIM, PAD> t;
       t.build(gx, gy, gz, d);
       // corner box clamped to the volume; inside the staged region?
@@ -178,7 +185,7 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
         float o = res[c];
         if (SELF && final_mode == 1) {
           // (sample - phi0) + identity   (adv_morph.py:143,176 + 474,483)
-          const float p0 = phi0[((int64_t)n * DIM + c) * V + s];
+          const float p0 = p0v[c];
           o = (o - p0) + (c == 0 ? lin_coord(sx, d.s2) : (c == 1 ? lin_coord(sy, d.s1) : lin_coord(sz, d.s0)));
         }
         on[(int64_t)c * V + s] = o;

@@ -194,6 +194,12 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
   load_str<VEC>(pn + v, na, gx);
   load_str<VEC>(pn + V + v, na, gy);
   if (DIM == 3) load_str<VEC>(pn + 2 * V + v, na, gz);
+  // final mode: phi0 is requested with the own values (in flight while the taps are built), not after the gathers
+  float p0[DIM][VEC];
+  if (final_mode == 1) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, p0[c]);
+  }
   Taps<DIM, PAD_BORDER> t[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) t[k].build(gx[k], gy[k], DIM == 3 ? gz[k] : 0.f, d);
@@ -207,8 +213,6 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
   if (final_mode == 1) {
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      float p0[VEC];
-      load_str<VEC>(phi0 + ((int64_t)n * DIM + c) * V + v, na, p0);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const int64_t vv = v + (int64_t)k * kBlock;
@@ -217,7 +221,7 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
         if (c == 0) { idx = (int)(vv % d.s2); S = d.s2; }
         else if (c == 1) { idx = (int)((vv / d.s2) % d.s1); S = d.s1; }
         else { idx = (int)(vv / ((int64_t)d.s2 * d.s1)); S = d.s0; }
-        r[c][k] = (r[c][k] - p0[k]) + lin_coord(idx, S);
+        r[c][k] = (r[c][k] - p0[c][k]) + lin_coord(idx, S);
       }
     }
   }
