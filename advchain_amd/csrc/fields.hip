@@ -104,10 +104,18 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
       if (i1 < i1_end) {
         const int s1 = A1.start[i1];
         const float* w1 = A1.w + i1 * A1.B;
-        for (int a = 0; a < A0.B; ++a) {
-          float acc1 = 0.f;
-          for (int b = 0; b < A1.B; ++b) acc1 += w1[b] * coef[((int64_t)(s0 + a) * A1.g + (s1 + b)) * g2 + k];
-          acc += w0[a] * acc1;
+        if (A0.B == 2 && A1.B == 2) {   // linear upsampling (uniform): the four terms' loads in flight together
+          const float* cb = coef + ((int64_t)s0 * A1.g + s1) * g2 + k;
+          const float c00 = cb[0], c01 = cb[g2], c10 = cb[(int64_t)A1.g * g2], c11 = cb[(int64_t)A1.g * g2 + g2];
+          const float u0 = w1[0], u1 = w1[1], v0 = w0[0], v1 = w0[1];
+          acc += v0 * (0.f + u0 * c00 + u1 * c01);
+          acc += v1 * (0.f + u0 * c10 + u1 * c11);
+        } else {
+          for (int a = 0; a < A0.B; ++a) {
+            float acc1 = 0.f;
+            for (int b = 0; b < A1.B; ++b) acc1 += w1[b] * coef[((int64_t)(s0 + a) * A1.g + (s1 + b)) * g2 + k];
+            acc += w0[a] * acc1;
+          }
         }
       }
       lds[e] = acc;
