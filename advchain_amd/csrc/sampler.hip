@@ -517,6 +517,8 @@ __global__ void k_affine_geometry(const float* __restrict__ theta, float* __rest
   mode[n] = ok ? 0 : 1;
 }
 
+constexpr int kGatherCand = 12;   // listed candidates per voxel (LDS column); the rest are accumulated where found
+
 template <int DIM, int CMAX>
 __global__ void __launch_bounds__(kBlock)
 k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ theta, const float* __restrict__ geo,
@@ -562,6 +564,11 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
   const float* gon = gout + (int64_t)n * C * V;
+  // Two passes: the candidates (sample index, weight) are first listed in a per-thread LDS column, then their grad_out
+  // values are loaded four at a time, unconditionally.  Loading each candidate where it is found made the loop
+  // load -> wait -> accumulate: 8-16 serial memory round trips per voxel.
+  __shared__ int2 cand[kGatherCand][kBlock];
+  int nc = 0;
   for (int vz = zlo; vz <= zhi; ++vz)
     for (int vy = ylo; vy <= yhi; ++vy) {
       // slab tests along x: |M[r][0] vx + k_r| < 1 for every output axis r
@@ -588,11 +595,35 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
         if (DIM == 3) w *= fmaxf(0.f, 1.f - fabsf(((gz + 1.f) * 0.5f) * (float)(d.s0 - 1) - (float)uz));
         if (!(w > 0.f)) continue;
         const int v = (vz * d.s1 + vy) * d.s2 + vx;
+        if (nc < kGatherCand) {
+          cand[nc][threadIdx.x] = make_int2(v, __float_as_int(w));
+          ++nc;
+        } else {      // more candidates than the column holds (strong minification): the old way
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-          if (c < C) acc[c] += w * gon[(int64_t)c * V + v];
+          for (int c = 0; c < CMAX; ++c)
+            if (c < C) acc[c] += w * gon[(int64_t)c * V + v];
+        }
       }
     }
+  for (int i0 = 0; i0 < nc; i0 += 4) {
+    int vi[4];
+    float wi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int2 e = cand[min(i0 + k, nc - 1)][threadIdx.x];
+      vi[k] = e.x;
+      wi[k] = i0 + k < nc ? __int_as_float(e.y) : 0.f;
+    }
+    float val[4][CMAX];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) val[k][c] = gon[(int64_t)(c < C ? c : 0) * V + vi[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) acc[c] += wi[k] > 0.f ? wi[k] * val[k][c] : 0.f;
+  }
 #pragma unroll
   for (int c = 0; c < CMAX; ++c)
     if (c < C) ginn[(int64_t)c * V] = acc[c];
