@@ -567,7 +567,10 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
   // Two passes: the candidates (sample index, weight) are first listed in a per-thread LDS column, then their grad_out
   // values are loaded four at a time, unconditionally.  Loading each candidate where it is found made the loop
   // load -> wait -> accumulate: 8-16 serial memory round trips per voxel.
-  __shared__ int2 cand[kGatherCand][kBlock];
+  __shared__ int2 cand[CMAX > 1 ? kGatherCand : 1][kBlock];
+  float minv[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) minv[r] = fabsf(M[r][0]) > 1e-3f ? 1.f / M[r][0] : 0.f;   // six divisions per candidate row otherwise
   int nc = 0;
   for (int vz = zlo; vz <= zhi; ++vz)
     for (int vy = ylo; vy <= yhi; ++vy) {
@@ -578,7 +581,7 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
         const float k = M[r][1] * (float)vy + M[r][2] * (float)vz - uu[r];
         const float m = M[r][0];
         if (fabsf(m) > 1e-3f) {
-          const float p = (-1.f - k) / m, q = (1.f - k) / m;
+          const float p = (-1.f - k) * minv[r], q = (1.f - k) * minv[r];   // (bounds carry 1e-3 of slack)
           lo = fmaxf(lo, fminf(p, q) - 1e-3f);
           hi = fminf(hi, fmaxf(p, q) + 1e-3f);
         }
@@ -595,7 +598,7 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
         if (DIM == 3) w *= fmaxf(0.f, 1.f - fabsf(((gz + 1.f) * 0.5f) * (float)(d.s0 - 1) - (float)uz));
         if (!(w > 0.f)) continue;
         const int v = (vz * d.s1 + vy) * d.s2 + vx;
-        if (nc < kGatherCand) {
+        if (CMAX > 1 && nc < kGatherCand) {   // one channel: a single load per candidate, listing costs more than it hides
           cand[nc][threadIdx.x] = make_int2(v, __float_as_int(w));
           ++nc;
         } else {      // more candidates than the column holds (strong minification): the old way
