@@ -153,14 +153,17 @@ k_edge_fwd(const float* __restrict__ D, const float* __restrict__ mask, float* _
         for (int a1 = 0; a1 < 3; ++a1)
 #pragma unroll
           for (int a2 = 0; a2 < 3; ++a2) {
+            // unconditional load from the clamped index, value discarded by a select outside the volume (a load
+            // inside the `if` is its own branch + s_waitcnt: 27 serial memory round trips per class)
             const int j0 = i0 + a0 - 1, j1 = i1 + a1 - 1, j2 = i2 + a2 - 1;
-            if (j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2) {
-              float wa, wb;
-              stencil_w<DIM>(a0, a1, a2, wa, wb);
-              const float x = Dk[(j0 * d.s1 + j1) * d.s2 + j2];
-              ga += wa * x;
-              gb += wb * x;
-            }
+            const bool in = j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2;
+            const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1), c2 = min(max(j2, 0), d.s2 - 1);
+            float wa, wb;
+            stencil_w<DIM>(a0, a1, a2, wa, wb);
+            const float xv = Dk[(c0 * d.s1 + c1) * d.s2 + c2];
+            const float x = in ? xv : 0.f;
+            ga += wa * x;
+            gb += wb * x;
           }
       const float ea = ga * m, eb = gb * m;
       acc[0] += ea * ea;
@@ -210,12 +213,13 @@ k_consistency_bwd(const float* __restrict__ P, const float* __restrict__ D, cons
           for (int a2 = 0; a2 < 3; ++a2) {
             // adjoint: contribution of output voxel u - delta, delta = a - 1
             const int j0 = i0 - (a0 - 1), j1 = i1 - (a1 - 1), j2 = i2 - (a2 - 1);
-            if (j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2) {
-              float wa, wb;
-              stencil_w<DIM>(a0, a1, a2, wa, wb);
-              const int q = (j0 * d.s1 + j1) * d.s2 + j2;
-              s += c_a * wa * Ra[q] + c_b * wb * Rb[q];
-            }
+            const bool in = j0 >= 0 && j0 < d.s0 && j1 >= 0 && j1 < d.s1 && j2 >= 0 && j2 < d.s2;
+            const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1), c2 = min(max(j2, 0), d.s2 - 1);
+            float wa, wb;
+            stencil_w<DIM>(a0, a1, a2, wa, wb);
+            const int q = (c0 * d.s1 + c1) * d.s2 + c2;          // unconditional loads, see k_edge_fwd
+            const float ra = Ra[q], rb = Rb[q];
+            s += in ? c_a * wa * ra + c_b * wb * rb : 0.f;
           }
       g += s;
     }
