@@ -617,3 +617,25 @@ def test_consistency_loss_row_kernels(dims):
         v.backward()
         assert abs(float(v) - float(v_ref)) < 1e-7 + 2e-5 * abs(float(v_ref))
         assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10
+
+
+@pytest.mark.parametrize("dims", [(9, 11), (5, 6, 7)])
+def test_out_of_range_corners_do_not_read_the_image(dims):
+    """Corner loads are unconditional (indices clamped into the volume) and an out-of-range corner's VALUE is
+    discarded by a select: an inf / NaN sitting at the border voxel the clamp lands on must not leak into samples that
+    fall outside the image under zeros padding (0 * inf would) -- same output and gradients as F.grid_sample."""
+    ops = _ops()
+    d = len(dims)
+    inp = rand((1, 2) + dims, 91)
+    inp[0, 0][(0,) * d] = float("inf")
+    inp[0, 1][tuple(s - 1 for s in dims)] = float("nan")
+    grid = rand((1,) + dims + (d,), 92, -1.6, 1.6)
+    grid.view(-1, d)[0] = -1.5          # fully outside, nearest voxel = the inf one
+    grid.view(-1, d)[1] = 1.5           # fully outside, nearest voxel = the NaN one
+    ref = F.grid_sample(inp, grid, padding_mode="zeros", align_corners=True)
+    out = ops.grid_sample(inp.to(DEV), to_planar(grid).to(DEV), "bilinear", "zeros")
+    r, o = ref.reshape(2, -1), out.cpu().reshape(2, -1)
+    assert float(o[0, 0]) == 0.0 and float(o[1, 1]) == 0.0 and float(r[0, 0]) == 0.0
+    fin = torch.isfinite(r)
+    assert torch.equal(torch.isfinite(o), fin)
+    assert maxdiff(o[fin], r[fin]) < TOL
