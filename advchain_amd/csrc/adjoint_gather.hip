@@ -518,6 +518,32 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement(const float* __rest
   }
 }
 
+// out[r] = max_j slots[r][j]  (NaN propagates, as torch.max does): one workgroup per row of displacement slots
+__global__ void __launch_bounds__(kBlock) k_slot_rows_max(const float* __restrict__ slots, float* __restrict__ out, int cols) {
+  const float* p = slots + (int64_t)blockIdx.x * cols;
+  float m = -3.4e38f;
+  bool nan = false;
+  for (int j = threadIdx.x; j < cols; j += kBlock) {
+    const float v = p[j];
+    nan = nan || !(v == v);
+    m = fmaxf(m, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int other = __shfl_xor((int)nan, o, 64);   // not inside `nan || ...`: a lane that short-circuits leaves the shuffle
+    nan = nan || other != 0;
+  }
+  __shared__ float sm[kBlock / 64];
+  __shared__ int sn[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sn[threadIdx.x >> 6] = nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) { m = fmaxf(m, sm[w]); nan = nan || sn[w]; }
+    out[blockIdx.x] = nan ? __int_as_float(0x7fc00000) : m;
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -641,6 +667,15 @@ extern "C" int advchain_max_displacement(const float* phi, float* out, int64_t N
   dim3 g((unsigned)blocks, (unsigned)(N * ndim));
   if (vec) hipLaunchKernelGGL((k_max_displacement<4>), g, dim3(kBlock), 0, (hipStream_t)stream, phi, out, d, ndim);
   else hipLaunchKernelGGL((k_max_displacement<1>), g, dim3(kBlock), 0, (hipStream_t)stream, phi, out, d, ndim);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+extern "C" int advchain_slot_rows_max(const float* slots, float* out, int64_t rows, int64_t cols, void* stream) {
+  ADVCHAIN_CHECK_ARG(slots && out, "slot_rows_max: null pointer");
+  ADVCHAIN_CHECK_ARG(rows >= 0 && rows < 65536 && cols >= 1 && cols < (1ll << 31), "slot_rows_max: bad shape");
+  if (rows == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_slot_rows_max, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -123,6 +123,14 @@ def raw_max_displacement(phi):
     return out
 
 
+def raw_slot_rows_max(slots):
+    """Row maxima of a (rows, slots) displacement accumulator (torch.max(dim=1) semantics incl. NaN)."""
+    out = torch.empty(slots.shape[0], device=slots.device, dtype=torch.float32)
+    _lib.check(_lib.load().advchain_slot_rows_max(_ptr(slots), _ptr(out), slots.shape[0], slots.shape[1], _stream()),
+               "slot_rows_max")
+    return out
+
+
 def squaring_halo(disp, d):
     """Displacement bound for the backward of one squaring from the MEASURED displacement of its input (voxels).
     Negative = exact (the gather-form adjoint then needs no overflow list): the measurement uses the kernels' own
@@ -489,7 +497,7 @@ class _DemonsField(torch.autograd.Function):
         pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1, disp_out=row(n))
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
-        ctx.disp = None if disp is None else _Readback(disp.max(dim=1).values)
+        ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp))
         global _LAST_FIELD_BOUND
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)

@@ -191,6 +191,12 @@ def test_displacement_measurements(dims):
     slots = torch.zeros(ops.DISP_SLOTS, device=DEV)
     out = ops.raw_compose_self_fwd(phi.to(DEV), disp_out=slots)
     assert abs(float(slots.max()) - disp_of(out.cpu())) < 1e-3
+    # row maxima of a slot tensor (torch.max(dim=1) semantics, NaN included)
+    acc = torch.rand(5, ops.DISP_SLOTS, device=DEV)
+    acc[3, 77] = float("nan")
+    got = ops.raw_slot_rows_max(acc).cpu()
+    ref = acc.max(dim=1).values.cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(got[~torch.isnan(ref)], ref[~torch.isnan(ref)])
 
 
 @pytest.mark.parametrize("dims", [(24, 40), (64, 256), (8, 12, 16), (9, 18, 64), (6, 10, 72), (21, 27), (7, 9, 50), (5, 6, 75),
