@@ -177,8 +177,11 @@ def run_gpu(args, wl, rank, world, device):
         torch.cuda.synchronize()
 
     lib = _lib.load()
-    # warm-up; the first warm-up step is instrumented on every entry point to find the dominant kernel
+    # warm-up; the first warm-up step is instrumented on every entry point to find the dominant kernel -- after one
+    # cold step of its own (first launches include code-object loading and would be booked to whichever entry runs first)
     dominant = None
+    step()
+    torch.cuda.synchronize()
     for i in range(max(1, args.warmup)):
         if i == 0:
             lib.records = []
