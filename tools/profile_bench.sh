@@ -17,5 +17,5 @@ run() {  # name, command...
 run cfg2 python $repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline
 run cfg3 python $repo/bench.py --workload cfg3 --steps 5 --warmup 2 --no-cpu-baseline
 run kb3d python $repo/tools/kernel_bench.py --shape 3d
-python $repo/tools/stats_per_call.py "$out/cfg2_kernel_stats.csv" 13 30
-python $repo/tools/stats_per_call.py "$out/cfg3_kernel_stats.csv" 7 30
+python $repo/tools/stats_per_call.py "$out/cfg2_kernel_stats.csv" 14 30
+python $repo/tools/stats_per_call.py "$out/cfg3_kernel_stats.csv" 8 30
