@@ -120,7 +120,7 @@ class AdvAffine(AdvTransformBase):
         self.affine_matrix = theta
         self._inverse_of = (theta, theta_inv)
         out = self.transform(data, theta, interp=interp, padding_mode=padding_mode)
-        self.diff = _LazyDiff(lambda o=out, d=data: d.detach() - o.detach())
+        self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): d - o)
         return out
 
     def backward(self, data, interp=None, padding_mode=None):

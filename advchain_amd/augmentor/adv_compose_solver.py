@@ -354,17 +354,21 @@ class ComposeAdversarialTransformSolver(object):
         also accumulates (and immediately zeroes, lines 310/366) the gradients of the model's weights -- for a conv
         net that is a weight-gradient convolution per ascent step that nobody reads.  Set ``full_backward = True``
         to get the literal behaviour."""
-        if getattr(self, 'full_backward', False):
+        flagged = [t for flag, t in zip(optimize_flags, self.chain_of_transforms) if flag]
+        restricted = (not getattr(self, 'full_backward', False)
+                      and all(isinstance(t, _NATIVE) and isinstance(t.param, torch.Tensor) and t.param.requires_grad
+                              for t in flagged))
+        if not flagged or not restricted:
+            # a third-party transform may keep several leaves (or a list / dict of them): only the literal
+            # backward() reaches every one of them
             dist.backward()
             return
-        leaves = [t.param for flag, t in zip(optimize_flags, self.chain_of_transforms)
-                  if flag and isinstance(t.param, torch.Tensor) and t.param.requires_grad]
-        if not leaves:
-            dist.backward()
-            return
+        leaves = [t.param for t in flagged]
         grads = torch.autograd.grad(dist, leaves, allow_unused=True)
         for p, g in zip(leaves, grads):
-            p.grad = g
+            if g is None:
+                continue
+            p.grad = g if p.grad is None else p.grad + g      # accumulate, as backward() does
 
     def rescale_intensity(self, data, new_min=0, new_max=1, eps=1e-20):
         # adv_compose_solver.py:407-421

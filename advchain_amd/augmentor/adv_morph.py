@@ -136,6 +136,12 @@ class AdvMorph(AdvTransformBase):
 
     def DemonsCompose(self, duv, init_deformation_dxy=None, smooth=True):
         """Clamped sampling grid (N,d,...) for an explicit low-res velocity (adv_morph.py:454-491)."""
+        if init_deformation_dxy is not None or not smooth:
+            raise NotImplementedError('DemonsCompose: only the call the reference itself makes is implemented '
+                                      '(init_deformation_dxy=None, smooth=True; adv_morph.py:299-303,322-324)')
+        if (self.sigma, self.num_steps, self.smooth_iter, self.integration_type) != (1, 8, 1, 'ss'):
+            raise NotImplementedError('DemonsCompose: the HIP chain implements the reference defaults only '
+                                      '(sigma=1, num_steps=8, smooth_iter=1, integration_type="ss"; adv_morph.py:236-242)')
         if self._tables is None:
             self._tables = bands.upsample_tables(list(self.vector_size), list(self.data_size[2:]), self.device)
         q = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
@@ -180,10 +186,12 @@ class AdvMorph(AdvTransformBase):
             interp = self.forward_interp
         q = self._field(+1.0)
         out = self.transform(data, q, interp=interp, padding_mode=padding_mode, _clamp=True)
-        self.diff = _LazyDiff(lambda o=out, d=data: o.detach() - d.detach())
+        # detached captures: a closure over `out` / `q` themselves would keep the whole DemonsCompose graph (n+1
+        # full-resolution fields) alive until the next forward
+        self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): o - d)
         perm = (0, 2, 3, 1) if self.spatial_dims == 2 else (0, 2, 3, 4, 1)
         self._displacement = _LazyDiff(
-            lambda q=q: torch.clamp(q.detach(), -1, 1).permute(*perm) - self.base_grid.permute(*perm))
+            lambda q=q.detach(): torch.clamp(q, -1, 1).permute(*perm) - self.base_grid.permute(*perm))
         return out
 
     def backward(self, data, interp=None, padding_mode=None):

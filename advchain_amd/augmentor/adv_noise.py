@@ -48,7 +48,7 @@ class AdvNoise(AdvTransformBase):
         if self.ignore_values is not None:
             keep = (abs(data - self.ignore_values) < 1e-8).detach()
             out = torch.where(keep, torch.full_like(out, float(self.ignore_values)), out)
-        self.diff = _LazyDiff(lambda o=out, d=data: o.detach() - d.detach())
+        self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): o - d)
         return out
 
     def optimize_parameters(self, step_size=None):

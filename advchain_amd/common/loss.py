@@ -57,8 +57,10 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
         has_cnt = 'contour' in divergence_types and K > 1
         m = _single_channel_mask(mask if scale == 0 else (None if mask is None else mask), K)
         if has_mse or has_cnt:
-            # 'mse': MSELoss(mean) over N*K*V elements, divided again by numel(mask)/K = N*V   (loss.py:62-64, Q13)
-            c_mse = (w_mse / (float(Ng) * K * V * float(Ng) * V)) if has_mse else 0.0
+            # 'mse': MSELoss(mean) over N*K*V elements, divided again by numel(mask)/K (loss.py:62-64, Q13): N*V for the
+            # default all-ones / K-channel mask, N*V/K for a caller's 1-channel mask (an expanded view counts as K)
+            mask_ch = K if mask is None else mask.shape[1]
+            c_mse = (w_mse / (float(Ng) * K * V * (float(Ng) * mask_ch * V / K))) if has_mse else 0.0
             # 'contour': mean over classes 1..K-1 of  2D 0.5*(MSE_x + MSE_y) | 3D 1/3*(2*MSE_A + MSE_B)  (loss.py:74-79,211-219, Q14)
             if has_cnt:
                 if spatial_dims == 2:

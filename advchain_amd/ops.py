@@ -5,6 +5,7 @@ PyTorch / CPU fallback -- a CPU tensor or a missing library raises.  PyTorch is 
 memory (``torch.empty``), the current stream and the autograd tape only.
 """
 import ctypes
+import functools
 import os
 
 import torch
@@ -39,6 +40,36 @@ def _dev(t, name="tensor"):
     if t.dtype != torch.float32:
         raise _lib.AdvchainHipError("%s must be float32, got %s" % (name, t.dtype))
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _same_device(*tensors):
+    """All operands of one launch must live on one GPU (raw pointers carry no device)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("Expected all tensors to be on the same device, but found at least two devices, "
+                               "%s and %s!" % (dev, t.device))
+
+
+def _on_tensor_device(fn):
+    """Run `fn` with the first tensor argument's GPU as the current device: `_stream()` hands the kernels the current
+    stream of the CURRENT device, so an operator called on cuda:1 tensors while cuda:0 is current would otherwise
+    launch on device 0's stream against device-1 pointers.  The common case (already current) costs one C call.
+    (Autograd runs a Function's backward on the device thread of its forward: only entry points need the guard.)"""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and _raw_device is not None and a.device.index != _raw_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return guarded
 
 
 def interp_code(interp):
@@ -222,6 +253,7 @@ def raw_axpy(x, y, a):
     return out
 
 
+@_on_tensor_device
 def normalized_axpy(base, x, step=1.0):
     """base + step * x / (||x||_2 per sample + 1e-20); base may be None.  No autograd (parameter updates)."""
     x = _dev(x.detach(), "x")
@@ -308,9 +340,18 @@ class _GridSample(torch.autograd.Function):
         return gin, ggrid, None, None, None, None
 
 
+@_on_tensor_device
 def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
     """F.grid_sample(inp, grid^T, mode, padding_mode, align_corners=True) with a PLANAR grid (N,d,...)."""
     code = interp_code(interp)
+    nd = inp.dim() - 2
+    if nd not in (2, 3) or grid.dim() != inp.dim() or grid.shape[1] != nd:
+        raise RuntimeError("grid_sample(): expected a planar grid of shape (N, %d, ...) for a %d-D input, got %s"
+                           % (nd, inp.dim(), tuple(grid.shape)))
+    if grid.shape[0] != inp.shape[0]:
+        raise RuntimeError("grid_sample(): expected grid and input to have same batch size, but got input with sizes "
+                           "%s and grid with sizes %s" % (list(inp.shape), list(grid.shape)))
+    _same_device(inp, grid)
     disp = None
     if (ADAPTIVE_HALO and code == 0 and torch.is_grad_enabled() and inp.requires_grad and grid.is_cuda
             and inp.shape[2:] == grid.shape[2:] and grid.dtype == torch.float32 and grid.is_contiguous()):
@@ -352,8 +393,14 @@ class _AffineWarp(torch.autograd.Function):
         return gin, gth, None, None
 
 
+@_on_tensor_device
 def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
     """F.grid_sample(inp, F.affine_grid(theta, inp.size(), align_corners=True), ..., align_corners=True)."""
+    nd = inp.dim() - 2
+    if tuple(theta.shape) != (inp.shape[0], nd, nd + 1):
+        raise RuntimeError("Expected a batch of %dD affine matrices of shape Nx%dx%d for size %s. Got %s."
+                           % (nd, nd, nd + 1, list(inp.shape), list(theta.shape)))
+    _same_device(inp, theta)
     return _AffineWarp.apply(inp, theta, interp_code(interp), pad_code(padding_mode))
 
 
@@ -384,6 +431,7 @@ class _AffineTheta(torch.autograd.Function):
         return gparam, None, None, None
 
 
+@_on_tensor_device
 def affine_theta(param, cfg, param_scale, nd):
     """(N,5|9) bounded parameters -> (theta, theta^-1), each (N, nd, nd+1)."""
     return _AffineTheta.apply(param, tuple(float(c) for c in cfg), float(param_scale), int(nd))
@@ -405,7 +453,12 @@ class _Axpy(torch.autograd.Function):
         return gx, gy, None
 
 
+@_on_tensor_device
 def axpy(x, y, a):
+    """x + a * y with torch's broadcasting rules (the reference writes ``data + epsilon * param``)."""
+    if x.shape != y.shape:
+        x, y = torch.broadcast_tensors(x, y)      # raises like torch when the shapes do not broadcast
+    _same_device(x, y)
     return _Axpy.apply(x, y, float(a))
 
 
@@ -445,11 +498,19 @@ class _BiasApply(torch.autograd.Function):
         return gcp, gdata, None, None, None, None
 
 
+@_on_tensor_device
 def bias_apply(cp, data, tables, eps, use_log=True, cp_scale=1.0):
     """(data * clipped_bias_field(cp), clipped_bias_field)."""
+    if cp.shape[0] != data.shape[0] or tuple(data.shape[2:]) != tuple(tables.full_dims) \
+            or tuple(cp.shape[2:]) != tuple(int(g) for g in tables.g[3 - tables.ndim:]):
+        raise RuntimeError("bias field: control points %s / data %s do not match the configured lattice %s -> image %s"
+                           % (list(cp.shape), list(data.shape), list(tables.g[3 - tables.ndim:]),
+                              list(tables.full_dims)))
+    _same_device(cp, data)
     return _BiasApply.apply(cp, data, tables, eps, use_log, cp_scale)
 
 
+@_on_tensor_device
 def bias_field_only(cp, tables, eps, use_log=True, cp_scale=1.0):
     cp = _dev(cp.detach(), "control points")
     N = cp.shape[0]
@@ -534,6 +595,7 @@ class _DemonsField(torch.autograd.Function):
 _LAST_FIELD_BOUND = None
 
 
+@_on_tensor_device
 def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
@@ -603,6 +665,7 @@ class _Consistency(torch.autograd.Function):
         return gpred, None, None, None, None, None
 
 
+@_on_tensor_device
 def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
     """Returns (coef . sums, sums) with sums = [S_mse, S_edgeA, S_edgeB] (device tensor, raw sums)."""
     return _Consistency.apply(pred, ref, mask, tuple(float(c) for c in coef), bool(ref_is_prob), bool(want_edges))

@@ -154,7 +154,8 @@ def build_solver(wl, device, process_group=None):
                                              divergence_weights=[1.0, 0.5], process_group=process_group)
 
 
-def run_gpu(args, wl, rank, world, device):
+def run_gpu(workload, wl, steps, warmup, rank, world, device):
+    """K timed steps of one workload.  Returns (max-over-ranks seconds, roofline of the dominant entry, breakdown)."""
     import torch.distributed as dist
     from advchain_amd import _lib
     pg = dist.group.WORLD if world > 1 else None
@@ -182,7 +183,7 @@ def run_gpu(args, wl, rank, world, device):
     dominant = None
     step()
     torch.cuda.synchronize()
-    for i in range(max(1, args.warmup)):
+    for i in range(max(1, warmup)):
         if i == 0:
             lib.records = []
             with lib.timed():
@@ -207,7 +208,7 @@ def run_gpu(args, wl, rank, world, device):
     sync()
     t0 = time.perf_counter()
     with lib.timed([dominant] if dominant else [], every=5):   # one launch in five carries an event pair (5 is coprime to the 8 squarings of a chain: no phase lock)
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -221,7 +222,7 @@ def run_gpu(args, wl, rank, world, device):
         avg_t = sum(durs) / len(durs)
         avg_b = sum(bts) / len(bts)
         achieved = avg_b / avg_t / 1e9
-        traffic, source = profiled_traffic(args.workload, dominant)
+        traffic, source = profiled_traffic(workload, dominant)
         roof = {"bound": "hbm", "kernel": dominant.replace("advchain_", ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": source,
@@ -235,65 +236,94 @@ def run_gpu(args, wl, rank, world, device):
 
 
 def profiled_traffic(workload, entry):
-    """HBM bytes per launch of `entry` from the committed PMC passes of this command (profiles/r01/traffic.json, made by
+    """HBM bytes per launch of `entry` from the committed PMC passes of this command (profiles/rNN/traffic.json, made by
     tools/profile_pmc.sh + tools/traffic_from_pmc.py: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs,
-    corrected as profiles/README.md states).  Counters cannot be read from inside the timed run; None if not profiled."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")
+    corrected as profiles/README.md states).  Counters cannot be read from inside the timed run; None if not profiled.
+    The newest round that profiled this (workload, entry) wins."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
-        with open(path) as f:
-            rec = json.load(f)[workload][entry]
-        return rec["traffic_bytes_per_launch"], "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-    except (OSError, KeyError, ValueError):
+        rounds = sorted((d for d in os.listdir(root) if d.startswith("r") and d[1:].isdigit()), reverse=True)
+    except OSError:
         return None, None
+    for rnd in rounds:
+        try:
+            with open(os.path.join(root, rnd, "traffic.json")) as f:
+                rec = json.load(f)[workload][entry]
+            return (rec["traffic_bytes_per_launch"],
+                    "profiles/%s/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % rnd)
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None, None
 
 
-def grid_sample3d_roofline(device, reps=20):
-    """North-star kernel: 3D trilinear grid_sample fwd+bwd at 4x1x128x128x64 on an AdvMorph field."""
-    from advchain_amd import ops
-    from advchain_amd.augmentor import AdvMorph
-    dims = (128, 128, 64)
-    ds = [4, 1] + list(dims)
-    t = AdvMorph(spatial_dims=3, config_dict=dict(epsilon=1.5, data_size=ds, vector_size=[8, 8, 32]), device=device)
-    torch.manual_seed(0)
-    t.init_parameters()
-    with torch.no_grad():
-        q = t._field(1.0).contiguous()
-    x = torch.rand(*ds, device=device)
-    go = torch.rand(*ds, device=device)
-    # the displacement bound the product measures in forward (ops._GridSample) and hands to the backward
-    halo = ops.warp_halo(ops.grid_displacement(q), 3)
-    for _ in range(3):
-        out = ops.raw_grid_sample_fwd(x, q, 0, 0, True)
-        ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
-    # average launch duration: `reps` launches back to back between two events on the launch stream (one event pair
-    # per single launch would add the ~5 us launch gap of an empty queue to a 25-60 us kernel)
-    from advchain_amd import _lib
+def _time_pair(x, go, q, halo, reps):
+    """Average launch duration of grid_sample fwd and bwd on field `q`: `reps` launches back to back between two events
+    on the launch stream (one event pair per single launch would add the ~5 us launch gap of an empty queue)."""
+    from advchain_amd import _lib, ops
     lib = _lib.load()
-    gin = torch.empty_like(x)
-    ggrid = torch.empty_like(q)
-    out = torch.empty_like(x)
-    ws = ops._scatter_workspace(4, dims, device)
+    N = x.shape[0]
+    dims = tuple(x.shape[2:])
+    gin, ggrid, out = torch.empty_like(x), torch.empty_like(q), torch.empty_like(x)
+    ws = ops._scatter_workspace(N, dims, x.device)
     da = _lib.dims_array(dims)
+    for _ in range(3):
+        ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
     ef = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     torch.cuda.synchronize()
     ef[0].record()
     for _ in range(reps):
-        _lib.check(lib.advchain_grid_sample_fwd(ops._ptr(x), ops._ptr(q), ops._ptr(out), 4, 1, 3, da, da, 0, 0, 1,
+        _lib.check(lib.advchain_grid_sample_fwd(ops._ptr(x), ops._ptr(q), ops._ptr(out), N, 1, 3, da, da, 0, 0, 1,
                                                 ops._stream()), "fwd")
     ef[1].record()
     for _ in range(reps):
         _lib.check(lib.advchain_grid_sample_bwd(ops._ptr(go), ops._ptr(x), ops._ptr(q), ops._ptr(gin), ops._ptr(ggrid),
-                                                ops._ptr(ws), 4, 1, 3, da, da, 0, 0, 1, halo, ops._stream()), "bwd")
+                                                ops._ptr(ws), N, 1, 3, da, da, 0, 0, 1, halo, ops._stream()), "bwd")
     ef[2].record()
     torch.cuda.synchronize()
-    tf = ef[0].elapsed_time(ef[1]) * 1e-3
-    tb = ef[1].elapsed_time(ef[2]) * 1e-3
-    tf, tb = tf / reps, tb / reps
+    return ef[0].elapsed_time(ef[1]) * 1e-3 / reps, ef[1].elapsed_time(ef[2]) * 1e-3 / reps
+
+
+def grid_sample3d_roofline(device, reps=20):
+    """North-star kernel: 3D trilinear grid_sample fwd+bwd at 4x1x128x128x64, at TWO displacement levels: a freshly
+    initialised AdvMorph field (sub-voxel) and the field the cfg-3 solver ends with after its 3 ascent steps."""
+    from advchain_amd import ops
+    dims = (128, 128, 64)
+    ds = [4, 1] + list(dims)
     nv = 4 * 128 * 128 * 64
     bf, bb = 20 * nv, 36 * nv
-    # second baseline (SURVEY §8d): stock ATen-HIP F.grid_sample forward + backward on the same tensors
+    torch.manual_seed(0)
+    x = torch.rand(*ds, device=device)
+    go = torch.rand(*ds, device=device)
+    wl = WORKLOADS["cfg3"]
+    solver = build_solver(wl, device)
+    morph = [t for t in solver.chain_of_transforms if t.get_name() == "morph"][0]
+    levels = {}
+    for tag in ("init_field", "after_cfg3_ascent"):
+        if tag == "init_field":
+            morph.init_parameters()
+        else:
+            torch.manual_seed(1234)
+            data = torch.rand(*ds, device=device)
+            solver.adversarial_training(data=data, model=make_model(3).to(device), n_iter=wl["n_iter"], step_sizes=1,
+                                        power_iteration=False)
+            morph = [t for t in solver.chain_of_transforms if t.get_name() == "morph"][0]
+        with torch.no_grad():
+            q = morph._field(1.0).contiguous()
+        # the displacement bound the product measures in forward (ops._GridSample) and hands to the backward
+        entry = ops.grid_displacement(q)
+        halo = ops.warp_halo(entry, 3)
+        tf, tb = _time_pair(x, go, q, halo, reps)
+        levels[tag] = {"max_displacement_voxels": round(float(entry[1]), 3), "bwd_form": _bwd_form(halo),
+                       "fwd_us": round(tf * 1e6, 2), "bwd_us": round(tb * 1e6, 2),
+                       "achieved": round((bf + bb) / (tf + tb) / 1e9, 1),
+                       "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": profiled_traffic("north_star", tag)[0]}
+        if tag == "init_field":
+            q0 = q
+    # second baseline (SURVEY 8d): stock ATen-HIP F.grid_sample forward + backward on the same tensors
     import torch.nn.functional as F
-    qn = torch.clamp(q, -1, 1).permute(0, 2, 3, 4, 1).contiguous()
+    qn = torch.clamp(q0, -1, 1).permute(0, 2, 3, 4, 1).contiguous()
     xr, qr = x.clone().requires_grad_(True), qn.clone().requires_grad_(True)
     for _ in range(2):
         torch.autograd.grad(F.grid_sample(xr, qr, align_corners=True), (xr, qr), go)
@@ -304,41 +334,101 @@ def grid_sample3d_roofline(device, reps=20):
     ea[1].record()
     torch.cuda.synchronize()
     t_aten = ea[0].elapsed_time(ea[1]) * 1e-3 / 5
+    worst = min(levels.values(), key=lambda r: r["frac"])
     return {"bound": "hbm", "kernel": "grid_sample3d fwd+bwd @4x1x128x128x64 (C=1, zeros, AdvMorph field)",
-            "achieved": round((bf + bb) / (tf + tb) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4), "fwd_us": round(tf * 1e6, 2),
-            "bwd_us": round(tb * 1e6, 2), "fwd_GBs": round(bf / tf / 1e9, 1), "bwd_GBs": round(bb / tb / 1e9, 1),
-            "algorithmic_bytes": bf + bb, "displacement_bound_voxels": abs(halo), "bound_is_exact": halo < 0,
-            "aten_hip_fwd_bwd_us": round(t_aten * 1e6, 2), "aten_hip_GBs": round((bf + bb) / t_aten / 1e9, 1),
-            "note": "bwd = gather-form adjoint (one launch) when the measured displacement is below 1 voxel, else "
-                    "LDS-tiled scatter + header-reset and overflow-drain launches"}
+            "achieved": worst["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": worst["frac"],
+            "frac_is": "the LOWER of the two displacement levels", "levels": levels,
+            "algorithmic_bytes": bf + bb, "traffic_unit": "bytes per fwd+bwd pair",
+            "aten_hip_fwd_bwd_us": round(t_aten * 1e6, 2), "aten_hip_GBs": round((bf + bb) / t_aten / 1e9, 1)}
+
+
+def _bwd_form(halo):
+    if halo < 0:
+        return "gather-form adjoint, exact bound %d voxel(s), one launch" % -halo
+    return "scatter (displacement hint %d voxels)" % halo
 
 
 def cpu_baseline(wl, name):
-    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload."""
+    """The CPU oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload, timed with
+    ALL host cores as torch threads and, when the host has more than 16, with 16 as well (measured on the GPU box: the
+    fastest setting for this path); `value` is the better of the two, `cores` the thread count that produced it."""
     from oracle import advchain_oracle as O
-    cores = min(os.cpu_count() or 1, 16)   # measured on the GPU box: 16 threads is the fastest setting for this path
-    torch.set_num_threads(cores)
+    host = os.cpu_count() or 1
     sd = len(wl["dims"])
     if sd == 2:
         batch, n_iter = min(wl["batch"], 32), wl["n_iter"]   # ~10 s of CPU work at cfg-2
     else:
         batch, n_iter = 1, 1
     cls = {"noise": O.OracleNoise, "bias": O.OracleBias, "morph": O.OracleMorph, "affine": O.OracleAffine}
-    chain = [cls[nm](sd, cfg) for nm, cfg in transform_configs(wl["dims"], batch, wl["chain"],
-                                                                morph_div8=wl.get("anatomy", False))]
-    torch.manual_seed(0)
-    data = torch.rand(batch, 1, *wl["dims"])
-    model = make_model(sd)
-    solver = O.OracleSolver(chain)
-    t0 = time.perf_counter()
-    solver.adversarial_training(data=data, model=model, n_iter=n_iter, step_sizes=1)
-    dt = time.perf_counter() - t0
     # scale to the workload's n_iter: cost ~ (n_iter ascent steps + 1 final pass ~ 0.4 step)
     scale = (wl["n_iter"] + 0.4) / (n_iter + 0.4)
-    return {"value": round(batch / (dt * scale), 4), "unit": "images/s", "cores": cores, "kind": "port",
+    runs = {}
+    for threads in sorted({host, min(host, 16)}, reverse=True):
+        torch.set_num_threads(threads)
+        chain = [cls[nm](sd, cfg) for nm, cfg in transform_configs(wl["dims"], batch, wl["chain"],
+                                                                    morph_div8=wl.get("anatomy", False))]
+        torch.manual_seed(0)
+        data = torch.rand(batch, 1, *wl["dims"])
+        model = make_model(sd)
+        solver = O.OracleSolver(chain)
+        t0 = time.perf_counter()
+        solver.adversarial_training(data=data, model=model, n_iter=n_iter, step_sizes=1)
+        dt = time.perf_counter() - t0
+        runs[threads] = (round(batch / (dt * scale), 4), dt)
+    best = max(runs, key=lambda k: runs[k][0])
+    return {"value": runs[best][0], "unit": "images/s", "cores": best, "host_cores": host, "threads_used": best,
+            "by_threads": {str(k): v[0] for k, v in runs.items()}, "kind": "port",
             "sample": "%d image(s), %d of %d ascent steps (+ final pass) of %s in %.1f s; scaled linearly in steps"
-                      % (batch, n_iter, wl["n_iter"], name, dt)}
+                      % (batch, n_iter, wl["n_iter"], name, runs[best][1])}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_spawn(args, stub):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import subprocess
+    if not stub:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) visible\n" % (args.gpus, have))
+            return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def run_stub(steps, warmup, rank, world):
+    """TEST ONLY (ADVCHAIN_BENCH_STUB=1, tests/test_bench_spawn.py): the launcher / rendezvous / reduction skeleton
+    of this script on CPU with `gloo` and a step that does nothing, so that the spawn path is covered without a GPU."""
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    for _ in range(warmup + steps):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), None, {}
+
+
+SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
+
+
+def result_record(name, wl, world, steps, warmup, elapsed, roof, breakdown):
+    unit = "images/s" if len(wl["dims"]) == 2 else "volumes/s"
+    return {"value": round(wl["batch"] * world * steps / elapsed, 3), "unit": unit, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "workload": "%s: %s" % (name, wl["desc"]),
+            "global_batch": wl["batch"] * world, "adv_steps": wl["n_iter"], "roofline": roof,
+            "kernel_time_ms_first_step": breakdown}
 
 
 def main():
@@ -348,34 +438,73 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 3D configs timed after the headline workload")
     args = ap.parse_args()
+    stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_spawn(args, stub))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (no CPU path for the product kernels)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if stub:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (no CPU path for the product kernels)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        # ranks that actually took part in a collective on device memory (RCCL), not what the environment claims
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        rccl_ranks = int(round(float(one.item())))
+        if rccl_ranks != world:
+            raise SystemExit("bench.py: all_reduce saw %d ranks, expected %d" % (rccl_ranks, world))
     wl = WORKLOADS[args.workload]
-    elapsed, roof, breakdown = run_gpu(args, wl, rank, world, device)
+    if stub:
+        elapsed, roof, breakdown = run_stub(args.steps, args.warmup, rank, world)
+    else:
+        elapsed, roof, breakdown = run_gpu(args.workload, wl, args.steps, args.warmup, rank, world, device)
     if rank == 0:
-        images = wl["batch"] * world * args.steps
+        rec = result_record(args.workload, wl, world, args.steps, args.warmup, elapsed, roof, breakdown)
         out = {
             "metric": "augmented images/sec (N adv steps, chain=noise+bias+morph+affine)",
-            "value": round(images / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "value": rec["value"], "unit": "images/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "global_batch": wl["batch"] * world,
+            "config": {"workload": rec["workload"], "global_batch": rec["global_batch"],
                        "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
                        "model": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},
             "roofline": roof,
             "kernel_time_ms_first_step": breakdown,
         }
-        if world == 1:
+        if world == 1 and not stub:
+            if not args.no_secondary:
+                # the 3D configs of BASELINE.json, timed by the same code on the same device (fewer steps: they are
+                # 2-15x longer); `value` above stays the headline workload's
+                other = {}
+                for name in SECONDARY:
+                    if name == args.workload:
+                        continue
+                    w2 = WORKLOADS[name]
+                    k2 = max(3, min(args.steps, 5))
+                    e2, r2, b2 = run_gpu(name, w2, k2, 1, 0, 1, device)
+                    other[name] = result_record(name, w2, 1, k2, 1, e2, r2, b2)
+                    other[name].pop("kernel_time_ms_first_step")
+                out["other_workloads"] = other
             out["roofline_grid_sample3d"] = grid_sample3d_roofline(device)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, args.workload)
