@@ -154,6 +154,14 @@ def build_solver(wl, device, process_group=None):
                                              divergence_weights=[1.0, 0.5], process_group=process_group)
 
 
+def solver_kwargs(wl, device):
+    kw = dict(n_iter=wl["n_iter"], step_sizes=1, power_iteration=False)
+    if wl.get("anatomy"):
+        kw.update(anatomy_mask_images=ellipsoid(wl["batch"], wl["dims"]).to(device), anatomy_reg_weight=50,
+                  volume_preserve_tolerance=5e-4)
+    return kw
+
+
 def run_gpu(workload, wl, steps, warmup, rank, world, device):
     """K timed steps of one workload.  Returns (max-over-ranks seconds, roofline of the dominant entry, breakdown)."""
     import torch.distributed as dist
@@ -164,10 +172,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     data = torch.rand(wl["batch"], 1, *wl["dims"], device=device)
     model = make_model(sd).to(device)
     solver = build_solver(wl, device, pg)
-    kw = dict(n_iter=wl["n_iter"], step_sizes=1, power_iteration=False)
-    if wl.get("anatomy"):
-        kw.update(anatomy_mask_images=ellipsoid(wl["batch"], wl["dims"]).to(device), anatomy_reg_weight=50,
-                  volume_preserve_tolerance=5e-4)
+    kw = solver_kwargs(wl, device)
 
     def step():
         return solver.adversarial_training(data=data, model=model, **kw)

@@ -12,8 +12,7 @@ including the reference's quirks.
 Parity pin: the reference ships no tests or golden vectors for this path, so
 the oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF, imported in the build
 container by ``oracle/make_golden.py`` and committed as ``tests/golden/*.npz``
-(``tests/test_oracle_golden.py`` checks every fixture; ``tests/test_oracle_vs_reference.py``
-re-checks live when ``/root/reference`` is mounted).  The arithmetic lives in un-vendored
+(``tests/test_oracle_golden.py`` checks every fixture).  The arithmetic lives in un-vendored
 PyTorch ATen ops (``torch>=1.6.0`` per ``requirements.txt:4``; exercised here with
 torch 2.10.0): ``grid_sampler_{2,3}d``, ``affine_grid_generator``, ``upsample_{bi,tri}linear``,
 ``conv_transpose{2,3}d``, ``linalg_inv`` -- the oracle calls the very same CPU ops.
@@ -331,20 +330,64 @@ def consistency_loss(output, reference, divergence_types=("mse", "contour"),
 # --------------------------------------------------------------------------------------
 # model-state helpers  (advchain/common/utils.py:114-173, common/layers.py)
 # --------------------------------------------------------------------------------------
+class OracleFixableDropout(torch.nn.Module):
+    """common/layers.py:5-63 (Fixable2DDropout / Fixable3DDropout; ``dims`` picks dropout2d / dropout3d): the seed of
+    the last mask is kept and replayed in training mode when ``lazy_load`` is set."""
+
+    def __init__(self, p=0.5, dims=2, inplace=False, lazy_load=False, training=True):
+        super().__init__()
+        assert 0 <= p <= 1
+        self.p, self.dims, self.inplace = p, dims, inplace
+        self.seed = None
+        self.lazy_load = lazy_load
+        self.training = training
+
+    def forward(self, X):
+        if self.training and self.lazy_load and self.seed is not None:      # layers.py:20-26
+            seed = self.seed
+        else:
+            seed = torch.seed()                                              # layers.py:27-30
+        self.seed = seed
+        torch.manual_seed(seed)
+        fn = F.dropout2d if self.dims == 2 else F.dropout3d
+        return fn(X, p=self.p, training=self.training, inplace=self.inplace)
+
+
+def _flip_fixable_dropout(model):
+    """common/utils.py:139-141,164-167: every Fixable*Dropout gets ``lazy_load = not lazy_load`` (duck-typed on the
+    attribute, so the reference's, the product's and the oracle's layer classes are all recognised)."""
+    for _, mod in model.named_modules():
+        if hasattr(mod, "lazy_load") and hasattr(mod, "seed"):
+            mod.lazy_load = not mod.lazy_load
+
+
 @contextlib.contextmanager
 def frozen_bn_stats(model):
-    """common/utils.py:114-147 (BatchNorm running-stat tracking off inside the block)."""
+    """common/utils.py:114-147 (BatchNorm running-stat tracking off inside the block; Fixable*Dropout.lazy_load is
+    flipped on entry and flipped back on exit)."""
     saved = {}
     for name, mod in model.named_modules():
         if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
             saved[name] = mod.track_running_stats
             mod.track_running_stats = False
+    _flip_fixable_dropout(model)
     try:
         yield
     finally:
         for name, mod in model.named_modules():
             if name in saved:
                 mod.track_running_stats = saved[name]
+        _flip_fixable_dropout(model)
+
+
+@contextlib.contextmanager
+def fixed_dropout(model):
+    """common/utils.py:149-173 (_fix_dropout)."""
+    _flip_fixable_dropout(model)
+    try:
+        yield
+    finally:
+        _flip_fixable_dropout(model)
 
 
 # --------------------------------------------------------------------------------------
@@ -507,6 +550,29 @@ class OracleBias(_OracleTransform):
         self.param = torch.clamp(self.param, self.low, self.high)
 
 
+def one_ulp_jitter(seed=0):
+    """Field hook: moves every value of a sampling grid by exactly one fp32 ulp, up or down at random, as a CONSTANT
+    offset (gradients flow through unchanged).  A parity tolerance on a quantity that this perturbation moves by x in
+    the reference / oracle itself cannot be tighter than x: that is rounding sensitivity, not a kernel difference."""
+    def hook(q):
+        g = torch.Generator().manual_seed(seed + q.numel())
+        up = torch.rand(q.shape, generator=g) < 0.5
+        d = q.detach()
+        target = torch.where(up, torch.full_like(d, float("inf")), torch.full_like(d, float("-inf")))
+        return q + (torch.nextafter(d, target) - d)
+    return hook
+
+
+def uniform_jitter(amplitude, seed=0):
+    """Field hook: constant offsets drawn uniformly from [-amplitude, amplitude] (normalised grid units) -- the
+    reference's sensitivity to a field that differs from its own by `amplitude` (e.g. another implementation's
+    rounding), see one_ulp_jitter."""
+    def hook(q):
+        g = torch.Generator().manual_seed(seed + q.numel())
+        return q + (torch.rand(q.shape, generator=g) * 2 - 1) * amplitude
+    return hook
+
+
 class OracleMorph(_OracleTransform):
     """adv_morph.py:204-564."""
     name = "morph"
@@ -541,9 +607,13 @@ class OracleMorph(_OracleTransform):
             self.init_parameters()
         self._as_leaf(unit_normalize(self.param) if self.power_iteration else self.param)
 
+    field_hook = None   # oracle-only: callable(field) -> field applied to every DemonsCompose output (sensitivity runs)
+
     def _field(self, sign):
         scale = self.xi if (self.power_iteration and self.is_training) else self.epsilon
-        return demons_compose(sign * scale * self.param, self.data_size[2:])
+        q = demons_compose(sign * scale * self.param, self.data_size[2:])
+        return q if self.field_hook is None else self.field_hook(q)
+
 
     def _warp(self, data, dxy, interp, padding_mode):
         if padding_mode is None:
@@ -788,7 +858,8 @@ class OracleSolver(object):
         adv = self.forward(data, chain)
         old = model.training
         model.train()
-        adv_out = model(adv.detach().clone())
+        with fixed_dropout(model):                       # adv_compose_solver.py:256-259
+            adv_out = model(adv.detach().clone())
         if self.has_geometric(chain):
             ones = torch.ones_like(init_output)
             m = self.predict_backward(self.predict_forward(ones, chain), chain)

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle._import_reference import import_reference  # noqa: E402
+from tests.helpers import bn_dropout_model, counted_torch_seed, device_independent, make_model_multi  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 CPU = torch.device("cpu")
@@ -278,11 +279,30 @@ def g5_loss():
                 v.backward()
                 out["%s_%s_%s_value" % (tag, name, mtag)] = v.detach().double()
                 out["%s_%s_%s_grad" % (tag, name, mtag)] = pred.grad.clone()
+        # is_gt=True: the reference map is used as given (one-hot ground truth) instead of softmax(logits) (loss.py:55-60,
+        # 66-69, 232-238); also a caller's ONE-channel mask, whose numel enters the 'mse' normaliser (loss.py:64)
+        onehot = F.one_hot(ref.argmax(dim=1), 4).movedim(-1, 1).float().contiguous()
+        out[tag + "_onehot"] = onehot
+        for name, types, weights in (("mse", ["mse"], [1.0]), ("contour", ["contour"], [1.0]), ("kl", ["kl"], [1.0]),
+                                     ("mix", ["mse", "contour"], [1.0, 0.5])):
+            pred.grad = None
+            v = L.calc_segmentation_consistency(output=pred, reference=onehot, divergence_types=types,
+                                                divergence_weights=weights, scales=[0], mask=mask, is_gt=True)
+            v.backward()
+            out["%s_%s_isgt_value" % (tag, name)] = v.detach().double()
+            out["%s_%s_isgt_grad" % (tag, name)] = pred.grad.clone()
+        pred.grad = None
+        v = L.calc_segmentation_consistency(output=pred, reference=ref, divergence_types=["mse", "contour"],
+                                            divergence_weights=[1.0, 0.5], scales=[0], mask=m1)
+        v.backward()
+        out[tag + "_mask1"] = m1
+        out[tag + "_mix_mask1_value"] = v.detach().double()
+        out[tag + "_mix_mask1_grad"] = pred.grad.clone()
     save("g5_loss", out)
 
 
 # ----------------------------------------------------------------------------- G6
-def build_chain(aug, spatial_dims, data_size, names, pad_morph="zeros", pad_affine="zeros"):
+def build_chain(aug, spatial_dims, data_size, names, pad_morph="zeros", pad_affine="zeros", bias_overrides=None):
     dims = data_size[2:]
     chain, spec = [], []
     for nm in names:
@@ -293,6 +313,7 @@ def build_chain(aug, spatial_dims, data_size, names, pad_morph="zeros", pad_affi
         elif nm == "bias":
             cfg = dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims], downscale=2, data_size=data_size,
                        interpolation_order=3, init_mode="random", space="log")
+            cfg.update(bias_overrides or {})
             t = aug.AdvBias(spatial_dims=spatial_dims, config_dict=cfg, use_gpu=False, device=CPU)
             kw = {}
         elif nm == "morph":
@@ -334,16 +355,39 @@ def g6_solver(aug):
         "3d_full_n1": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["noise", "bias", "morph", "affine"], n_iter=1),
         "3d_morph_anat_n2": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["morph"], n_iter=2, anatomy=True),
         "2d_n0": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=0),
+        # a11: Conv + BatchNorm + Fixable*Dropout models (adv_compose_solver.py:256-259,315-316,429-433, common/utils.py:
+        # 114-173, common/layers.py) -- a train()-mode model (dropout mask replayed through lazy_load) and the 3D
+        # notebook's eval()-mode toy model (dropout only active in the final model.train() pass)
+        "2d_bn_drop_train_n2": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                                    model="train"),
+        "3d_bn_drop_eval_n2": dict(sd=3, ds=[2, 1, 16, 16, 8], names=["noise", "bias", "morph", "affine"], n_iter=2,
+                                   model="eval"),
+        # AdvBias init_mode 'gaussian' (adv_bias.py:240-242: no clamp bounds) in linear space, two-channel data
+        "2d_bias_gauss_c2_n2": dict(sd=2, ds=[2, 2, 32, 32], names=["bias"], n_iter=2, in_ch=2,
+                                    bias=dict(init_mode="gaussian", space="linear")),
+        # is_gt=True solver (reference = init_output used as given)
+        "2d_isgt_n1": dict(sd=2, ds=[2, 1, 32, 32], names=["morph", "affine"], n_iter=1, solver=dict(is_gt=True)),
     }
+    only = set(ONLY)
     for ci, (tag, c) in enumerate(cases.items()):
+        if only and not any(tag.startswith(o[3:]) for o in only if o.startswith("g6_")) and "g6" not in only:
+            continue
         sd, ds = c["sd"], c["ds"]
-        chain, spec = build_chain(aug, sd, ds, c["names"])
+        chain, spec = build_chain(aug, sd, ds, c["names"], bias_overrides=c.get("bias"))
         solver_kw = dict(divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
         solver_kw.update(c.get("solver", {}))
         solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
                                                        **solver_kw)
-        model = make_model(sd)
-        data = smooth_data(ds[0], 1, ds[2:], 2000 + ci)
+        in_ch = c.get("in_ch", 1)
+        if c.get("model"):
+            import advchain.common.layers as RL
+            cls = device_independent(RL.Fixable2DDropout if sd == 2 else RL.Fixable3DDropout)
+            model = bn_dropout_model(sd, c["model"], lambda p: cls(p))
+        elif in_ch > 1:
+            model = make_model_multi(sd, in_ch)
+        else:
+            model = make_model(sd)
+        data = smooth_data(ds[0], in_ch, ds[2:], 2000 + ci)
         torch.manual_seed(3000 + ci)
         init_params = []
         for t in chain:
@@ -387,9 +431,10 @@ def g6_solver(aug):
             kw.update(anatomy_mask_images=anatomy, anatomy_reg_weight=50, volume_preserve_tolerance=5e-4)
         import io
         import contextlib
-        with contextlib.redirect_stdout(io.StringIO()):
+        with contextlib.redirect_stdout(io.StringIO()), counted_torch_seed(1000):
             loss = solver.adversarial_training(data=data, model=model, **kw)
-        out = dict(meta=dict(spatial_dims=sd, data_size=ds, chain=spec, solver=solver_kw, train=kw if anatomy is None
+        out = dict(meta=dict(spatial_dims=sd, data_size=ds, chain=spec, solver=solver_kw, model=c.get("model"),
+                             in_ch=in_ch, train=kw if anatomy is None
                              else {k: v for k, v in kw.items() if k != "anatomy_mask_images"},
                              has_anatomy=anatomy is not None, n_transforms=len(solver.chain_of_transforms)),
                    data=data, final_loss=loss.detach().double(), adv_data=solver.adv_data.detach(),
@@ -399,6 +444,11 @@ def g6_solver(aug):
                    n_updates=len(steps))
         if anatomy is not None:
             out["anatomy"] = anatomy
+        if c.get("model"):
+            out["bn_running_mean"], out["bn_running_var"] = model[1].running_mean, model[1].running_var
+            out["bn_num_batches"] = model[1].num_batches_tracked
+            out["dropout_seed"], out["dropout_lazy_load"] = int(model[2].seed), bool(model[2].lazy_load)
+            out["model_training"] = bool(model.training)
         for i, p in enumerate(init_params):
             out["init_param_%d" % i] = p
         for i, t in enumerate(chain):
@@ -462,17 +512,241 @@ def kat(aug):
     save("kat_2d", out)
 
 
+# ----------------------------------------------------------------------------- G7: sub-features without a pin so far
+def g7_misc(aug):
+    """ignore_values of AdvNoise / AdvBias (adv_noise.py:85-89, adv_bias.py:176-184), AdvBias init modes
+    (adv_bias.py:237-252) and the multi-channel bias expand (adv_bias.py:170-171)."""
+    out, meta = {}, {}
+    for tag, sd, ds in (("2d", 2, [2, 2, 24, 32]), ("3d", 3, [1, 3, 10, 12, 8])):
+        dims = ds[2:]
+        data = smooth_data(ds[0], ds[1], dims, 4100 + sd)
+        data = torch.where(data < 0.35, torch.full_like(data, 0.25), data)      # a flat background at exactly 0.25
+        w = rand(tuple(data.shape), 4200 + sd)
+        out[tag + "_data"], out[tag + "_w"] = data, w
+        # --- noise
+        ncfg = dict(epsilon=0.7, xi=1e-6, data_size=ds)
+        t = aug.AdvNoise(spatial_dims=sd, config_dict=ncfg, ignore_values=0.25, use_gpu=False, device=CPU)
+        t.init_parameters()
+        p = t.unit_normalize(rand(tuple(ds), 4300 + sd)).requires_grad_(True)
+        t.param = p
+        o = t.forward(data)
+        (o * w).sum().backward()
+        out[tag + "_noise_param"], out[tag + "_noise_out"], out[tag + "_noise_grad"] = p.detach(), o.detach(), p.grad.clone()
+        meta[tag + "_noise"] = dict(spatial_dims=sd, config=ncfg, ignore_values=0.25,
+                                    n_ignored=int((o.detach() == 0.25).sum()))
+        # --- bias with ignore_values on multi-channel data, log and linear space
+        for space in ("log", "linear"):
+            bcfg = dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims], downscale=2, data_size=ds,
+                        interpolation_order=3, init_mode="random", space=space)
+            t = aug.AdvBias(spatial_dims=sd, config_dict=bcfg, ignore_values=0.25, use_gpu=False, device=CPU)
+            torch.manual_seed(4400 + sd)
+            t.init_parameters()
+            p = (rand(tuple(t.param.shape), 4500 + sd) * 0.2).requires_grad_(True)
+            t.param = p
+            o = t.forward(data)
+            (o * w).sum().backward()
+            k = "%s_bias_%s_" % (tag, space)
+            out[k + "param"], out[k + "out"], out[k + "grad"] = p.detach(), o.detach(), p.grad.clone()
+            out[k + "field"] = t.bias_field.detach()
+            meta[k] = dict(spatial_dims=sd, config=bcfg, ignore_values=0.25, field_shape=list(t.bias_field.shape))
+        # --- init modes: bounds, parameter statistics, rescale_parameters
+        for mode in ("gaussian", "identity", "random"):
+            bcfg = dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims], downscale=2, data_size=ds,
+                        interpolation_order=3, init_mode=mode, space="log")
+            t = aug.AdvBias(spatial_dims=sd, config_dict=bcfg, use_gpu=False, device=CPU)
+            torch.manual_seed(4600 + sd)
+            t.init_parameters()
+            k = "%s_init_%s_" % (tag, mode)
+            meta[k] = dict(spatial_dims=sd, config=bcfg, low=float(t.low), high=float(t.high),
+                           shape=list(t.param.shape), param_abs_max=float(t.param.abs().max()),
+                           param_std=float(t.param.std()))
+            p = rand(tuple(t.param.shape), 4700 + sd) * 0.9          # beyond log(1.3): 'random' clamps, the others do not
+            t.param = p.clone()
+            t.rescale_parameters()
+            out[k + "param_in"], out[k + "param_rescaled"] = p, t.param.detach().clone()
+            out[k + "forward"] = t.forward(data).detach()
+    out["meta"] = meta
+    save("g7_misc", out)
+
+
+# ----------------------------------------------------------------------------- G8: kinks of the interpolant
+def _node_margin_px(q, dims):
+    """Smallest distance (pixels) of any UNCLAMPED sampling coordinate to a grid node, over all axes; coordinates the
+    final clamp(-1,1) pins to the border count by how far beyond the border they were (the clamp's sub-gradient is
+    robust there)."""
+    d = len(dims)
+    worst = float("inf")
+    for a in range(d):                      # channel a <-> spatial axis d-1-a
+        S = dims[d - 1 - a]
+        x = q[:, a].double()
+        ix = (x + 1) / 2 * (S - 1)
+        inside = (x.abs() < 1)
+        frac = ix - torch.floor(ix)
+        dist = torch.minimum(frac, 1 - frac)
+        beyond = (x.abs() - 1) / 2 * (S - 1)
+        m = torch.where(inside, dist, beyond.abs())
+        worst = min(worst, float(m.min()))
+    return worst
+
+
+def _morph_case(aug, sd, ds, vs, eps, seed):
+    cfg = dict(epsilon=eps, data_size=ds, vector_size=vs)
+    t = aug.AdvMorph(spatial_dims=sd, config_dict=cfg, use_gpu=False, device=CPU)
+    torch.manual_seed(seed)
+    t.init_parameters()
+    p = t.unit_normalize(rand(tuple(t.param.shape), seed + 1)).detach().requires_grad_(True)
+    t.param = p
+    return t, p, cfg
+
+
+def _one_ulp(q, seed):
+    g = torch.Generator().manual_seed(seed + q.numel())
+    up = torch.rand(q.shape, generator=g) < 0.5
+    d = q.detach()
+    target = torch.where(up, torch.full_like(d, float("inf")), torch.full_like(d, float("-inf")))
+    return q + (torch.nextafter(d, target) - d)
+
+
+def g8_kinks(aug):
+    from oracle import advchain_oracle as O
+    """Two kinds of evidence for the composite (image warp -> field -> velocity) gradients of AdvMorph:
+    (a) KINK-MARGIN cases: seeds searched until no sampling coordinate of the +eps and -eps fields lies within
+        MARGIN px of a grid node -- there the reference gradient is a smooth function of the field and the GPU path
+        must reproduce it to 1e-4 of its scale;
+    (b) SENSITIVITY of the reference itself on the G3 cases: the same gradients recomputed with every value of the
+        DemonsCompose output moved by ONE fp32 ulp (constant offset, random sign).  Whatever that moves is rounding
+        sensitivity of the reference's own arithmetic and bounds any meaningful parity tolerance from below."""
+    out, meta = {}, {}
+    MARGIN = 1e-3
+    AMPLITUDES = [0, 1e-6, 4e-6, 1.6e-5]     # normalised grid units; 0 = exactly one ulp
+    geoms = {"2d": (2, [1, 1, 12, 12], [3, 3]), "2d_c2": (2, [1, 2, 10, 14], [3, 4]), "3d": (3, [1, 1, 6, 6, 6], [3, 3, 3]),
+             "3d_b": (3, [1, 2, 6, 8, 5], [3, 4, 2])}
+    for tag, (sd, ds, vs) in geoms.items():
+        found, best = None, 0.0
+        for seed in range(5000, 9000):
+            t, p, cfg = _morph_case(aug, sd, ds, vs, 1.5, seed)
+            with torch.no_grad():
+                # the un-clamped field (how far beyond the border a pinned coordinate was) is not observable on the
+                # reference's DemonsCompose, which clamps inside (adv_morph.py:490): the search uses the oracle's
+                # restatement of it (bit-identical to the reference here, tests/test_oracle_golden.py::test_g3_morph);
+                # everything STORED below comes from the reference
+                qf = O.demons_compose(t.epsilon * p, ds[2:], final_clamp=False)
+                qb = O.demons_compose(-t.epsilon * p, ds[2:], final_clamp=False)
+                ref_f, _ = t.get_deformation_displacement_field(duv=t.epsilon * p)
+                assert float((torch.clamp(qf, -1, 1) - ref_f).abs().max()) < 1e-6
+            mg = min(_node_margin_px(qf, ds[2:]), _node_margin_px(qb, ds[2:]))
+            best = max(best, mg)
+            if mg > MARGIN:
+                found = (seed, mg)
+                break
+        if found is None:
+            raise RuntimeError("no kink-margin seed for %s (best %.2e px)" % (tag, best))
+        seed, mg = found
+        data = smooth_data(ds[0], ds[1], ds[2:], seed + 2)
+        w = rand(tuple(data.shape), seed + 3)
+        key = "margin_%s_" % tag
+        o = t.forward(data)
+        (o * w).sum().backward()
+        gf = p.grad.clone(); p.grad = None
+        ob = t.backward(data)
+        (ob * w).sum().backward()
+        gb = p.grad.clone(); p.grad = None
+        rt = t.backward(t.forward(data))
+        (rt * w).sum().backward()
+        grt = p.grad.clone(); p.grad = None
+        meta[key] = dict(spatial_dims=sd, config=cfg, seed=seed, margin_px=mg)
+        out.update({key + "param": p.detach(), key + "data": data, key + "w": w, key + "forward": o.detach(),
+                    key + "backward": ob.detach(), key + "grad_param_fwd": gf, key + "grad_param_bwd": gb,
+                    key + "roundtrip": rt.detach(), key + "roundtrip_grad_param": grt})
+        print("  %s: seed %d margin %.2e px" % (tag, seed, mg))
+
+    # (b) the reference's own one-ulp sensitivity on the G3 cases (same seeds as g3_morph)
+    g3 = {
+        "2d": dict(spatial_dims=2, data_size=[2, 1, 32, 32], vector_size=[4, 4], epsilon=1.5, C=1),
+        "2d_k4": dict(spatial_dims=2, data_size=[2, 4, 24, 40], vector_size=[3, 5], epsilon=1.5, C=4),
+        "3d": dict(spatial_dims=3, data_size=[2, 1, 16, 16, 8], vector_size=[4, 4, 2], epsilon=1.5, C=1),
+        "3d_k4": dict(spatial_dims=3, data_size=[1, 4, 12, 10, 14], vector_size=[3, 2, 4], epsilon=1.5, C=4),
+        "3d_bigeps": dict(spatial_dims=3, data_size=[2, 1, 16, 16, 8], vector_size=[4, 4, 2], epsilon=400.0, C=1),
+    }
+    for i, (tag, c) in enumerate(g3.items()):
+        cfg = dict(epsilon=c["epsilon"], data_size=c["data_size"], vector_size=c["vector_size"])
+        t = aug.AdvMorph(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
+        torch.manual_seed(500 + i)
+        t.init_parameters()
+        p = t.unit_normalize(rand(tuple(t.param.shape), 600 + i)).detach().requires_grad_(True)
+        t.param = p
+        data = smooth_data(c["data_size"][0], c["C"], c["data_size"][2:], 700 + i)
+        w = rand(tuple(data.shape), 800 + i)
+
+        def grads():
+            res = []
+            for fn in (lambda: t.forward(data), lambda: t.backward(data), lambda: t.backward(t.forward(data))):
+                p.grad = None
+                (fn() * w).sum().backward()
+                res.append(p.grad.clone())
+            p.grad = None
+            return res
+        base = grads()
+        orig = t.DemonsCompose
+        key = "sens_%s_" % tag
+        meta[key] = dict(trials=4, amplitudes=AMPLITUDES, note="rel_spread[k][j]: max over trials of "
+                         "max|grad_j(jittered) - grad_j| / max|grad_j| for j = fwd, bwd, roundtrip at AMPLITUDES[k] "
+                         "(0 = one ulp, else uniform in [-A, A], in normalised grid units)")
+        spreads = []
+        for amp in AMPLITUDES:
+            worst = [0.0, 0.0, 0.0]
+            for trial in range(4):
+                calls = [0]
+
+                def jittered(*a, **k):
+                    calls[0] += 1
+                    q = orig(*a, **k)
+                    if amp == 0:
+                        return _one_ulp(q, 17 * trial + calls[0])
+                    g = torch.Generator().manual_seed(1000 * trial + calls[0])
+                    return q + (torch.rand(q.shape, generator=g) * 2 - 1) * amp
+                t.DemonsCompose = jittered
+                pert = grads()
+                t.DemonsCompose = orig
+                for j in range(3):
+                    worst[j] = max(worst[j], float((pert[j] - base[j]).abs().max() / base[j].abs().max()))
+            spreads.append(worst)
+            print("  jitter %-8g spread %-10s fwd %.2e bwd %.2e roundtrip %.2e" % (amp, tag, *worst))
+        meta[key]["rel_spread"] = spreads
+    out["meta"] = meta
+    save("g8_kinks", out)
+
+
+ONLY = []
+
+
 def main():
+    global ONLY
+    ONLY = sys.argv[1:]
     torch.manual_seed(0)
     torch.set_num_threads(8)
     aug = import_reference()
-    g1_grid_sample()
-    g2_bias(aug)
-    g3_morph(aug)
-    g4_affine(aug)
-    g5_loss()
-    g6_solver(aug)
-    kat(aug)
+
+    def want(name):
+        return not ONLY or any(o == name or o.startswith(name + "_") for o in ONLY)
+    if want("g1"):
+        g1_grid_sample()
+    if want("g2"):
+        g2_bias(aug)
+    if want("g3"):
+        g3_morph(aug)
+    if want("g4"):
+        g4_affine(aug)
+    if want("g5"):
+        g5_loss()
+    if want("g6"):
+        g6_solver(aug)
+    if want("g7"):
+        g7_misc(aug)
+    if want("g8"):
+        g8_kinks(aug)
+    if want("kat"):
+        kat(aug)
 
 
 if __name__ == "__main__":

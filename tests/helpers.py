@@ -1,5 +1,7 @@
 """Shared test helpers: golden-fixture loading and oracle construction (tests only)."""
+import contextlib
 import json
+import math
 import os
 
 import numpy as np
@@ -72,3 +74,77 @@ def oracle_chain(spec):
 
 def maxdiff(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+# ------------------------------------------------------------------ BatchNorm / Fixable*Dropout test models (a11)
+def device_independent(dropout_cls):
+    """Subclass of a Fixable{2,3}DDropout class (the reference's, the product's or the oracle's) that keeps the parent's
+    seed / lazy_load logic but draws the (N, C, 1, ...) feature mask on the CPU generator, so that a CPU reference run
+    and a GPU product run see the same mask for the same seed (the CUDA and CPU generators differ)."""
+    class DeviceIndependentDropout(dropout_cls):
+        def forward(self, X):
+            ones = torch.ones(X.shape[0], X.shape[1], *([1] * (X.dim() - 2)))
+            return X * super().forward(ones).to(X.device)
+    return DeviceIndependentDropout
+
+
+@contextlib.contextmanager
+def counted_torch_seed(start=1000):
+    """``torch.seed()`` draws from the OS: inside this block it returns start+1, start+2, ... instead, so that runs of
+    models with Fixable*Dropout layers are reproducible (same patch in oracle/make_golden.py and in the tests)."""
+    orig, state = torch.seed, [start]
+
+    def fake():
+        state[0] += 1
+        torch.manual_seed(state[0])
+        return state[0]
+    torch.seed = fake
+    try:
+        yield
+    finally:
+        torch.seed = orig
+
+
+def bn_dropout_model(sd, kind, make_dropout):
+    """Conv + BatchNorm + Fixable dropout models with closed-form weights.  ``make_dropout(p)`` builds the dropout
+    layer (so the same architecture is built on the reference's, the product's and the oracle's layer classes).
+      'train': Conv(1,4,3) -> BN(4) -> Dropout(0.3) -> Conv(4,4,1), left in train() mode (the SSL use of README:175-278)
+      'eval' : Conv(1,4,3) -> BN(4) -> Dropout(0.1) -> Softmax(dim=1) in eval() mode with non-trivial running
+               statistics (the 3D notebook's toy model, example/adv_chain_data_generation_cardiac_2D_3D.ipynb cell 26)"""
+    conv = torch.nn.Conv2d if sd == 2 else torch.nn.Conv3d
+    bn = torch.nn.BatchNorm2d if sd == 2 else torch.nn.BatchNorm3d
+    first = make_model(sd)
+    norm = bn(4)
+    c = torch.arange(4.)
+    norm.weight.data = 1 + 0.1 * c
+    norm.bias.data = 0.05 * c
+    norm.running_mean.data = 0.1 * c - 0.1
+    norm.running_var.data = 1 + 0.2 * c
+    if kind == "train":
+        last = conv(4, 4, 1)
+        w = torch.tensor([[0.25 * math.cos(1.3 * q + 0.7 * k) for k in range(4)] for q in range(4)])
+        last.weight.data = w.reshape(4, 4, *([1] * sd)).contiguous()
+        last.bias.data = 0.02 * c
+        return torch.nn.Sequential(first, norm, make_dropout(0.3), last).train()
+    return torch.nn.Sequential(first, norm, make_dropout(0.1), torch.nn.Softmax(dim=1)).eval()
+
+
+def make_model_multi(spatial_dims, in_ch, k=4, device="cpu"):
+    """Conv(in_ch,k,3,1,1): channel c of the single-channel closed-form kernel scaled by (1 - 0.3 c)."""
+    base = make_model(spatial_dims, k)
+    conv = (torch.nn.Conv2d if spatial_dims == 2 else torch.nn.Conv3d)(in_ch, k, 3, 1, 1)
+    conv.weight.data = torch.cat([base.weight.data * (1 - 0.3 * c) for c in range(in_ch)], dim=1).contiguous()
+    conv.bias.data = base.bias.data.clone()
+    return conv.eval().to(device)
+
+
+def fixture_model(meta, dropout_classes, device="cpu"):
+    """The model a g6 fixture was generated with; ``dropout_classes`` = (2D class, 3D class) of the implementation under
+    test (product layers, or the oracle's)."""
+    sd = meta["spatial_dims"]
+    if meta.get("model"):
+        cls = device_independent(dropout_classes[sd - 2])
+        return bn_dropout_model(sd, meta["model"], lambda p: cls(p)).to(device)
+    if meta.get("in_ch", 1) > 1:
+        return make_model_multi(sd, meta["in_ch"], device=device)
+    return make_model(sd, device=device)

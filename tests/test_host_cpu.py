@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from tests import cpu_backend
-from tests.helpers import Fixture, make_model, maxdiff, rand, smooth_data
+from tests.helpers import Fixture, counted_torch_seed, fixture_model, make_model, maxdiff, rand, smooth_data
 
 CPU = torch.device("cpu")
 
@@ -123,7 +123,24 @@ def test_loss_normalisers_match_the_reference(cpu_ops):
 
 
 G6_CASES = ["2d_full_n1", "2d_full_n3", "2d_full_n2_norm", "2d_smart_n2", "2d_power_n2", "2d_kl_n1",
-            "2d_photometric_n2", "2d_step_n2", "3d_bma_n2", "3d_full_n1", "3d_morph_anat_n2", "2d_n0"]
+            "2d_photometric_n2", "2d_step_n2", "3d_bma_n2", "3d_full_n1", "3d_morph_anat_n2", "2d_n0",
+            "2d_bn_drop_train_n2", "3d_bn_drop_eval_n2", "2d_bias_gauss_c2_n2", "2d_isgt_n1"]
+
+
+def product_dropout_classes():
+    from advchain_amd.common.layers import Fixable2DDropout, Fixable3DDropout
+    return Fixable2DDropout, Fixable3DDropout
+
+
+def check_model_state(model, fx):
+    """a11: the BatchNorm statistics saw exactly the reference's updates (only the final model.train() pass of
+    calc_adv_consistency_loss tracks them) and the Fixable*Dropout seed / lazy_load ended where the reference's did."""
+    assert maxdiff(model[1].running_mean.cpu(), fx.t("bn_running_mean")) < 2e-5
+    assert maxdiff(model[1].running_var.cpu(), fx.t("bn_running_var")) < 2e-5
+    assert int(model[1].num_batches_tracked) == int(fx.arr("bn_num_batches"))
+    assert int(model[2].seed) == int(fx.arr("dropout_seed"))
+    assert bool(model[2].lazy_load) == bool(fx.arr("dropout_lazy_load"))
+    assert bool(model.training) == bool(fx.arr("model_training"))
 
 
 @pytest.mark.parametrize("case", G6_CASES)
@@ -140,8 +157,11 @@ def test_solver_control_flow_reproduces_reference_runs(cpu_ops, case):
     kw = dict(meta["train"])
     if meta["has_anatomy"]:
         kw["anatomy_mask_images"] = fx.t("anatomy")
-    with contextlib.redirect_stdout(io.StringIO()):
-        loss = solver.adversarial_training(data=fx.t("data"), model=make_model(meta["spatial_dims"]), **kw)
+    model = fixture_model(meta, product_dropout_classes())
+    with contextlib.redirect_stdout(io.StringIO()), counted_torch_seed(1000):
+        loss = solver.adversarial_training(data=fx.t("data"), model=model, **kw)
+    if meta.get("model"):
+        check_model_state(model, fx)
     assert abs(float(loss) - fx.f("final_loss")) < 1e-7 + 2e-4 * abs(fx.f("final_loss"))
     assert maxdiff(solver.adv_data, fx.t("adv_data")) < 1e-4
     assert len(solver.chain_of_transforms) == meta["n_transforms"]

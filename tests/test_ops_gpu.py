@@ -272,6 +272,85 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
         assert maxdiff(g2s.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dims,bound", [((8, 12, 16), 1), ((9, 18, 64), 1), ((24, 40), 1), ((24, 40), 2), ((40, 72), 4)])
+def test_strict_gather_at_the_displacement_boundary(dims, bound):
+    """Exact-bound (negative halo) gather-form adjoint with samples displaced by bound - 1.1e-3 voxels along every axis
+    and sign -- right under the `disp < bound - 1e-3` rule of ops.squaring_halo / ops.warp_halo that selects it: a
+    dropped sample would show as a missing deposit against autograd through F.grid_sample."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = len(dims)
+    g = torch.Generator().manual_seed(5)
+    disp = (torch.rand((2, d) + dims, generator=g) * 2 - 1) * 0.4 * bound            # background: well inside the bound
+    edge = bound - 1.1e-3
+    for a in range(d):                 # a few samples per axis at +-(bound - 1.1e-3) voxels, away from the volume border
+        for sgn in (1.0, -1.0):
+            for _ in range(6):
+                idx = [int(torch.randint(0, 2, (1,), generator=g))] + [a] + \
+                      [int(torch.randint(bound + 1, s - bound - 1, (1,), generator=g)) for s in dims]
+                disp[tuple(idx)] = sgn * edge
+    scale = torch.tensor([2.0 / (dims[d - 1 - a] - 1) for a in range(d)]).view(1, d, *([1] * d))
+    phi = (O.identity_grid(2, dims) + disp * scale).contiguous()
+    measured = float(ops.raw_max_displacement(phi.to(DEV)).item())
+    assert bound - 2e-3 < measured < bound - 1e-3, measured
+    assert ops.squaring_halo(measured, d) == -bound          # the product's rule picks the exact gather form here
+    w = rand((2, d) + dims, 33)
+    p = phi.clone().requires_grad_(True)
+    (O.compose_fields(p, p) * w).sum().backward()
+    ws = ops._scatter_workspace(2, dims, DEV)
+    got = ops.raw_compose_self_bwd(w.to(DEV), phi.to(DEV), ws, chain=False, halo=-bound)
+    assert maxdiff(got.cpu(), p.grad) < 5e-5 * max(1.0, float(p.grad.abs().max()))
+    # the same field as an image warp (C = 1 and 4), exact bound
+    for C in (1, 4):
+        inp, wo = rand((2, C) + dims, 34), rand((2, C) + dims, 35)
+        a, gr = inp.clone().requires_grad_(True), phi.clone().requires_grad_(True)
+        perm = (0, 2, 3, 1) if d == 2 else (0, 2, 3, 4, 1)
+        (F.grid_sample(a, gr.permute(*perm), padding_mode="zeros", align_corners=True) * wo).sum().backward()
+        gin, ggrid = ops.raw_grid_sample_bwd(wo.to(DEV), inp.to(DEV), phi.to(DEV), 0, 0, False, True, True, -bound)
+        assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max())), C
+        assert maxdiff(ggrid.cpu(), gr.grad) < 5e-5 * max(1.0, float(gr.grad.abs().max())), C
+
+
+@pytest.mark.parametrize("dims,vs", [((16, 16, 16), [4, 4, 4]), ((32, 48), [4, 6])])
+@pytest.mark.parametrize("window", [(0.9975, 0.9990), (0.9990, 1.0005)])
+def test_demons_field_backward_across_the_gather_threshold(dims, vs, window):
+    """Through the PRODUCT path (ops.demons_field forward measures the displacement of every squaring, its backward
+    picks the form per step): velocities scaled by bisection until the last squaring's measured displacement lies just
+    below / just above the 0.999-voxel rule, gradients vs autograd through the oracle's DemonsCompose."""
+    from oracle import advchain_oracle as O
+    from advchain_amd import bands
+    ops = _ops()
+    d = len(dims)
+    vel = O.unit_normalize(rand((2, d) + tuple(vs), 71))
+    tables = bands.upsample_tables(list(vs), list(dims), torch.device(DEV))
+
+    def last_step_disp(scale):
+        q = ops.demons_field(vel.to(DEV), scale, tables, d == 3)
+        rb, n = q._advchain_disp[0], q._advchain_disp[3]
+        return rb.values()[n - 1], n           # displacement of phi_{n-1}, the input of the last squaring
+    lo, hi = 0.05, 60.0
+    scale = None
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        dm, n = last_step_disp(mid)
+        if window[0] <= dm < window[1]:
+            scale = mid
+            break
+        if dm < window[0]:
+            lo = mid
+        else:
+            hi = mid
+    assert scale is not None, (lo, hi)
+    assert ops.squaring_halo(dm, d) == (-1 if window[1] <= 0.9991 else (2 if d == 3 else -2))
+    gq = rand((2, d) + tuple(dims), 72)
+    pc = vel.clone().requires_grad_(True)
+    O.demons_compose(scale * pc, dims, final_clamp=False).backward(gq)
+    pg = vel.to(DEV).requires_grad_(True)
+    ops.demons_field(pg, scale, tables, d == 3).backward(gq.to(DEV))
+    err = maxdiff(pg.grad.cpu(), pc.grad) / float(pc.grad.abs().max())
+    assert err < 1e-4, (dims, window, scale, dm, err)
+
+
 def _smooth_field(dims, amp_vox, seed):
     """identity + a smooth displacement of up to ~amp_vox voxels (low-resolution noise, upsampled)."""
     from oracle import advchain_oracle as O
@@ -477,14 +556,8 @@ def test_bias_data_gradient():
 
 def test_demons_field_golden():
     """G3: DemonsCompose grid (+/- velocity) and warps vs the reference (tight), composite velocity gradients
-    vs the reference (loose, see below) and the hand-written Demons adjoint vs the oracle for IDENTICAL
-    upstream gradients (tight).
-
-    Why two tolerances: the derivative of a (bi/tri)linear interpolant w.r.t. the sampling position jumps at
-    the grid nodes, and a near-zero displacement component parks samples within ~1e-5 px of a node, where
-    rounding-level differences in the field (scaling-and-squaring doubles them 8 times: ~3e-6) select the left
-    or the right cell.  A handful of such voxels per volume move the composite gradient by up to ~1e-3 of its
-    scale; with identical coordinates (operator tests above, adjoint test below) the agreement is ~1e-5."""
+    (test_morph_composite_gradients_kink_margin_and_sensitivity, which ties the allowance to the reference's own
+    sensitivity) and the hand-written Demons adjoint vs the oracle for IDENTICAL upstream gradients (tight)."""
     from advchain_amd.augmentor import AdvMorph
     from oracle import advchain_oracle as O
     ops = _ops()
@@ -504,22 +577,16 @@ def test_demons_field_golden():
         o = t.forward(data)
         (o * w).sum().backward()
         assert maxdiff(o.cpu(), fx.t(key + "forward")) < vtol, key
-        g = fx.t(key + "grad_param_fwd")
-        assert maxdiff(p.grad.cpu(), g) < 2e-3 * float(g.abs().max()), key
-        p.grad = None
+        p.grad = None      # composite gradients: test_morph_composite_gradients_kink_margin_and_sensitivity
         ob = t.backward(data)
         (ob * w).sum().backward()
         assert maxdiff(ob.cpu(), fx.t(key + "backward")) < vtol, key
-        g = fx.t(key + "grad_param_bwd")
-        assert maxdiff(p.grad.cpu(), g) < 2e-3 * float(g.abs().max()), key
         p.grad = None
         dd = data.clone().requires_grad_(True)
         rt = t.backward(t.forward(dd))
         (rt * w).sum().backward()
         assert maxdiff(rt.cpu(), fx.t(key + "roundtrip")) < vtol, key
         assert maxdiff(dd.grad.cpu(), fx.t(key + "roundtrip_grad_data")) < (2e-4 if big else 5e-5), key
-        g = fx.t(key + "roundtrip_grad_param")
-        assert maxdiff(p.grad.cpu(), g) < 2e-3 * float(g.abs().max()), key
         assert maxdiff(t.forward(data, padding_mode="border").cpu(), fx.t(key + "forward_border")) < vtol
         nn_out = t.forward(data, interp="nearest").cpu()
         assert float((nn_out - fx.t(key + "forward_nearest")).abs().gt(1e-6).float().mean()) < 5e-3
@@ -601,6 +668,140 @@ def test_consistency_loss_golden():
                 assert abs(float(v) - fx.f(k + "value")) < 1e-7 + 2e-5 * abs(fx.f(k + "value")), k
                 g = fx.t(k + "grad")
                 assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, k
+
+
+def test_consistency_loss_golden_is_gt_and_one_channel_mask():
+    """G5: is_gt=True (one-hot reference used as given, loss.py:55-60,66-69,232-238) and a caller's ONE-channel mask,
+    whose numel enters the 'mse' normaliser (loss.py:64)."""
+    from advchain_amd.common.loss import calc_segmentation_consistency
+    fx = Fixture("g5_loss")
+    for tag in ("2d", "3d"):
+        mask, onehot = fx.t(tag + "_mask", DEV), fx.t(tag + "_onehot", DEV)
+        for name, types, weights in (("mse", ["mse"], [1.0]), ("contour", ["contour"], [1.0]), ("kl", ["kl"], [1.0]),
+                                     ("mix", ["mse", "contour"], [1.0, 0.5])):
+            pred = fx.t(tag + "_pred", DEV).requires_grad_(True)
+            v = calc_segmentation_consistency(output=pred, reference=onehot, divergence_types=types,
+                                              divergence_weights=weights, scales=[0], mask=mask, is_gt=True)
+            v.backward()
+            k = "%s_%s_isgt_" % (tag, name)
+            assert abs(float(v) - fx.f(k + "value")) < 1e-7 + 2e-5 * abs(fx.f(k + "value")), k
+            g = fx.t(k + "grad")
+            assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, k
+        pred = fx.t(tag + "_pred", DEV).requires_grad_(True)
+        v = calc_segmentation_consistency(output=pred, reference=fx.t(tag + "_ref", DEV), divergence_types=["mse", "contour"],
+                                          divergence_weights=[1.0, 0.5], scales=[0], mask=fx.t(tag + "_mask1", DEV))
+        v.backward()
+        ref = fx.f(tag + "_mix_mask1_value")
+        assert abs(float(v) - ref) < 1e-7 + 2e-5 * abs(ref), tag
+        g = fx.t(tag + "_mix_mask1_grad")
+        assert maxdiff(pred.grad.cpu(), g) < 2e-5 * float(g.abs().max()) + 1e-10, tag
+
+
+def test_ignore_values_init_modes_multichannel_golden():
+    """G7: ignore_values of AdvNoise / AdvBias (adv_noise.py:85-89, adv_bias.py:176-184), AdvBias init modes and their
+    clamp bounds (adv_bias.py:237-252, 136-137), the multi-channel bias expand (adv_bias.py:170-171)."""
+    from advchain_amd.augmentor import AdvBias, AdvNoise
+    fx = Fixture("g7_misc")
+    meta = fx.json()
+    dev = torch.device(DEV)
+    for tag in ("2d", "3d"):
+        data, w = fx.t(tag + "_data", DEV), fx.t(tag + "_w", DEV)
+        m = meta[tag + "_noise"]
+        t = AdvNoise(spatial_dims=m["spatial_dims"], config_dict=m["config"], ignore_values=m["ignore_values"], device=dev)
+        t.init_parameters()
+        p = fx.t(tag + "_noise_param", DEV).requires_grad_(True)
+        t.param = p
+        o = t.forward(data)
+        (o * w).sum().backward()
+        assert maxdiff(o.cpu(), fx.t(tag + "_noise_out")) < 1e-6
+        assert maxdiff(p.grad.cpu(), fx.t(tag + "_noise_grad")) < 1e-6
+        assert int((o.detach() == m["ignore_values"]).sum()) == m["n_ignored"]
+        for space in ("log", "linear"):
+            k = "%s_bias_%s_" % (tag, space)
+            m = meta[k]
+            t = AdvBias(spatial_dims=m["spatial_dims"], config_dict=m["config"], ignore_values=m["ignore_values"], device=dev)
+            t.init_parameters()
+            p = fx.t(k + "param", DEV).requires_grad_(True)
+            t.param = p
+            o = t.forward(data)
+            (o * w).sum().backward()
+            assert list(t.bias_field.shape) == m["field_shape"], k
+            assert maxdiff(o.cpu(), fx.t(k + "out")) < 5e-6, k
+            assert maxdiff(t.bias_field.cpu(), fx.t(k + "field")) < 5e-6, k
+            g = fx.t(k + "grad")
+            assert maxdiff(p.grad.cpu(), g) < 2e-5 * max(1.0, float(g.abs().max())), k
+        for mode in ("gaussian", "identity", "random"):
+            k = "%s_init_%s_" % (tag, mode)
+            m = meta[k]
+            t = AdvBias(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=dev)
+            torch.manual_seed(7)
+            t.init_parameters()
+            assert list(t.param.shape) == m["shape"]
+            assert float(t.low) == m["low"] and float(t.high) == m["high"], k
+            if mode == "identity":
+                assert float(t.param.abs().max()) == 0.0
+            elif mode == "gaussian":      # N(0, 0.5) control points (different generator: statistics only)
+                assert 0.2 < float(t.param.std()) < 0.9
+            else:
+                assert float(t.param.min()) >= m["low"] - 1e-6 and float(t.param.max()) <= m["high"] + 1e-6
+            t.param = fx.t(k + "param_in", DEV).clone()
+            t.rescale_parameters()
+            assert maxdiff(t.param.cpu(), fx.t(k + "param_rescaled")) < 1e-7, k
+            assert maxdiff(t.forward(data).cpu(), fx.t(k + "forward")) < 5e-6, k
+
+
+def test_morph_composite_gradients_kink_margin_and_sensitivity():
+    """G8.  The composite gradient image warp -> field -> velocity of AdvMorph is a piecewise-smooth function of the
+    field: the derivative of a (bi/tri)linear interpolant jumps where a sampling coordinate crosses a grid node.
+    (a) On the kink-margin cases (no coordinate of either field within 1e-3 px of a node; seeds searched by
+        oracle/make_golden.py) the HIP path must match the REFERENCE gradients to 1e-4 of their scale.
+    (b) On the G3 cases the allowance is tied to evidence: the fixture stores by how much the reference's OWN
+        gradients move when its field is jittered by A (normalised units) for A in `amplitudes`; the GPU field is
+        compared with the reference's, the smallest A covering that difference is looked up, and the gradient
+        error may not exceed max(1e-4, 2 x the reference's own spread at A)."""
+    from advchain_amd.augmentor import AdvMorph
+    fx = Fixture("g8_kinks")
+    g3 = Fixture("g3_morph")
+    meta = fx.json()
+    for key, m in meta.items():
+        if not key.startswith("margin_"):
+            continue
+        t = AdvMorph(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
+        t.init_parameters()
+        p = fx.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        data, w = fx.t(key + "data", DEV), fx.t(key + "w", DEV)
+        for fn, name in ((lambda: t.forward(data), "fwd"), (lambda: t.backward(data), "bwd"),
+                         (lambda: t.backward(t.forward(data)), "roundtrip")):
+            p.grad = None
+            out = fn()
+            (out * w).sum().backward()
+            g = fx.t(key + ("roundtrip_grad_param" if name == "roundtrip" else "grad_param_" + name))
+            err = maxdiff(p.grad.cpu(), g) / float(g.abs().max())
+            assert err < TOL, (key, name, err)
+            ref_out = fx.t(key + {"fwd": "forward", "bwd": "backward", "roundtrip": "roundtrip"}[name])
+            assert maxdiff(out.cpu(), ref_out) < 2e-5, (key, name)
+    for key, m in g3.json().items():
+        sens = meta["sens_" + key]
+        t = AdvMorph(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
+        t.init_parameters()
+        p = g3.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        data, w = g3.t(key + "data", DEV), g3.t(key + "w", DEV)
+        with torch.no_grad():
+            dq = max(maxdiff(t.get_deformation_displacement_field(duv=s * t.epsilon * p)[0].cpu(), g3.t(key + nm))
+                     for s, nm in ((1.0, "dxy_fwd"), (-1.0, "dxy_bwd")))
+        amps = [a if a > 0 else 6e-8 for a in sens["amplitudes"]]
+        level = next((i for i, a in enumerate(amps) if dq <= a), None)
+        assert level is not None, (key, "field differs from the reference's by %.2e" % dq)
+        for j, (fn, gname) in enumerate(((lambda: t.forward(data), "grad_param_fwd"), (lambda: t.backward(data), "grad_param_bwd"),
+                                         (lambda: t.backward(t.forward(data)), "roundtrip_grad_param"))):
+            p.grad = None
+            (fn() * w).sum().backward()
+            g = g3.t(key + gname)
+            err = maxdiff(p.grad.cpu(), g) / float(g.abs().max())
+            allowed = max(TOL, 2.0 * sens["rel_spread"][level][j])
+            assert err < allowed, (key, gname, "err %.2e field diff %.2e allowed %.2e" % (err, dq, allowed))
 
 
 @pytest.mark.parametrize("dims", [(12, 64), (9, 128), (5, 6, 64), (3, 4, 128), (7, 9, 80), (11, 20), (13, 100), (4, 5, 36),

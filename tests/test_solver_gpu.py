@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import Fixture, make_model, maxdiff, rand, smooth_data
+from tests.helpers import Fixture, counted_torch_seed, fixture_model, make_model, maxdiff, rand, smooth_data
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -35,11 +35,26 @@ def make_solver(fx):
         t.init_parameters()
         t.set_parameters(fx.t("init_param_%d" % i, DEV))
     solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, **meta["solver"])
-    return solver, chain, meta, make_model(meta["spatial_dims"], device=DEV)
+    from advchain_amd.common.layers import Fixable2DDropout, Fixable3DDropout
+    return solver, chain, meta, fixture_model(meta, (Fixable2DDropout, Fixable3DDropout), device=DEV)
 
 
 G6_CASES = ["2d_full_n1", "2d_full_n3", "2d_full_n2_norm", "2d_smart_n2", "2d_power_n2", "2d_kl_n1",
-            "2d_photometric_n2", "2d_step_n2", "3d_bma_n2", "3d_full_n1", "3d_morph_anat_n2", "2d_n0"]
+            "2d_photometric_n2", "2d_step_n2", "3d_bma_n2", "3d_full_n1", "3d_morph_anat_n2", "2d_n0",
+            # a11: Conv + BatchNorm + Fixable*Dropout models (train()-mode with replayed mask; the notebook's eval()-mode
+            # toy model); AdvBias init_mode='gaussian' on 2-channel data; is_gt=True
+            "2d_bn_drop_train_n2", "3d_bn_drop_eval_n2", "2d_bias_gauss_c2_n2", "2d_isgt_n1"]
+
+
+def check_model_state(model, fx):
+    """The BatchNorm statistics saw exactly the reference's updates and the Fixable*Dropout seed / lazy_load flags
+    ended where the reference's did (adv_compose_solver.py:256-259,315-316, common/utils.py:114-173)."""
+    assert maxdiff(model[1].running_mean.cpu(), fx.t("bn_running_mean")) < 2e-5
+    assert maxdiff(model[1].running_var.cpu(), fx.t("bn_running_var")) < 2e-5
+    assert int(model[1].num_batches_tracked) == int(fx.arr("bn_num_batches"))
+    assert int(model[2].seed) == int(fx.arr("dropout_seed"))
+    assert bool(model[2].lazy_load) == bool(fx.arr("dropout_lazy_load"))
+    assert bool(model.training) == bool(fx.arr("model_training"))
 
 
 def _kwargs(fx, meta):
@@ -54,8 +69,10 @@ def test_free_running(case):
     """Whole adversarial_training call vs the reference (horizons <= 3 steps on smooth data)."""
     fx = Fixture("g6_" + case)
     solver, chain, meta, model = make_solver(fx)
-    with contextlib.redirect_stdout(io.StringIO()):
+    with contextlib.redirect_stdout(io.StringIO()), counted_torch_seed(1000):
         loss = solver.adversarial_training(data=fx.t("data", DEV), model=model, **_kwargs(fx, meta))
+    if meta.get("model"):
+        check_model_state(model, fx)
     ref = fx.f("final_loss")
     n_iter = meta["train"]["n_iter"]
     assert maxdiff(solver.init_output.cpu(), fx.t("init_output")) < 1e-5
@@ -97,6 +114,11 @@ def test_teacher_forced_steps(case):
         t.power_iteration = pi
     step_sizes = kw.get("step_sizes", 1)
     step_sizes = [step_sizes] * n_t if isinstance(step_sizes, (int, float)) else step_sizes
+    with counted_torch_seed(1000):
+        _teacher_forced(case, fx, solver, chain, meta, model, data, kw, n_steps, n_t, step_sizes)
+
+
+def _teacher_forced(case, fx, solver, chain, meta, model, data, kw, n_steps, n_t, step_sizes):
     init_output = solver.get_init_output(model, data)
     anatomy = kw.get("anatomy_mask_images")
     loss_trace = fx.arr("loss_trace")
