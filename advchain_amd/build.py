@@ -34,25 +34,48 @@ def torch_lib_dir():
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared library.  Returns its path."""
-    if not force and not _stale():
-        return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tl = torch_lib_dir()
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "-I" + os.path.join(HERE, "..", "include"), "-I" + CSRC]
-    cmd += sources()
-    cmd += ["-o", LIB_PATH, "-no-hip-rt", "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl]
+def _compile_one(args):
+    hipcc, src, obj, flags, verbose = args
+    cmd = [hipcc, "-c"] + flags + [src, "-o", obj]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return src, res.returncode, res.stdout
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 (one object per source, in parallel, rebuilt only when the source or a header
+    is newer) and link them into one shared library.  Returns its path."""
+    if not force and not _stale():
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tl = torch_lib_dir()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+             "-I" + os.path.join(HERE, "..", "include"), "-I" + CSRC]
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    newest_header = max([os.path.getmtime(h) for h in headers] + [os.path.getmtime(os.path.abspath(__file__))])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append((hipcc, src, obj, flags, verbose))
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        for src, rc, log in pool.map(_compile_one, jobs):
+            if rc != 0:
+                sys.stderr.write(log)
+                raise RuntimeError("hipcc failed compiling %s" % src)
+            if verbose:
+                print(log)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + \
+          ["-o", LIB_PATH, "-no-hip-rt", "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
-        raise RuntimeError("hipcc failed building %s" % LIB_PATH)
-    if verbose:
-        print(res.stdout)
+        raise RuntimeError("hipcc failed linking %s" % LIB_PATH)
     return LIB_PATH
 
 

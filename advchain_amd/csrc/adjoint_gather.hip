@@ -592,6 +592,12 @@ static void launch_gather(const float* gout, const float* in, const float* grid,
 // rows that are not 16-byte aligned are staged with dword loads (launch_gather: kUnaligned)
 static bool gather_shape_ok(const Dims& d) { return d.s2 >= 8; }
 
+// adjoint_march.hip: z-marching form for exact sub-voxel bounds in 3D
+int advchain_self_adjoint_march_launch(const float* gout, const float* phi, float* gphi, int64_t N, Dims d,
+                                       int32_t* workspace, hipStream_t st);
+int advchain_warp_adjoint_march_launch(const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                       int64_t N, int64_t C, Dims d, int padding, int clamp_grid, hipStream_t st);
+
 // Self-composition backward in gather form.  `halo` is the caller's displacement bound in voxels; shapes or bounds the
 // gather form does not cover return ADVCHAIN_ERR_UNSUPPORTED (the caller uses the LDS-tiled scatter).
 // Workspace protocol identical to advchain_scatter_tiled_launch (header [0] overflow count, [3] max|result|).
@@ -601,6 +607,10 @@ int advchain_self_adjoint_gather_launch(const float* gout, const float* phi, flo
   const bool strict = halo < 0;     // negative: exact bound |halo|, guaranteed by the caller
   if (strict) halo = -halo;
   if (off || !workspace || halo < 1 || !gather_shape_ok(d)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (strict && ndim == 3 && halo == 1) {
+    const int rc = advchain_self_adjoint_march_launch(gout, phi, gphi, N, d, workspace, st);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
 #define SELF_GO(DIM_, H_, TZ_, TY_, NT_) \
   launch_gather<DIM_, DIM_, H_, true, false, TZ_, TY_, NT_>(gout, phi, phi, gphi, nullptr, N, d, PAD_BORDER, 0, workspace, chain, strict, st)
   if (ndim == 3) {
@@ -627,6 +637,10 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
   if (off || !workspace || halo < 1 || !gin || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   if (!gather_shape_ok(d)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (C != 1 && C != 4) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (strict && ndim == 3 && halo == 1) {
+    const int rc = advchain_warp_adjoint_march_launch(gout, in, grid, gin, ggrid, N, C, d, padding, clamp_grid, st);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
 #define WARP_GO(DIM_, C_, H_, GG_, TZ_, TY_, NT_) \
   launch_gather<DIM_, C_, H_, false, GG_, TZ_, TY_, NT_>(gout, in, grid, gin, ggrid, N, d, padding, clamp_grid, workspace, 0, strict, st)
   const bool gg = ggrid != nullptr;
