@@ -14,7 +14,14 @@
 //     step): the loads of step k+1 are in flight under the arithmetic of step k.  The image / field planes the
 //     coordinate path needs (z-1, z, z+1 around a sample) live in a 4-slot ring, staged two steps ahead.
 //   * with |p - s| < 1 guaranteed the tents need no general max(0, 1 - |f - k|): t(-1) = max(0, -f), t(+1) = max(0, f),
-//     t(0) = 1 - t(-1) - t(+1).
+//     t(0) = 1 - t(-1) - t(+1); the lower corner of an axis is s + floor(f) with floor(f) in {-1, 0}.
+//   * staged rows carry 4 zero floats on either side of their 64 voxels: a corner at x = -1 or x = S2 reads the 0 that
+//     zeros padding asks for, without a select; rows and planes outside the volume are staged as zeros.
+//   * results leave through LDS: a wave writes its rows lane <-> x and reads them back 4 voxels per lane, so that two
+//     16-byte store instructions replace eight 4-byte ones (a vector-memory instruction costs the CU ~26 clk whether
+//     it carries 4 or 16 bytes per lane).
+//   * padding mode and clamp are template parameters: run-time selects on per-lane conditions cost scalar-ALU
+//     instructions (64-bit lane masks), and the first version of this kernel issued 470 of them per wave and step.
 //
 // Contract: the caller guarantees |unnormalize(grid) - s| < 1 voxel for every sample (ops.squaring_halo / ops.warp_halo
 // measure it in the forward).  Shapes outside the fast form (rows longer than 64 voxels, rows not a multiple of 4,
@@ -24,36 +31,47 @@
 
 namespace advchain {
 
-constexpr int kMarchClip = 1;     // sampling positions are clipped to [0, S-1] (border padding and/or clamp_grid)
-constexpr int kMarchBorder = 2;   // border padding: zero coordinate gradient AT and beyond the border (else: beyond only)
+// MODE: 0 = zeros padding, positions as given; 1 = positions clipped to [0, S-1] (clamp_grid), zero coordinate gradient
+// beyond the border; 2 = border padding (clipped, zero coordinate gradient AT and beyond the border)
+enum { kMarchFree = 0, kMarchClamp = 1, kMarchBorder = 2 };
+// timing experiments only (ADVCHAIN_MARCH_DEBUG, results are wrong): switch a phase off
+constexpr int kDbgNoA = 16, kDbgNoB = 32, kDbgNoStore = 64, kDbgNoStage = 128;
 
 template <int C, bool SELF, bool GG, int NW, int RPW>
 struct MarchCfg {
   static constexpr int TY = NW * RPW;
   static constexpr int R = TY + 2;                              // staged rows per plane (one halo row each side)
   static constexpr int NT = NW * 64;
+  static constexpr int PITCH = 72;                              // 4 zeros | 64 voxels | 4 zeros
   static constexpr bool HAS_IMG = GG && !SELF;
   static constexpr int RING_CH = SELF ? 3 : (HAS_IMG ? C : 0);  // planes z-1..z+1 are needed: 4-slot ring
   static constexpr int LATE_CH = SELF ? 3 : 3 + C;              // only the current plane is needed: 2 slots
-  static constexpr int RING_FLOATS = 4 * RING_CH * R * 64;
-  static constexpr size_t LDS = (size_t)(RING_FLOATS + 2 * LATE_CH * R * 64) * sizeof(float);
+  static constexpr int PS = RING_CH * R * PITCH;                // floats per ring slot
+  static constexpr int LS = LATE_CH * R * PITCH;                // floats per late slot
+  static constexpr int NA = SELF ? 3 : C + (GG ? 3 : 0);        // arrays written per step (grad_in channels, grad_grid)
+  static constexpr int NA_ROUND = NA > 2 ? 2 : NA;              // arrays transposed per round
+  static constexpr int TRW = NA_ROUND * RPW * 64;               // transposition scratch per wave (floats)
+  static constexpr size_t LDS = (size_t)(4 * PS + 2 * LS + NW * TRW) * sizeof(float);
+  static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF && RPW == 1 ? 3 : 2);   // per SIMD: 128 / 168 / 256 VGPRs
   static_assert(R * 16 <= NT, "one staging item (4 voxels of one row, all channels) per thread");
   static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
 };
 
 __device__ __forceinline__ float march_unnormalize(float g, int S) { return ((g + 1.f) * 0.5f) * (float)(S - 1); }
 
-template <int C, bool SELF, bool GG, int NW, int RPW>
-__global__ void __launch_bounds__(NW * 64)
+template <int C, bool SELF, bool GG, int MODE, int NW, int RPW>
+__global__ void __launch_bounds__(NW * 64, (MarchCfg<C, SELF, GG, NW, RPW>::MIN_WAVES))
 k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                 float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int flags,
                 int32_t* __restrict__ untracked) {
   using G = MarchCfg<C, SELF, GG, NW, RPW>;
-  constexpr int R = G::R, TY = G::TY, RC = G::RING_CH, LC = G::LATE_CH;
+  constexpr int R = G::R, TY = G::TY, RC = G::RING_CH, LC = G::LATE_CH, P = G::PITCH, PS = G::PS, LS = G::LS;
+  constexpr bool CLIP = MODE != kMarchFree, BORDER = MODE == kMarchBorder;
   if (untracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) untracked[3] = -1;   // see adjoint_gather.hip
   extern __shared__ float lds[];
-  float* const ring = lds;                       // [slot 4][RC][R][64]
-  float* const late = lds + G::RING_FLOATS;      // [slot 2][LC][R][64]
+  float* const ring = lds;                       // [slot 4][RC][R][P]
+  float* const late = lds + 4 * PS;              // [slot 2][LC][R][P]
+  float* const trbuf = lds + 4 * PS + 2 * LS;    // [wave][TRW]
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -64,8 +82,15 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   const float* gon = gout + (int64_t)n * C * V;
   const float* inn = in + (int64_t)n * C * V;
   float* ginn = gin + (int64_t)n * C * V;
+  float* ggn = GG ? ggrid + (int64_t)n * 3 * V : nullptr;
   const int S[3] = {d.s2, d.s1, d.s0};
-  const bool clip = SELF ? true : (flags & kMarchClip) != 0, border = SELF ? true : (flags & kMarchBorder) != 0;
+  const int plane_stride = d.s1 * d.s2;
+
+  // ---- the zero columns of every staged row (never written again)
+  for (int e = threadIdx.x; e < (4 * RC + 2 * LC) * R * 2; e += G::NT) {
+    const int row = e >> 1, side = e & 1;
+    *reinterpret_cast<float4*>(lds + row * P + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
   const bool has_item = threadIdx.x < R * 16;
@@ -73,101 +98,80 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
   const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
   const int row_off = sy_st * d.s2 + x_st;
-  const int lds_item = r_st * 64 + x_st;
+  const int lds_item = r_st * P + 4 + x_st;
 
-  // field plane p -> offsets o = unnormalize(field) - own voxel (what the tents and the corner search work on)
-  auto load_field = [&](int p, float (&v)[3][4]) {
-    if (row_ok && p >= 0 && p < d.s0) {
-      const int s = p * d.s1 * d.s2 + row_off;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) load_vec<4>(gn + (int64_t)a * V + s, v[a]);
-    } else {
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[a][k] = __int_as_float(0x7fc00000);   // marker: outside the volume
-    }
-  };
-  auto field_to_offsets = [&](int p, float (&v)[3][4]) {
-    const int sc[3] = {x_st, sy_st, p};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xs = march_unnormalize(v[a][k], S[a]);
-        const float sa = (float)(sc[a] + (a == 0 ? k : 0));
-        v[a][k] = (xs > -1.0e9f && xs < 1.0e9f) ? xs - sa : 0.f;            // NaN (outside the volume) -> 0
-      }
-  };
-  auto load_plain = [&](const float* base, int nch, int p, float (*v)[4]) {
-    const bool ok = row_ok && p >= 0 && p < d.s0;
-    const int s = p * d.s1 * d.s2 + row_off;
+  auto plane_ok = [&](int p) { return row_ok && p >= 0 && p < d.s0; };
+  auto load_rows = [&](const float* base, int nch, int p, float (*v)[4]) {
+    const bool ok = plane_ok(p);
+    const uint32_t s = (uint32_t)(p * plane_stride + row_off);
+#pragma unroll 4
     for (int c = 0; c < nch; ++c) {
       if (ok) {
-        const float4 t = *reinterpret_cast<const float4*>(base + (int64_t)c * V + s);
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * V + s);
         v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
       } else {
         v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
       }
     }
   };
-  auto store_lds = [&](float* base, int ch, int nch_total, int slot, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(base + ((slot * nch_total + ch) * R) * 64 + lds_item) = make_float4(v[0], v[1], v[2], v[3]);
+  // field plane p -> offsets o = unnormalize(field) - own voxel (what the tents and the corner search work on)
+  auto field_to_offsets = [&](int p, float (*v)[4]) {
+    const bool ok = plane_ok(p);          // rows / planes outside the volume: offset 0 (their grad_out is 0 as well)
+    const float sa[3] = {(float)x_st, (float)sy_st, (float)p};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xs = march_unnormalize(v[a][k], S[a]);
+        v[a][k] = ok ? xs - (a == 0 ? sa[0] + (float)k : sa[a]) : 0.f;
+      }
+  };
+  auto store_lds = [&](float* slot_base, int ch, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(slot_base + ch * R * P + lds_item) = make_float4(v[0], v[1], v[2], v[3]);
   };
   // ring plane p: SELF -> field offsets; warp with grad_grid -> the image.  late plane p: SELF -> grad_out; warp ->
   // field offsets + grad_out
-  float pr[RC > 0 ? RC : 1][4], pl[LC][4];
-  auto fetch_ring = [&](int p) {
-    if constexpr (SELF) load_field(p, pr);
-    else if constexpr (G::HAS_IMG) load_plain(inn, C, p, pr);
+  constexpr int RCA = RC > 0 ? RC : 1;
+  auto fetch_ring = [&](int p, float (*v)[4]) {
+    if constexpr (SELF) load_rows(gn, 3, p, v);
+    else if constexpr (G::HAS_IMG) load_rows(inn, C, p, v);
   };
-  auto commit_ring = [&](int p) {
+  auto commit_ring = [&](int p, float (*v)[4]) {
     if constexpr (RC > 0) {
-      if constexpr (SELF) field_to_offsets(p, pr);
+      if constexpr (SELF) field_to_offsets(p, v);
       if (has_item) {
 #pragma unroll
-        for (int c = 0; c < RC; ++c) store_lds(ring, c, RC, p & 3, pr[c]);
+        for (int c = 0; c < RC; ++c) store_lds(ring + (p & 3) * PS, c, v[c]);
       }
     }
   };
-  auto fetch_late = [&](int p) {
-    if constexpr (SELF) load_plain(gon, 3, p, pl);
+  auto fetch_late = [&](int p, float (*v)[4]) {
+    if constexpr (SELF) load_rows(gon, 3, p, v);
     else {
-      float f[3][4];
-      load_field(p, f);
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pl[a][k] = f[a][k];
-      load_plain(gon, C, p, pl + 3);
+      load_rows(gn, 3, p, v);
+      load_rows(gon, C, p, v + 3);
     }
   };
-  auto commit_late = [&](int p) {
-    if constexpr (!SELF) {
-      float f[3][4];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f[a][k] = pl[a][k];
-      field_to_offsets(p, f);
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pl[a][k] = f[a][k];
-    }
+  auto commit_late = [&](int p, float (*v)[4]) {
+    if constexpr (!SELF) field_to_offsets(p, v);
     if (has_item) {
 #pragma unroll
-      for (int c = 0; c < LC; ++c) store_lds(late, c, LC, p & 1, pl[c]);
+      for (int c = 0; c < LC; ++c) store_lds(late + (p & 1) * LS, c, v[c]);
     }
   };
 
-  // ---- prologue: ring planes za-1, za; late plane za-1
-  fetch_ring(za - 1);
-  commit_ring(za - 1);
-  fetch_ring(za);
-  commit_ring(za);
-  fetch_late(za - 1);
-  commit_late(za - 1);
+  // ---- prologue: ring planes za-1, za; late plane za-1 -- every load is issued before the first LDS write (one
+  // memory round trip, not three)
+  float pr[RCA][4], pl[LC][4];
+  {
+    float pr0[RCA][4];
+    fetch_ring(za - 1, pr0);
+    fetch_ring(za, pr);
+    fetch_late(za - 1, pl);
+    commit_ring(za - 1, pr0);
+    commit_ring(za, pr);
+    commit_late(za - 1, pl);
+  }
   __syncthreads();
 
   // partial sums: [owned row][target plane zp-1, zp, zp+1][channel][deposit on x-1, x, x+1]
@@ -184,36 +188,75 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
   for (int o = 0; o < RPW; ++o) gg_hold[o][0] = gg_hold[o][1] = gg_hold[o][2] = 0.f;
 
-  const float xlo = clip ? -(float)lane : -3.0e38f, xhi = clip ? (float)(d.s2 - 1 - lane) : 3.0e38f;
-  const bool xowned = lane < d.s2;
+  const float flane = (float)lane;
+  const float xlo = -flane, xhi = (float)(d.s2 - 1) - flane;
+  const float half_top[3] = {0.5f * (float)(d.s2 - 1), 0.5f * (float)(d.s1 - 1), 0.5f * (float)(d.s0 - 1)};
+  float* const tr = trbuf + wave * G::TRW;
+  const int own_row0 = wave * RPW;              // first owned output row of this wave within the tile
+
+  // results of one step: `vals[a][o]` (array a, owned row o) go out 4 voxels per lane through the wave's LDS scratch.
+  // Array a of the step starts at dst[a] + row_base[a] (floats), row o at + o * S2; `ok[a]` says whether the array is
+  // produced in this step (wave-uniform).
+  auto store_rows = [&](float (&vals)[G::NA][RPW], float* const (&dst)[G::NA], const int (&row_base)[G::NA],
+                        const bool (&ok)[G::NA]) {
+    constexpr int NR = G::NA_ROUND;
+#pragma unroll
+    for (int a0 = 0; a0 < G::NA; a0 += NR) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int o = 0; o < RPW; ++o)
+          if (a0 + a < G::NA) tr[(a * RPW + o) * 64 + lane] = vals[a0 + a][o];
+      // items of this round: (array, row, quad); 16 quads per row
+      constexpr int ITEMS = NR * RPW * 16;
+#pragma unroll
+      for (int i0 = 0; i0 < ITEMS; i0 += 64) {
+        const int j = i0 + lane;
+        const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
+        const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
+        const bool inside = j < ITEMS && 4 * q < d.s2 && (y0 + own_row0 + o) < d.s1;
+        bool valid = false;
+        float* p = nullptr;
+#pragma unroll
+        for (int aa = 0; aa < NR; ++aa)
+          if (a0 + aa < G::NA && a == aa) {
+            valid = inside && ok[a0 + aa];
+            p = dst[a0 + aa] + (uint32_t)(row_base[a0 + aa] + o * d.s2 + 4 * q);
+          }
+        if (valid) *reinterpret_cast<float4*>(p) = v4;
+      }
+    }
+  };
 
   for (int zp = za - 1; zp <= zb; ++zp) {
     // ---- loads of the next planes go out first: they land while this plane is being worked on
-    const bool more_ring = zp + 2 <= zb, more_late = zp + 1 <= zb;
-    if (more_ring) fetch_ring(zp + 2);
-    if (more_late) fetch_late(zp + 1);
+    const bool more_ring = zp + 2 <= zb && !(flags & kDbgNoStage), more_late = zp + 1 <= zb && !(flags & kDbgNoStage);
+    if (more_ring) fetch_ring(zp + 2, pr);
+    if (more_late) fetch_late(zp + 1, pl);
 
-    const int rs = zp & 3, ls = zp & 1;
-    const float* fbase = SELF ? ring + (rs * RC) * R * 64 : late + (ls * LC) * R * 64;              // field offsets, 3 ch
-    const float* gobase = SELF ? late + (ls * LC) * R * 64 : late + (ls * LC + 3) * R * 64;         // grad_out, C ch
+    const float* lslot = late + (zp & 1) * LS;
+    const float* fbase = (SELF ? ring + (zp & 3) * PS : lslot) + 4 + lane;     // field offsets, 3 ch; [ch * R * P + row * P]
+    const float* gobase = (SELF ? lslot : lslot + 3 * R * P) + 4 + lane;       // grad_out, C ch
+    const float fzp = (float)zp;
+    const float zlo = -fzp, zhi = (float)(d.s0 - 1) - fzp;
 
     // ---- phase B: deposits of sample plane zp on the target planes zp-1, zp, zp+1
-    if (zp >= 0 && zp < d.s0) {
-      const float zlo = clip ? -(float)zp : -3.0e38f, zhi = clip ? (float)(d.s0 - 1 - zp) : 3.0e38f;
+    if (zp >= 0 && zp < d.s0 && !(flags & kDbgNoB)) {
 #pragma unroll
       for (int i = 0; i < RPW + 2; ++i) {
-        const int r = wave * RPW + i;           // staged row of the sample; sample y = y0 - 1 + r
-        const int ys = y0 - 1 + r;
-        float fx = fbase[(0 * R + r) * 64 + lane];
-        float fy = fbase[(1 * R + r) * 64 + lane];
-        float fz = fbase[(2 * R + r) * 64 + lane];
+        const int r = own_row0 + i;             // staged row of the sample; sample y = y0 - 1 + r
+        float fx = fbase[(0 * R + r) * P];
+        float fy = fbase[(1 * R + r) * P];
+        float fz = fbase[(2 * R + r) * P];
         float go[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * 64 + lane];
-        const float ylo = clip ? -(float)ys : -3.0e38f, yhi = clip ? (float)(d.s1 - 1 - ys) : 3.0e38f;
-        fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
-        fy = __builtin_amdgcn_fmed3f(fy, ylo, yhi);
-        fz = __builtin_amdgcn_fmed3f(fz, zlo, zhi);
+        for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
+        if (CLIP) {
+          const float ys = (float)(y0 - 1 + r);
+          fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
+          fy = __builtin_amdgcn_fmed3f(fy, -ys, (float)(d.s1 - 1) - ys);
+          fz = __builtin_amdgcn_fmed3f(fz, zlo, zhi);
+        }
         float tx[3], tyv[3], tzv[3];
         tx[0] = fmaxf(0.f, -fx); tx[2] = fmaxf(0.f, fx); tx[1] = (1.f - tx[0]) - tx[2];
         tyv[0] = fmaxf(0.f, -fy); tyv[2] = fmaxf(0.f, fy); tyv[1] = (1.f - tyv[0]) - tyv[2];
@@ -237,20 +280,24 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
       }
     }
 
-    // ---- target plane zp-1 has now seen its three sample planes: fold over x and store
+    float vals[G::NA][RPW];
+    float* dst[G::NA];
+    int row_base[G::NA];
+    bool ok[G::NA];
+    // ---- target plane zp-1 has now seen its three sample planes: fold over x
     const int zt = zp - 1;
-    if (zt >= za && zt < zb) {
+    const bool fin = zt >= za && zt < zb;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int a = (SELF || !GG) ? c : 3 + c;
+      dst[a] = ginn + (size_t)c * V;
+      row_base[a] = (zt * d.s1 + y0 + own_row0) * d.s2;
+      ok[a] = fin;
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
-        const int uy = y0 + wave * RPW + o;
-        if (uy >= d.s1) continue;               // wave-uniform
-        const int s = (zt * d.s1 + uy) * d.s2 + lane;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          float v = lane_prev_f(acc[o][0][c][2]) + acc[o][0][c][1] + lane_next_f(acc[o][0][c][0]);
-          if (SELF) v += gg_hold[o][c < 3 ? c : 0];
-          if (xowned) ginn[(int64_t)c * V + s] = v;
-        }
+        float v = lane_prev_f(acc[o][0][c][2]) + acc[o][0][c][1] + lane_next_f(acc[o][0][c][0]);
+        if (SELF) v += gg_hold[o][c < 3 ? c : 0];
+        vals[a][o] = v;
       }
     }
 #pragma unroll
@@ -265,38 +312,48 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
         }
 
     // ---- phase A: coordinate-path gradient of the owned samples of plane zp (corner values from the ring)
-    if ((SELF || GG) && zp >= za && zp < zb) {
+    const bool do_a = (SELF || GG) && zp >= za && zp < zb && !(flags & kDbgNoA);
+    if constexpr (!SELF && GG) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        dst[a] = ggn + (size_t)a * V;
+        row_base[a] = (zp * d.s1 + y0 + own_row0) * d.s2;
+        ok[a] = do_a;
+#pragma unroll
+        for (int o = 0; o < RPW; ++o) vals[a][o] = 0.f;
+      }
+    }
+    if (do_a) {
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
-        const int r = wave * RPW + o + 1;
-        const int uy = y0 - 1 + r;
-        if (uy >= d.s1) continue;               // wave-uniform
-        const int sc[3] = {lane, uy, zp};
+        const int r = own_row0 + o + 1;
+        const float ys = (float)(y0 - 1 + r);
+        const float lo[3] = {xlo, -ys, zlo};
+        const float hi[3] = {xhi, (float)(d.s1 - 1) - ys, zhi};
         float w1[3], mult[3];
-        int i0[3];
+        int fl[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          float xs = fbase[(a * R + r) * 64 + lane] + (float)sc[a];
-          const float top = (float)(S[a] - 1);
-          mult[a] = 0.5f * top;
-          if (clip) {
-            if (border ? xs <= 0.f : xs < 0.f) mult[a] = 0.f;
-            if (border ? xs >= top : xs > top) mult[a] = 0.f;
-            xs = fminf(fmaxf(xs, 0.f), top);
+          const float f = fbase[(a * R + r) * P];
+          float fc = f;
+          mult[a] = half_top[a];
+          if (CLIP) {
+            fc = __builtin_amdgcn_fmed3f(f, lo[a], hi[a]);
+            if (BORDER) mult[a] = (f > lo[a] && f < hi[a]) ? mult[a] : 0.f;
+            else mult[a] = (fc == f) ? mult[a] : 0.f;
           }
-          const float fl = floorf(xs);
-          i0[a] = (int)fl;
-          w1[a] = xs - fl;
+          const float flo = floorf(fc);         // -1 or 0
+          w1[a] = fc - flo;
+          fl[a] = (int)flo;
         }
         float go[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * 64 + lane];
-        // a corner outside the volume reads as 0: rows and planes outside it are staged as zeros; only x needs a select
-        const bool okx0 = i0[0] >= 0, okx1 = i0[0] + 1 < d.s2;
-        const int lx0 = max(i0[0], 0), lx1 = min(i0[0] + 1, d.s2 - 1);
-        const int ry = i0[1] - (y0 - 1);        // staged row of the lower y corner (0 .. R-2)
-        const int p0 = (i0[2] & 3) * RC * R * 64, p1 = ((i0[2] + 1) & 3) * RC * R * 64;
-        const float wx1 = w1[0], wx0 = 1.f - wx1, wy1 = w1[1], wy0 = 1.f - wy1, wz1 = w1[2], wz0 = 1.f - wz1;
+        for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
+        // corner (0,0,0) of this sample in the ring: plane zp + fl_z, staged row r + fl_y, x = lane + fl_x (the zero
+        // columns, rows and planes make a corner outside the volume read 0)
+        const float* q0 = ring + ((zp + fl[2]) & 3) * PS + (r + fl[1]) * P + 4 + lane + fl[0];
+        const float* q1 = ring + ((zp + fl[2] + 1) & 3) * PS + (r + fl[1]) * P + 4 + lane + fl[0];
+        const float wx1 = w1[0], wy1 = w1[1], wz1 = w1[2];
         float acc3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -305,40 +362,42 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
           for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
             for (int cy = 0; cy < 2; ++cy) {
-              const float* p = ring + (cz ? p1 : p0) + (c * R + ry + cy) * 64;
-              const float a0 = p[lx0], a1 = p[lx1];
-              v[cz][cy][0] = okx0 ? a0 : 0.f;
-              v[cz][cy][1] = okx1 ? a1 : 0.f;
+              const float* p = (cz ? q1 : q0) + (c * R + cy) * P;
+              v[cz][cy][0] = p[0];
+              v[cz][cy][1] = p[1];
             }
           // SELF: phi_c(u) = (o_c(u) + u_c) * 2/(S_c-1) - 1: only differences along an axis enter; the identity part of a
           // difference along axis c is the index step (1)
           const float ux = (SELF && c == 0) ? 1.f : 0.f, uyy = (SELF && c == 1) ? 1.f : 0.f, uzz = (SELF && c == 2) ? 1.f : 0.f;
-          const float dx = ((v[0][0][1] - v[0][0][0] + ux) * wy0 + (v[0][1][1] - v[0][1][0] + ux) * wy1) * wz0 +
-                           ((v[1][0][1] - v[1][0][0] + ux) * wy0 + (v[1][1][1] - v[1][1][0] + ux) * wy1) * wz1;
-          const float dy = ((v[0][1][0] - v[0][0][0] + uyy) * wx0 + (v[0][1][1] - v[0][0][1] + uyy) * wx1) * wz0 +
-                           ((v[1][1][0] - v[1][0][0] + uyy) * wx0 + (v[1][1][1] - v[1][0][1] + uyy) * wx1) * wz1;
-          const float dz = ((v[1][0][0] - v[0][0][0] + uzz) * wx0 + (v[1][0][1] - v[0][0][1] + uzz) * wx1) * wy0 +
-                           ((v[1][1][0] - v[0][1][0] + uzz) * wx0 + (v[1][1][1] - v[0][1][1] + uzz) * wx1) * wy1;
-          const float kc = SELF ? go[c] * (2.f / (float)(S[c < 3 ? c : 0] - 1)) : go[c];
+          // d/dx: x differences, interpolated over y then z; likewise the other two
+          const float ex00 = v[0][0][1] - v[0][0][0], ex01 = v[0][1][1] - v[0][1][0];
+          const float ex10 = v[1][0][1] - v[1][0][0], ex11 = v[1][1][1] - v[1][1][0];
+          const float ax0 = fmaf(wy1, ex01 - ex00, ex00), ax1 = fmaf(wy1, ex11 - ex10, ex10);
+          const float dx = fmaf(wz1, ax1 - ax0, ax0) + ux;
+          const float ey00 = v[0][1][0] - v[0][0][0], ey01 = v[0][1][1] - v[0][0][1];
+          const float ey10 = v[1][1][0] - v[1][0][0], ey11 = v[1][1][1] - v[1][0][1];
+          const float ay0 = fmaf(wx1, ey01 - ey00, ey00), ay1 = fmaf(wx1, ey11 - ey10, ey10);
+          const float dy = fmaf(wz1, ay1 - ay0, ay0) + uyy;
+          const float ez00 = v[1][0][0] - v[0][0][0], ez01 = v[1][0][1] - v[0][0][1];
+          const float ez10 = v[1][1][0] - v[0][1][0], ez11 = v[1][1][1] - v[0][1][1];
+          const float az0 = fmaf(wx1, ez01 - ez00, ez00), az1 = fmaf(wx1, ez11 - ez10, ez10);
+          const float dz = fmaf(wy1, az1 - az0, az0) + uzz;
+          const float kc = SELF ? go[c] * (1.f / half_top[c < 3 ? c : 0]) : go[c];
           acc3[0] = fmaf(dx, kc, acc3[0]); acc3[1] = fmaf(dy, kc, acc3[1]); acc3[2] = fmaf(dz, kc, acc3[2]);
         }
-        if constexpr (SELF) {
 #pragma unroll
-          for (int a = 0; a < 3; ++a) gg_hold[o][a] = mult[a] * acc3[a];
-        } else {
-          if (xowned) {
-            float* gq = ggrid + (int64_t)n * 3 * V + (zp * d.s1 + uy) * d.s2 + lane;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) gq[(int64_t)a * V] = mult[a] * acc3[a];
-          }
+        for (int a = 0; a < 3; ++a) {
+          if constexpr (SELF) gg_hold[o][a] = mult[a] * acc3[a];
+          else vals[a][o] = mult[a] * acc3[a];
         }
       }
     }
+    if (!(flags & kDbgNoStore)) store_rows(vals, dst, row_base, ok);
 
     // ---- the prefetched planes go to LDS; nobody reads these slots in this step (ring: zp+2 = zp-2 mod 4, last read
     // in step zp-1; late: zp+1 = zp-1 mod 2, last read in step zp-1)
-    if (more_ring) commit_ring(zp + 2);
-    if (more_late) commit_late(zp + 1);
+    if (more_ring) commit_ring(zp + 2, pr);
+    if (more_late) commit_late(zp + 1, pl);
     __syncthreads();
   }
 }
@@ -357,60 +416,63 @@ static int march_zc(const Dims& d, int64_t N, int ty) {
   return zc;
 }
 
-template <int C, bool SELF, bool GG, int NW, int RPW>
+template <int C, bool SELF, bool GG, int MODE, int NW, int RPW>
 static void launch_march(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
-                         Dims d, int flags, int32_t* ws, hipStream_t st) {
+                         Dims d, int32_t* ws, hipStream_t st) {
   using G = MarchCfg<C, SELF, GG, NW, RPW>;
-  auto kern = k_adjoint_march<C, SELF, GG, NW, RPW>;
+  auto kern = k_adjoint_march<C, SELF, GG, MODE, NW, RPW>;
   static bool attr_set = false;
   if (G::LDS > 65536 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
+  static const int dbg = getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0;
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
   const int zc = march_zc(d, N, G::TY);
   const int n0 = (d.s0 + zc - 1) / zc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, gout, in, grid, gin, ggrid, d, n1,
-                     zc, flags, SELF ? ws : (int32_t*)nullptr);
+                     zc, dbg, SELF ? ws : (int32_t*)nullptr);
 }
 
-static bool march_shape_ok(const Dims& d, const void* a, const void* b, const void* c) {
+static bool march_shape_ok(const Dims& d, const void* a, const void* b, const void* c, const void* e, const void* f) {
   static const bool off = getenv("ADVCHAIN_NO_MARCH_ADJOINT") != nullptr;   // A/B knob
   if (off) return false;
-  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
-  return d.s2 >= 8 && d.s2 <= 64 && (d.s2 & 3) == 0 && (al & 15) == 0 && d.s0 >= 2;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                       reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f);
+  return d.s2 >= 8 && d.s2 <= 64 && (d.s2 & 3) == 0 && (al & 15) == 0 && d.s0 >= 2 && d.voxels() * 4 < (1ll << 31);
 }
 
 // Exact-bound (|displacement| < 1 voxel) self-composition backward, 3D.  ADVCHAIN_ERR_UNSUPPORTED: use the tile kernel.
 int advchain_self_adjoint_march_launch(const float* gout, const float* phi, float* gphi, int64_t N, Dims d,
                                        int32_t* workspace, hipStream_t st) {
-  if (!march_shape_ok(d, gout, phi, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
-  static const int rpw = getenv("ADVCHAIN_MARCH_SELF_RPW") ? atoi(getenv("ADVCHAIN_MARCH_SELF_RPW")) : 1;   // tuning knob
-  if (rpw == 2) launch_march<3, true, false, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, 0, workspace, st);
-  else launch_march<3, true, false, 4, 1>(gout, phi, phi, gphi, nullptr, N, d, 0, workspace, st);
+  if (!march_shape_ok(d, gout, phi, gphi, nullptr, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+  static const int rpw = getenv("ADVCHAIN_MARCH_SELF_RPW") ? atoi(getenv("ADVCHAIN_MARCH_SELF_RPW")) : 2;   // tuning knob
+  if (rpw == 2) launch_march<3, true, false, kMarchBorder, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
+  else launch_march<3, true, false, kMarchBorder, 4, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
+}
+
+template <int MODE>
+static void launch_warp_march(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
+                              int64_t C, Dims d, hipStream_t st) {
+  if (C == 1) {
+    if (ggrid) launch_march<1, false, true, MODE, 4, 2>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+    else launch_march<1, false, false, MODE, 4, 2>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+  } else {
+    if (ggrid) launch_march<4, false, true, MODE, 4, 1>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+    else launch_march<4, false, false, MODE, 4, 1>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+  }
 }
 
 // Exact-bound grid_sample backward (grad_in [+ grad_grid]), 3D, C in {1, 4}, zeros / border padding.
 int advchain_warp_adjoint_march_launch(const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
                                        int64_t N, int64_t C, Dims d, int padding, int clamp_grid, hipStream_t st) {
   if (padding == PAD_REFLECTION || (C != 1 && C != 4) || !gin) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (!march_shape_ok(d, gout, grid, ggrid ? in : nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
-  const bool border = padding == PAD_BORDER;
-  const int flags = ((border || clamp_grid) ? kMarchClip : 0) | (border ? kMarchBorder : 0);
-  static const int rpw1 = getenv("ADVCHAIN_MARCH_C1_RPW") ? atoi(getenv("ADVCHAIN_MARCH_C1_RPW")) : 2;   // tuning knob
-  if (C == 1) {
-    if (ggrid) {
-      if (rpw1 == 2) launch_march<1, false, true, 4, 2>(gout, in, grid, gin, ggrid, N, d, flags, nullptr, st);
-      else launch_march<1, false, true, 4, 1>(gout, in, grid, gin, ggrid, N, d, flags, nullptr, st);
-    } else {
-      launch_march<1, false, false, 4, 2>(gout, in, grid, gin, ggrid, N, d, flags, nullptr, st);
-    }
-  } else {
-    if (ggrid) launch_march<4, false, true, 4, 1>(gout, in, grid, gin, ggrid, N, d, flags, nullptr, st);
-    else launch_march<4, false, false, 4, 1>(gout, in, grid, gin, ggrid, N, d, flags, nullptr, st);
-  }
+  if (!march_shape_ok(d, gout, grid, gin, ggrid, ggrid ? in : nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (padding == PAD_BORDER) launch_warp_march<kMarchBorder>(gout, in, grid, gin, ggrid, N, C, d, st);
+  else if (clamp_grid) launch_warp_march<kMarchClamp>(gout, in, grid, gin, ggrid, N, C, d, st);
+  else launch_warp_march<kMarchFree>(gout, in, grid, gin, ggrid, N, C, d, st);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

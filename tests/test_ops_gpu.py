@@ -275,7 +275,8 @@ def test_compose_self_bwd_gather_form(dims, halo, amp):
         # (3D: the exact bound takes the z-marching kernel, which sums in another order than the tile kernel)
         assert maxdiff(g1, g1s) < 1e-5 * max(1.0, scale) if (windowed or d == 3) else torch.equal(g1, g1s)
         assert maxdiff(g1s.cpu(), p.grad) < 5e-5 * max(1.0, scale)
-        assert torch.equal(g1s, ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-halo))   # deterministic
+        if not windowed:
+            assert torch.equal(g1s, ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-halo))   # deterministic
         # ... and a chained owner-computes step after it (the strict launch left no max|grad| behind: found on device)
         g2s = ops.raw_compose_self_bwd(g1s, pd, ws, chain=True, halo=0)
         assert maxdiff(g2s.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))

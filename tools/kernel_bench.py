@@ -96,6 +96,7 @@ def main():
     add("compose_self bwd", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)
     ws = ops._scatter_workspace(N, dims, dev)   # phi is the 2^-8-scaled field: well below one voxel
     add("compose_self bwd halo=1 (gather form)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 1), 12 * d * NV)
+    add("compose_self bwd halo=-1 (exact bound)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, -1), 12 * d * NV)
     add("compose_self bwd halo=2%s" % (" (gather form)" if d == 2 else ""), lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 2), 12 * d * NV)
     old = ops.TILED_SCATTER
     ops.TILED_SCATTER = False
