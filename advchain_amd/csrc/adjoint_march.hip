@@ -207,6 +207,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
         for (int o = 0; o < RPW; ++o)
           if (a0 + a < G::NA) tr[(a * RPW + o) * 64 + lane] = vals[a0 + a][o];
+      lds_order();
       // items of this round: (array, row, quad); 16 quads per row
       constexpr int ITEMS = NR * RPW * 16;
 #pragma unroll
@@ -225,6 +226,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
           }
         if (valid) *reinterpret_cast<float4*>(p) = v4;
       }
+      lds_order();
     }
   };
 

@@ -252,12 +252,21 @@ static bool launch_sample_c(int C, dim3 g, size_t lds, hipStream_t st, const flo
 #undef LAUNCH
 }
 
+// sample_march.hip: z-marching form (3D, rows of at most 64 voxels)
+int advchain_sample_march_launch(bool self, const float* in, const float* grid, float* out, const float* phi0, int64_t N,
+                                 int64_t C, Dims d, int padding, int clamp_grid, int final_mode, float* disp_out,
+                                 hipStream_t st);
+
 // Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify (caller uses the direct-gather kernels).
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
                                  int halo, float* disp_out, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_GATHER_TILES") != nullptr;   // A/B knob
   if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (ndim == 3) {
+    const int rc = advchain_sample_march_launch(self, in, grid, out, phi0, N, C, d, padding, clamp_grid, final_mode, disp_out, st);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
   const int unaligned = (reinterpret_cast<uintptr_t>(in) & 15) != 0 || (d.s2 & 3) != 0;   // only `in` is read 16 bytes at a time
   GTile tc;
   if (!choose_gtile(ndim, d, (int)C, halo, tc)) return ADVCHAIN_ERR_UNSUPPORTED;

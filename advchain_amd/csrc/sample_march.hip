@@ -1,0 +1,292 @@
+// z-marching forward sampler for 3D warps at equal input / output size (gfx950): advchain_grid_sample_fwd and
+// advchain_compose_self_fwd for fields that move a sample by less than a voxel -- the image warps of a freshly
+// initialised AdvMorph and the early squarings of its scaling-and-squaring chain (adv_morph.py:132-135,165-168).
+//
+// A workgroup owns TY output rows (whole x rows, lane <-> x) and walks ZC planes.  The input planes z-1, z, z+1 of its
+// rows (plus one halo row either side) live in a 4-slot LDS ring: every plane is staged ONCE per workgroup with 16-byte
+// loads -- the tile kernel of gather_tiled.hip stages a (2+2) x (8+2) block for 2 x 8 outputs, 2.5x its tile -- and
+// the plane two steps ahead is loaded into registers at the top of a step and written to LDS at its end, so that its
+// memory round trip runs under the taps of the current plane (one barrier per step).  Staged rows carry 4 zero floats
+// either side and rows / planes outside the volume are staged as zeros: a corner outside the volume reads the 0 zeros
+// padding asks for without a select.  A wave whose lanes all find their 8 corners in the ring takes them from LDS;
+// otherwise (displacement of a voxel or more somewhere in the row) the row falls back to global gathers, so results do
+// not depend on what is staged.  Results leave through LDS, 16 bytes per lane (see adjoint_march.hip).
+//
+// The arithmetic of a tap (weights as products, accumulation order) is the one of gather_tiled.hip / sample_linear:
+// the squaring chain amplifies rounding differences 2^8-fold and its parity tolerance was set with that order.
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+enum { kFwdFree = 0, kFwdClamp = 1, kFwdBorder = 2 };   // zeros padding | zeros padding + clamp(grid, -1, 1) | border padding
+
+template <int C, bool SELF, int NW, int RPW>
+struct FwdMarchCfg {
+  static constexpr int TY = NW * RPW;
+  static constexpr int R = TY + 2;
+  static constexpr int NT = NW * 64;
+  static constexpr int PITCH = 72;                          // 4 zeros | 64 voxels | 4 zeros
+  static constexpr int PS = C * R * PITCH;                  // floats per ring slot
+  static constexpr int NA_ROUND = C > 2 ? 2 : C;            // output channels transposed per round
+  static constexpr int TRW = NA_ROUND * RPW * 64;
+  static constexpr size_t LDS = (size_t)(4 * PS + NW * TRW) * sizeof(float);
+  static_assert(R * 16 <= NT, "one staging item (4 voxels of one row, all channels) per thread");
+  static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
+};
+
+template <int C, bool SELF, int MODE, int NW, int RPW>
+__global__ void __launch_bounds__(NW * 64)
+k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
+               const float* __restrict__ phi0, Dims d, int n1, int zc, int final_mode, float* __restrict__ disp_out) {
+  using G = FwdMarchCfg<C, SELF, NW, RPW>;
+  constexpr int R = G::R, TY = G::TY, P = G::PITCH, PS = G::PS;
+  constexpr int PAD = MODE == kFwdBorder ? PAD_BORDER : PAD_ZEROS;
+  extern __shared__ float lds[];
+  float* const ring = lds;                  // [slot 4][C][R][P]
+  float* const trbuf = lds + 4 * PS;        // [wave][TRW]
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  const int y0 = ty * TY;
+  const int za = tz * zc, zb = min(za + zc, d.s0);
+  const float* inn = in + (int64_t)n * C * V;
+  const float* gn = SELF ? nullptr : grid + (int64_t)n * 3 * V;
+  const float* p0n = (SELF && final_mode == 1) ? phi0 + (int64_t)n * 3 * V : nullptr;
+  float* outn = out + (int64_t)n * C * V;
+  const int plane_stride = d.s1 * d.s2;
+
+  // ---- the zero columns of every staged row (never written again)
+  for (int e = threadIdx.x; e < 4 * C * R * 2; e += G::NT) {
+    const int row = e >> 1, side = e & 1;
+    *reinterpret_cast<float4*>(lds + row * P + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
+  const bool has_item = threadIdx.x < R * 16;
+  const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
+  const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
+  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
+  const int row_off = sy_st * d.s2 + x_st;
+  const int lds_item = r_st * P + 4 + x_st;
+  auto fetch = [&](int p, float (*v)[4]) {
+    const bool ok = row_ok && p >= 0 && p < d.s0;
+    const uint32_t s = (uint32_t)(p * plane_stride + row_off);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (ok) {
+        const float4 t = *reinterpret_cast<const float4*>(inn + (size_t)c * V + s);
+        v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+      } else {
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
+      }
+    }
+  };
+  auto commit = [&](int p, float (*v)[4]) {
+    if (has_item) {
+      float* slot = ring + (p & 3) * PS + lds_item;
+#pragma unroll
+      for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(slot + c * R * P) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+    }
+  };
+
+  // ---- prologue: planes za-1, za, za+1 (all loads issued before the first LDS write)
+  float pr[C][4];
+  {
+    float pa[C][4], pb[C][4];
+    fetch(za - 1, pa);
+    fetch(za, pb);
+    fetch(za + 1, pr);
+    commit(za - 1, pa);
+    commit(za, pb);
+    commit(za + 1, pr);
+  }
+  __syncthreads();
+
+  float* const tr = trbuf + wave * G::TRW;
+  const int own_row0 = wave * RPW;
+  float dmax = 0.f;
+  const float topx = (float)(d.s2 - 1), topy = (float)(d.s1 - 1), topz = (float)(d.s0 - 1);
+
+  for (int z = za; z < zb; ++z) {
+    const bool more = z + 2 <= zb;          // plane zb (= z+1 of the last step) is the last one needed
+    if (more) fetch(z + 2, pr);
+    // grid values (and phi0 in final mode) of the owned rows: requested now, used below
+    float g[RPW][3], p0v[RPW][3];
+    if constexpr (!SELF) {
+#pragma unroll
+      for (int o = 0; o < RPW; ++o) {
+        const int uy = min(y0 + own_row0 + o, d.s1 - 1);
+        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(lane, d.s2 - 1));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[o][a] = gn[(size_t)a * V + s];
+      }
+    } else if (p0n) {
+#pragma unroll
+      for (int o = 0; o < RPW; ++o) {
+        const int uy = min(y0 + own_row0 + o, d.s1 - 1);
+        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(lane, d.s2 - 1));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p0v[o][a] = p0n[(size_t)a * V + s];
+      }
+    }
+
+    float res[C][RPW];
+#pragma unroll
+    for (int o = 0; o < RPW; ++o) {
+      const int r = own_row0 + o + 1;       // staged row of this output row
+      const int uy = y0 - 1 + r;
+      if (uy >= d.s1) {                     // wave-uniform: row beyond the volume (partial last tile)
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][o] = 0.f;
+        continue;
+      }
+      float gx, gy, gz;
+      if constexpr (SELF) {
+        const float* c0 = ring + (z & 3) * PS + r * P + 4 + lane;
+        gx = c0[0]; gy = c0[R * P]; gz = c0[2 * R * P];
+      } else {
+        gx = g[o][0]; gy = g[o][1]; gz = g[o][2];
+        if (MODE == kFwdClamp) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
+      }
+      // unnormalised source coordinates (grid_sampler_unnormalize, align_corners); border padding clips them
+      float xs = ((gx + 1.f) * 0.5f) * topx, ys = ((gy + 1.f) * 0.5f) * topy, zs = ((gz + 1.f) * 0.5f) * topz;
+      if (PAD == PAD_BORDER) {
+        xs = fminf(fmaxf(xs, 0.f), topx); ys = fminf(fmaxf(ys, 0.f), topy); zs = fminf(fmaxf(zs, 0.f), topz);
+      }
+      // NaN / huge: every corner out of range (med3 returns the smallest operand when one is NaN)
+      xs = __builtin_amdgcn_fmed3f(xs, -16.f, 1.0e9f);
+      ys = __builtin_amdgcn_fmed3f(ys, -16.f, 1.0e9f);
+      zs = __builtin_amdgcn_fmed3f(zs, -16.f, 1.0e9f);
+      const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
+      const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+      const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs;
+      const float wy1 = ys - fy, wy0 = (fy + 1.f) - ys;
+      const float wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
+      const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)d.s2;
+      if (__builtin_amdgcn_ballot_w64(!staged && lane < d.s2) == 0) {
+        float w[8];
+        w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
+        w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
+        const int oxy = (r + (iy - uy)) * P + 4 + ix;
+        const float* q0 = ring + (iz & 3) * PS + oxy;
+        const float* q1 = ring + ((iz + 1) & 3) * PS + oxy;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float acc = 0.f;
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+              for (int cx = 0; cx < 2; ++cx) acc += ((cz ? q1 : q0) + (c * R + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
+          res[c][o] = acc;
+        }
+      } else {
+        // a lane of this row samples outside the ring: the whole row from global memory (same arithmetic)
+        Taps<3, PAD> t;
+        t.build(gx, gy, gz, d);
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][o] = sample_linear<3, PAD>(inn + (size_t)c * V, t, d);
+      }
+      if constexpr (SELF) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float v = res[c][o];
+          const int sc = c == 0 ? lane : (c == 1 ? uy : z), Sc = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
+          if (final_mode == 1) v = (v - p0v[o][c]) + lin_coord(sc, Sc);   // (sample - phi0) + identity (adv_morph.py:143,176 + 474,483)
+          res[c][o] = v;
+          if (disp_out && lane < d.s2 && uy < d.s1) dmax = fmaxf(dmax, voxel_displacement(v, Sc, sc));
+        }
+      }
+    }
+
+    // ---- results leave 4 voxels per lane through the wave's LDS scratch
+    constexpr int NR = G::NA_ROUND;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += NR) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int o = 0; o < RPW; ++o)
+          if (c0 + a < C) tr[(a * RPW + o) * 64 + lane] = res[c0 + a][o];
+      lds_order();
+      constexpr int ITEMS = NR * RPW * 16;
+#pragma unroll
+      for (int i0 = 0; i0 < ITEMS; i0 += 64) {
+        const int j = i0 + lane;
+        const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
+        const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
+        const bool valid = j < ITEMS && c0 + a < C && 4 * q < d.s2 && (y0 + own_row0 + o) < d.s1;
+        if (valid)
+          *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + (uint32_t)((z * d.s1 + y0 + own_row0 + o) * d.s2 + 4 * q)) = v4;
+      }
+      lds_order();
+    }
+
+    if (more) commit(z + 2, pr);
+    __syncthreads();
+  }
+  if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+static int fwd_march_zc(const Dims& d, int64_t N, int ty) {
+  static const int forced = getenv("ADVCHAIN_FWD_MARCH_ZC") ? atoi(getenv("ADVCHAIN_FWD_MARCH_ZC")) : 0;   // tuning knob
+  if (forced > 0) return forced;
+  const int64_t cols = N * ((d.s1 + ty - 1) / ty);
+  int zc = d.s0;
+  while (zc > 8 && cols * ((d.s0 + zc - 1) / zc) < 1024) zc = (zc + 1) / 2;
+  return zc;
+}
+
+template <int C, bool SELF, int MODE, int NW, int RPW>
+static void launch_fwd_march(const float* in, const float* grid, float* out, const float* phi0, int64_t N, Dims d,
+                             int final_mode, float* disp_out, hipStream_t st) {
+  using G = FwdMarchCfg<C, SELF, NW, RPW>;
+  auto kern = k_sample_march<C, SELF, MODE, NW, RPW>;
+  static bool attr_set = false;
+  if (G::LDS > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    attr_set = true;
+  }
+  const int n1 = (d.s1 + G::TY - 1) / G::TY;
+  const int zc = fwd_march_zc(d, N, G::TY);
+  const int n0 = (d.s0 + zc - 1) / zc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
+                     final_mode, disp_out);
+}
+
+template <int C>
+static void launch_fwd_march_mode(int mode, const float* in, const float* grid, float* out, int64_t N, Dims d, hipStream_t st) {
+  if (mode == kFwdBorder) launch_fwd_march<C, false, kFwdBorder, 4, 2>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+  else if (mode == kFwdClamp) launch_fwd_march<C, false, kFwdClamp, 4, 2>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+  else launch_fwd_march<C, false, kFwdFree, 4, 2>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+}
+
+// 3D forward warps at equal size with rows of at most 64 voxels.  ADVCHAIN_ERR_UNSUPPORTED: use the tile kernel.
+int advchain_sample_march_launch(bool self, const float* in, const float* grid, float* out, const float* phi0, int64_t N,
+                                 int64_t C, Dims d, int padding, int clamp_grid, int final_mode, float* disp_out,
+                                 hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_MARCH_FWD") != nullptr;   // A/B knob
+  if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out);
+  if (d.s2 < 8 || d.s2 > 64 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
+    return ADVCHAIN_ERR_UNSUPPORTED;
+  if (self) {
+    if (C != 3) return ADVCHAIN_ERR_UNSUPPORTED;
+    launch_fwd_march<3, true, kFwdBorder, 4, 2>(in, nullptr, out, phi0, N, d, final_mode, disp_out, st);
+  } else {
+    const int mode = padding == PAD_BORDER ? kFwdBorder : (clamp_grid ? kFwdClamp : kFwdFree);
+    // (border padding with clamp_grid: the clamp is implied by the clip of the source coordinate)
+    if (C == 1) launch_fwd_march_mode<1>(mode, in, grid, out, N, d, st);
+    else if (C == 4) launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
+    else return ADVCHAIN_ERR_UNSUPPORTED;
+  }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}

@@ -132,6 +132,11 @@ __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&r
   }
 }
 
+// Compiler-only ordering point for a wave's private LDS scratch: the hardware executes one wave's LDS instructions in
+// order, but the compiler may move a 16-byte read of the scratch across the 4-byte writes that fill it (it treats the
+// two access types as non-aliasing: seen as channel 2's values stored for channel 0 in sample_march.hip).
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ float clamp_unit(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
 // displacement of a sampling position from its own voxel, in voxels (NaN -> ignored by the max, inf -> capped)
