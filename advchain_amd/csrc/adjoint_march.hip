@@ -36,6 +36,7 @@ namespace advchain {
 enum { kMarchFree = 0, kMarchClamp = 1, kMarchBorder = 2 };
 // timing experiments only (ADVCHAIN_MARCH_DEBUG, results are wrong): switch a phase off
 constexpr int kDbgNoA = 16, kDbgNoB = 32, kDbgNoStore = 64, kDbgNoStage = 128;
+constexpr int kMarchXcd = 256;    // workgroup -> tile map that keeps halo-sharing tiles on one XCD (one L2)
 
 template <int C, bool SELF, bool GG, int NW, int RPW>
 struct MarchCfg {
@@ -73,9 +74,14 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   float* const late = lds + 4 * PS;              // [slot 2][LC][R][P]
   float* const trbuf = lds + 4 * PS + 2 * LS;    // [wave][TRW]
   const int V = (int)d.voxels();
-  const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  // workgroup L runs on XCD L % 8 (observed dispatch order; speed only): give every XCD a contiguous run of tiles, so
+  // that the halo rows / planes two neighbouring workgroups both stage are served by the same L2
+  int tile = blockIdx.x + gridDim.x * blockIdx.y;
+  const int tiles = gridDim.x * gridDim.y;
+  if ((flags & kMarchXcd) && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);
+  const int n = tile / (int)gridDim.x, rem = tile - n * (int)gridDim.x;
+  const int ty = rem % n1, tz = rem / n1;
   const int y0 = ty * TY;
   const int za = tz * zc, zb = min(za + zc, d.s0);
   const float* gn = grid + (int64_t)n * 3 * V;
@@ -428,7 +434,8 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
-  static const int dbg = getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0;
+  static const int dbg = (getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0) |
+                         (getenv("ADVCHAIN_NO_XCD_MAP") ? 0 : kMarchXcd);
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
   const int zc = march_zc(d, N, G::TY);
   const int n0 = (d.s0 + zc - 1) / zc;

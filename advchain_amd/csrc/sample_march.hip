@@ -235,12 +235,16 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 
 using namespace advchain;
 
-static int fwd_march_zc(const Dims& d, int64_t N, int ty) {
+static int fwd_march_zc(const Dims& d, int64_t N, int ty, int C) {
   static const int forced = getenv("ADVCHAIN_FWD_MARCH_ZC") ? atoi(getenv("ADVCHAIN_FWD_MARCH_ZC")) : 0;   // tuning knob
   if (forced > 0) return forced;
+  // measured at 4 x C x 128 x 128 x 64: the one-channel warp is latency-bound and wants 8 workgroups per CU even at
+  // chunks of 4 planes (15.4 us against 17.7 at 8 and 25 at 16 planes); 3-4 channels want 4 per CU and chunks >= 8
+  // (a measured dead end: handing the grid values to their lanes through LDS with 16-byte loads -- 18.9 us)
   const int64_t cols = N * ((d.s1 + ty - 1) / ty);
+  const int want = C == 1 ? 2048 : 1024, floor_zc = C == 1 ? 4 : 8;
   int zc = d.s0;
-  while (zc > 8 && cols * ((d.s0 + zc - 1) / zc) < 1024) zc = (zc + 1) / 2;
+  while (zc > floor_zc && cols * ((d.s0 + zc - 1) / zc) < want) zc = (zc + 1) / 2;
   return zc;
 }
 
@@ -255,7 +259,7 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
     attr_set = true;
   }
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
-  const int zc = fwd_march_zc(d, N, G::TY);
+  const int zc = fwd_march_zc(d, N, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
                      final_mode, disp_out);
