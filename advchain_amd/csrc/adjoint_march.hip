@@ -103,22 +103,28 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
   const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
   const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
-  const int row_off = sy_st * d.s2 + x_st;
   const int lds_item = r_st * P + 4 + x_st;
 
+  // Loads are UNCONDITIONAL, from addresses clamped into the volume, and what lies outside is zeroed with selects when
+  // the values go to LDS: a load inside `if (inside)` gets its own exec-mask block, and the compiler put a full
+  // `s_waitcnt vmcnt(0)` between two such blocks -- one exposed memory round trip per step.
+  const int sy_c = min(max(sy_st, 0), d.s1 - 1), x_c = x_st < d.s2 ? x_st : 0;
+  const int row_off = sy_c * d.s2 + x_c;
   auto plane_ok = [&](int p) { return row_ok && p >= 0 && p < d.s0; };
   auto load_rows = [&](const float* base, int nch, int p, float (*v)[4]) {
-    const bool ok = plane_ok(p);
-    const uint32_t s = (uint32_t)(p * plane_stride + row_off);
+    const uint32_t s = (uint32_t)(min(max(p, 0), d.s0 - 1) * plane_stride + row_off);
 #pragma unroll 4
     for (int c = 0; c < nch; ++c) {
-      if (ok) {
-        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * V + s);
-        v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
-      } else {
-        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
-      }
+      const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * V + s);
+      v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
     }
+  };
+  auto zero_outside = [&](int p, int nch, float (*v)[4]) {
+    const bool ok = plane_ok(p);
+#pragma unroll 4
+    for (int c = 0; c < nch; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[c][k] = ok ? v[c][k] : 0.f;
   };
   // field plane p -> offsets o = unnormalize(field) - own voxel (what the tents and the corner search work on)
   auto field_to_offsets = [&](int p, float (*v)[4]) {
@@ -145,10 +151,9 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   auto commit_ring = [&](int p, float (*v)[4]) {
     if constexpr (RC > 0) {
       if constexpr (SELF) field_to_offsets(p, v);
-      if (has_item) {
+      else zero_outside(p, RC, v);
 #pragma unroll
-        for (int c = 0; c < RC; ++c) store_lds(ring + (p & 3) * PS, c, v[c]);
-      }
+      for (int c = 0; c < RC; ++c) store_lds(ring + (p & 3) * PS, c, v[c]);
     }
   };
   auto fetch_late = [&](int p, float (*v)[4]) {
@@ -160,16 +165,15 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   };
   auto commit_late = [&](int p, float (*v)[4]) {
     if constexpr (!SELF) field_to_offsets(p, v);
-    if (has_item) {
+    zero_outside(p, SELF ? 3 : C, SELF ? v : v + 3);
 #pragma unroll
-      for (int c = 0; c < LC; ++c) store_lds(late + (p & 1) * LS, c, v[c]);
-    }
+    for (int c = 0; c < LC; ++c) store_lds(late + (p & 1) * LS, c, v[c]);
   };
 
   // ---- prologue: ring planes za-1, za; late plane za-1 -- every load is issued before the first LDS write (one
   // memory round trip, not three)
   float pr[RCA][4], pl[LC][4];
-  {
+  if (has_item) {
     float pr0[RCA][4];
     fetch_ring(za - 1, pr0);
     fetch_ring(za, pr);
@@ -239,8 +243,11 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   for (int zp = za - 1; zp <= zb; ++zp) {
     // ---- loads of the next planes go out first: they land while this plane is being worked on
     const bool more_ring = zp + 2 <= zb && !(flags & kDbgNoStage), more_late = zp + 1 <= zb && !(flags & kDbgNoStage);
-    if (more_ring) fetch_ring(zp + 2, pr);
-    if (more_late) fetch_late(zp + 1, pl);
+    if (has_item) {
+      // (a plane beyond the chunk is loaded from a clamped address and never committed: no branch around the loads)
+      fetch_ring(zp + 2, pr);
+      fetch_late(zp + 1, pl);
+    }
 
     const float* lslot = late + (zp & 1) * LS;
     const float* fbase = (SELF ? ring + (zp & 3) * PS : lslot) + 4 + lane;     // field offsets, 3 ch; [ch * R * P + row * P]
@@ -404,8 +411,10 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 
     // ---- the prefetched planes go to LDS; nobody reads these slots in this step (ring: zp+2 = zp-2 mod 4, last read
     // in step zp-1; late: zp+1 = zp-1 mod 2, last read in step zp-1)
-    if (more_ring) commit_ring(zp + 2, pr);
-    if (more_late) commit_late(zp + 1, pl);
+    if (has_item) {
+      if (more_ring) commit_ring(zp + 2, pr);
+      if (more_late) commit_late(zp + 1, pl);
+    }
     __syncthreads();
   }
 }

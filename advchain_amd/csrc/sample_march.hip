@@ -68,32 +68,30 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
   const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
   const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
-  const int row_off = sy_st * d.s2 + x_st;
+  // loads are unconditional, from addresses clamped into the volume; what lies outside is zeroed on the way to LDS (a
+  // load inside `if (inside)` gets its own exec-mask block and the compiler serialises such blocks with full waits)
+  const int row_off = min(max(sy_st, 0), d.s1 - 1) * d.s2 + (x_st < d.s2 ? x_st : 0);
   const int lds_item = r_st * P + 4 + x_st;
   auto fetch = [&](int p, float (*v)[4]) {
-    const bool ok = row_ok && p >= 0 && p < d.s0;
-    const uint32_t s = (uint32_t)(p * plane_stride + row_off);
+    const uint32_t s = (uint32_t)(min(max(p, 0), d.s0 - 1) * plane_stride + row_off);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      if (ok) {
-        const float4 t = *reinterpret_cast<const float4*>(inn + (size_t)c * V + s);
-        v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
-      } else {
-        v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f;
-      }
+      const float4 t = *reinterpret_cast<const float4*>(inn + (size_t)c * V + s);
+      v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
     }
   };
   auto commit = [&](int p, float (*v)[4]) {
-    if (has_item) {
-      float* slot = ring + (p & 3) * PS + lds_item;
+    const bool ok = row_ok && p >= 0 && p < d.s0;
+    float* slot = ring + (p & 3) * PS + lds_item;
 #pragma unroll
-      for (int c = 0; c < C; ++c) *reinterpret_cast<float4*>(slot + c * R * P) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
-    }
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<float4*>(slot + c * R * P) = make_float4(ok ? v[c][0] : 0.f, ok ? v[c][1] : 0.f, ok ? v[c][2] : 0.f,
+                                                                 ok ? v[c][3] : 0.f);
   };
 
   // ---- prologue: planes za-1, za, za+1 (all loads issued before the first LDS write)
   float pr[C][4];
-  {
+  if (has_item) {
     float pa[C][4], pb[C][4];
     fetch(za - 1, pa);
     fetch(za, pb);
@@ -111,7 +109,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 
   for (int z = za; z < zb; ++z) {
     const bool more = z + 2 <= zb;          // plane zb (= z+1 of the last step) is the last one needed
-    if (more) fetch(z + 2, pr);
+    if (has_item) fetch(z + 2, pr);      // (beyond the chunk: a clamped address, never committed)
     // grid values (and phi0 in final mode) of the owned rows: requested now, used below
     float g[RPW][3], p0v[RPW][3];
     if constexpr (!SELF) {
@@ -225,7 +223,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
       lds_order();
     }
 
-    if (more) commit(z + 2, pr);
+    if (has_item && more) commit(z + 2, pr);
     __syncthreads();
   }
   if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
