@@ -53,7 +53,7 @@ struct MarchCfg {
   static constexpr int NA_ROUND = NA > 2 ? 2 : NA;              // arrays transposed per round
   static constexpr int TRW = NA_ROUND * RPW * 64;               // transposition scratch per wave (floats)
   static constexpr size_t LDS = (size_t)(4 * PS + 2 * LS + NW * TRW) * sizeof(float);
-  static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF && RPW == 1 ? 3 : 2);   // per SIMD: 128 / 168 / 256 VGPRs
+  static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF && RPW == 1 ? (NW == 8 ? 4 : 3) : 2);   // per SIMD: 128 / 168 / 256 VGPRs (512-thread blocks: 2 waves per SIMD each)
   static_assert(R * 16 <= NT, "one staging item (4 voxels of one row, all channels) per thread");
   static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
 };
@@ -466,6 +466,7 @@ int advchain_self_adjoint_march_launch(const float* gout, const float* phi, floa
   if (!march_shape_ok(d, gout, phi, gphi, nullptr, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
   static const int rpw = getenv("ADVCHAIN_MARCH_SELF_RPW") ? atoi(getenv("ADVCHAIN_MARCH_SELF_RPW")) : 2;   // tuning knob
   if (rpw == 2) launch_march<3, true, false, kMarchBorder, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
+  else if (rpw == 8) launch_march<3, true, false, kMarchBorder, 8, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   else launch_march<3, true, false, kMarchBorder, 4, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;

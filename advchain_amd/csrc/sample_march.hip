@@ -163,7 +163,10 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
       const float wy1 = ys - fy, wy0 = (fy + 1.f) - ys;
       const float wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
       const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)d.s2;
-      if (__builtin_amdgcn_ballot_w64(!staged && lane < d.s2) == 0) {
+      // lanes whose 8 corners are in the ring take them from LDS; the others (displacement of a voxel or more) gather
+      // from global memory with the same arithmetic.  Smooth fields make whole rows one or the other, and the empty
+      // side of the branch is skipped (execz).
+      if (staged) {
         float w[8];
         w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
         w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
@@ -181,12 +184,14 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
               for (int cx = 0; cx < 2; ++cx) acc += ((cz ? q1 : q0) + (c * R + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
           res[c][o] = acc;
         }
-      } else {
-        // a lane of this row samples outside the ring: the whole row from global memory (same arithmetic)
+      } else if (lane < d.s2) {
         Taps<3, PAD> t;
         t.build(gx, gy, gz, d);
 #pragma unroll
         for (int c = 0; c < C; ++c) res[c][o] = sample_linear<3, PAD>(inn + (size_t)c * V, t, d);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][o] = 0.f;
       }
       if constexpr (SELF) {
 #pragma unroll

@@ -455,6 +455,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 3D configs timed after the headline workload")
+    ap.add_argument("--only-workload", action="store_true",
+                    help="profiling runs: the chosen workload and nothing else (no secondary configs, no north-star "
+                         "kernel pair, no CPU baseline)")
     args = ap.parse_args()
     stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
     if args.gpus < 1:
@@ -508,7 +511,7 @@ def main():
             "kernel_time_ms_first_step": breakdown,
         }
         if world == 1 and not stub:
-            if not args.no_secondary:
+            if not (args.no_secondary or args.only_workload):
                 # the 3D configs of BASELINE.json, timed by the same code on the same device (fewer steps: they are
                 # 2-15x longer); `value` above stays the headline workload's
                 other = {}
@@ -521,8 +524,9 @@ def main():
                     other[name] = result_record(name, w2, 1, k2, 1, e2, r2, b2)
                     other[name].pop("kernel_time_ms_first_step")
                 out["other_workloads"] = other
-            out["roofline_grid_sample3d"] = grid_sample3d_roofline(device)
-            if not args.no_cpu_baseline:
+            if not args.only_workload:
+                out["roofline_grid_sample3d"] = grid_sample3d_roofline(device)
+            if not (args.no_cpu_baseline or args.only_workload):
                 out["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(out))
     if world > 1:
