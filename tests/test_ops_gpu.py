@@ -416,7 +416,9 @@ def test_window_scatter_3d(dims, amp_vox, halo):
             assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
-@pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4)])
+@pytest.mark.parametrize("dims,C", [((18, 22), 1), ((16, 16), 4), ((8, 10, 12), 1), ((6, 7, 9), 4),
+                                    # several tiles of the LDS-staged source-box kernels (affine_box.hip), partial tiles
+                                    ((40, 64), 1), ((70, 48), 4), ((20, 24, 16), 1), ((24, 40, 32), 4), ((18, 17, 36), 2)])
 @pytest.mark.parametrize("pad", ["zeros", "border"])
 def test_affine_warp(dims, C, pad):
     from oracle import advchain_oracle as O
@@ -441,7 +443,8 @@ def test_affine_warp(dims, C, pad):
     (O.affine_warp(a3, t3, "bilinear", pad) * w).sum().backward()
     a4, t4 = inp.to(DEV).requires_grad_(True), theta_s.to(DEV).requires_grad_(True)
     (ops.affine_warp(a4, t4, "bilinear", pad) * w.to(DEV)).sum().backward()
-    assert maxdiff(a4.grad.cpu(), a3.grad) < TOL
+    # (border padding piles hundreds of samples on the border voxels: sums of ~40, fp32 order noise ~1e-6 relative)
+    assert maxdiff(a4.grad.cpu(), a3.grad) < TOL * max(1.0, float(a3.grad.abs().max()))
     assert rel(t4.grad.cpu(), t3.grad) < 5e-5
     n_ref = O.affine_warp(inp, theta, "nearest", pad)
     n_out = ops.affine_warp(inp.to(DEV), theta.to(DEV), "nearest", pad)

@@ -15,9 +15,12 @@ run() {  # counter, name, command...
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${lc}_$name -o $name -- "$@" > /tmp/pmc_${lc}_$name.log 2>&1
   python $repo/tools/pmc_summary.py /tmp/pmc_${lc}_$name "$out/pmc_${lc}_$name.csv"
 }
+python $repo/tools/north_star_pair.py --make-fields /tmp/ns_fields.pt > /tmp/ns_make.log 2>&1     # not profiled
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  run $ctr cfg2 python $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  run $ctr cfg3 python $repo/bench.py --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline
+  run $ctr cfg2 python $repo/bench.py --steps 2 --warmup 1 --only-workload
+  run $ctr cfg3 python $repo/bench.py --workload cfg3 --steps 2 --warmup 1 --only-workload
   run $ctr kb3d python $repo/tools/kernel_bench.py --shape 3d --reps 3
+  run $ctr ns_init_field python $repo/tools/north_star_pair.py --fields /tmp/ns_fields.pt --level init_field --reps 5
+  run $ctr ns_after_cfg3_ascent python $repo/tools/north_star_pair.py --fields /tmp/ns_fields.pt --level after_cfg3_ascent --reps 5
 done
 ls -la "$out"

@@ -20,12 +20,43 @@ ENTRIES = {   # entry -> (regexes of the kernels an entry launch runs, regex of 
     "advchain_compose_self_bwd": ([r"k_scatter_rows<\d, 1, \d, true", r"k_scatter_overflow<\d, 1>", r"k_gather_overflow<\d, 1>",
                                    r"k_adjoint_gather<\d, \d, \d, true", r"k_compose_self_bwd<", r"k_scatter_window[23]d<\d, \d, true"],
                                   r"k_scatter_rows<\d, 1, \d, true|k_adjoint_gather<\d, \d, \d, true|k_compose_self_bwd<|k_scatter_window[23]d<\d, \d, true"),
-    "advchain_compose_self_fwd": ([r"k_compose_self_fwd<", r"k_sample_tiled<\d, 1, \d, true>"],
-                                  r"k_compose_self_fwd<|k_sample_tiled<\d, 1, \d, true>"),
-    "advchain_grid_sample_fwd": ([r"k_grid_sample_fwd<", r"k_sample_tiled<\d, \d, \d, false>"],
-                                 r"k_grid_sample_fwd<|k_sample_tiled<\d, \d, \d, false>"),
+    "advchain_compose_self_fwd": ([r"k_compose_self_fwd<", r"k_sample_tiled<\d, 1, \d, true>", r"k_sample_march<3, true"],
+                                  r"k_compose_self_fwd<|k_sample_tiled<\d, 1, \d, true>|k_sample_march<3, true"),
+    "advchain_grid_sample_fwd": ([r"k_grid_sample_fwd<", r"k_sample_tiled<\d, \d, \d, false>", r"k_sample_march<\d, false"],
+                                 r"k_grid_sample_fwd<|k_sample_tiled<\d, \d, \d, false>|k_sample_march<\d, false"),
+    "advchain_affine_warp_fwd": ([r"k_affine_warp_fwd<"], r"k_affine_warp_fwd<"),
+    "advchain_affine_warp_bwd": ([r"k_affine_warp_bwd<", r"k_affine_gather_bwd<", r"k_affine_geometry<", r"k_reduce_partials"],
+                                 r"k_affine_warp_bwd<"),
+    "advchain_gauss_axis": ([r"k_gauss_axis"], r"k_gauss_axis"),
+    "advchain_tp_interp_fwd": ([r"k_tp_interp_fwd<"], r"k_tp_interp_fwd<"),
+    "advchain_band_reduce_axis": ([r"k_band_reduce"], r"k_band_reduce"),
+    "advchain_bias_field_fwd": ([r"k_bias_field_fwd|k_bias_fwd"], r"k_bias_field_fwd|k_bias_fwd"),
+    "advchain_bias_field_bwd": ([r"k_bias_field_bwd|k_bias_bwd"], r"k_bias_field_bwd|k_bias_bwd"),
+    "advchain_consistency_fwd": ([r"k_softmax_diff", r"k_edge_fwd"], r"k_softmax_diff"),
+    "advchain_consistency_bwd": ([r"k_consistency_bwd"], r"k_consistency_bwd"),
+    "advchain_axpy": ([r"k_axpy"], r"k_axpy"),
 }
-WIDE = re.compile(r"k_adjoint_gather|k_sample_tiled|k_gauss_axis_v4|k_max_displacement|k_axpy|k_absmax")   # 16 B / lane
+# kernels whose global reads are 16 B per lane (FETCH_SIZE x 2.0); the rest read 4 B per lane (x 1.19).  The marching
+# forward sampler mixes both (16-B staging of the image, 4-B grid loads): its factor is the blend for its byte split.
+for _e in ("advchain_grid_sample_bwd", "advchain_compose_self_bwd"):
+    ENTRIES[_e][0].append(r"k_adjoint_march<")
+    ENTRIES[_e] = (ENTRIES[_e][0], ENTRIES[_e][1] + r"|k_adjoint_march<")
+ENTRIES["advchain_grid_sample_bwd"] = ([p for p in ENTRIES["advchain_grid_sample_bwd"][0] if p != r"k_adjoint_march<"] +
+                                       [r"k_adjoint_march<\d, false"],
+                                       ENTRIES["advchain_grid_sample_bwd"][1].replace(r"|k_adjoint_march<", r"|k_adjoint_march<\d, false"))
+ENTRIES["advchain_compose_self_bwd"] = ([p for p in ENTRIES["advchain_compose_self_bwd"][0] if p != r"k_adjoint_march<"] +
+                                        [r"k_adjoint_march<3, true"],
+                                        ENTRIES["advchain_compose_self_bwd"][1].replace(r"|k_adjoint_march<", r"|k_adjoint_march<3, true"))
+WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_max_displacement|"
+                  r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4")   # 16 B / lane
+MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
+
+
+def read_factor(kernel):
+    for pat, f in MIXED.items():
+        if re.search(pat, kernel):
+            return f
+    return 2.0 if WIDE.search(kernel) else 1.0 / 0.84
 
 
 def load(path):
@@ -50,7 +81,7 @@ def main(root, out):
             parts = {}
             for k, (calls, kb) in fetch.items():
                 if any(re.search(p, k) for p in pats):
-                    f = 2.0 if WIDE.search(k) else 1.0 / 0.84
+                    f = read_factor(k)
                     rb += calls * kb * 1024 * f
                     parts[k] = {"calls": calls, "FETCH_SIZE_KB": round(kb, 1), "read_factor": round(f, 2),
                                 "WRITE_SIZE_KB": round(write.get(k, (0, 0.0))[1], 1)}
@@ -62,14 +93,40 @@ def main(root, out):
             if launches:
                 res[wl][entry] = {"traffic_bytes_per_launch": int((rb + wb) / launches), "read_bytes_per_launch": int(rb / launches),
                                   "write_bytes_per_launch": int(wb / launches), "entry_launches_profiled": launches, "kernels": parts}
+    # the north-star pair on its own (tools/north_star_pair.py): every kernel of the run belongs to the pair
+    ns = {}
+    for level in ("init_field", "after_cfg3_ascent"):
+        fetch = load(os.path.join(root, "pmc_fetch_size_ns_%s.csv" % level))
+        write = load(os.path.join(root, "pmc_write_size_ns_%s.csv" % level))
+        if not fetch:
+            continue
+        skip = re.compile(r"k_max_displacement|elementwise|distribution|fillBuffer|copyBuffer|Cijk|reduce_kernel")
+        main_calls = max((c for k, (c, _) in fetch.items() if re.search(r"k_sample_march|k_sample_tiled|k_grid_sample_fwd", k)),
+                         default=0)
+        if not main_calls:
+            continue
+        rb = sum(c * kb * 1024 * read_factor(k) for k, (c, kb) in fetch.items() if not skip.search(k))
+        wb = sum(c * kb * 1024 for k, (c, kb) in write.items() if not skip.search(k))
+        ns[level] = {"traffic_bytes_per_launch": int((rb + wb) / main_calls), "read_bytes": int(rb / main_calls),
+                     "write_bytes": int(wb / main_calls), "pairs_profiled": main_calls,
+                     "kernels": {k: {"calls": c, "FETCH_SIZE_KB": round(kb, 1), "read_factor": round(read_factor(k), 2),
+                                     "WRITE_SIZE_KB": round(write.get(k, (0, 0.0))[1], 1)}
+                                 for k, (c, kb) in fetch.items() if not skip.search(k)}}
+    if ns:
+        res["north_star"] = ns
     json.dump(res, open(out, "w"), indent=1)
     for wl in res:
-        if wl.startswith("_"):
+        if wl.startswith("_") or wl == "north_star":
             continue
         for e, v in res[wl].items():
             print("%s %-28s traffic %.1f MB/launch (read %.1f, write %.1f) over %d launches" % (
                 wl, e, v["traffic_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6,
                 v["entry_launches_profiled"]))
+
+
+    for level, v in res.get("north_star", {}).items():
+        print("north-star pair %-18s traffic %.1f MB per fwd+bwd (read %.1f, write %.1f) against 234.9 MB algorithmic" % (
+            level, v["traffic_bytes_per_launch"] / 1e6, v["read_bytes"] / 1e6, v["write_bytes"] / 1e6))
 
 
 if __name__ == "__main__":
