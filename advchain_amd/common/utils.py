@@ -45,22 +45,31 @@ def set_grad(module, requires_grad=False):
         p.requires_grad = requires_grad
 
 
+def _shuffle_with_constant(x, r):
+    """``random.shuffle(x, lambda: r)`` of Python <= 3.10 (the 2-argument form the reference calls, removed in 3.11):
+    Fisher-Yates from the end with every draw equal to r, in place."""
+    for i in reversed(range(1, len(x))):
+        j = int(r * (i + 1))
+        x[i], x[j] = x[j], x[i]
+
+
 def random_chain(alist, max_length=None, size_list=None):
-    """Random sub-chain in random order (utils.py:180-212; the reference relies on the 2-argument
-    ``random.shuffle`` removed in Python 3.11 and on an undefined name for 1-element lists -- both
-    are made well-defined here)."""
+    """Random sub-chain in random order (utils.py:180-212), draw for draw like the reference: the length from
+    ``np.random.randint``, ONE ``random.random()`` that drives the shuffle of ``alist`` (and of ``size_list`` with the
+    same permutation), both shuffled IN PLACE as the reference does.  The reference raises NameError for one-element
+    lists (undefined ``args``, utils.py:194); here that case returns the element."""
     length = len(alist)
     assert length >= 1, "input list must contains at least one element"
     max_length = length if max_length is None else min(max_length, length)
     if length == 1:
         return [alist[0]] if size_list is None else ([alist[0]], [size_list[0]])
     sub_len = np.random.randint(low=1, high=max_length + 1)
-    order = list(range(length))
-    random.shuffle(order)
-    chain = [alist[i] for i in order][:sub_len]
+    r = random.random()
+    _shuffle_with_constant(alist, r)
     if size_list is not None and len(size_list) >= 0:
-        return chain, [size_list[i] for i in order][:sub_len]
-    return chain
+        _shuffle_with_constant(size_list, r)
+        return alist[:sub_len], size_list[:sub_len]
+    return alist[:sub_len]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -717,6 +717,65 @@ def g8_kinks(aug):
     save("g8_kinks", out)
 
 
+# ----------------------------------------------------------------------------- G9: caller utilities (section 8 f4)
+def g9_utils(aug):
+    """random_chain (common/utils.py:180-212) under fixed seeds, rescale_intensity (utils.py:82-95), and the example
+    volume the notebooks load (example/data/cardiac/img.nrrd).  The reference reads it through SimpleITK, which this
+    image does not have: the fixture records an independent decode of the file (NRRD spec: header lines, blank line,
+    raw little-endian payload, fastest axis first), i.e. what sitk.GetArrayFromImage returns for it."""
+    import random
+    import hashlib
+    import advchain.common.utils as U
+    out, meta = {}, {}
+    cases = []
+    for seed in range(12):
+        n = 2 + seed % 4
+        names = ["t%d" % i for i in range(n)]
+        sizes = [10 * (i + 1) for i in range(n)]
+        max_len = None if seed % 3 == 0 else 1 + seed % n
+        with_sizes = seed % 2 == 1
+        np.random.seed(seed)
+        random.seed(1000 + seed)
+        a, s = list(names), list(sizes)
+        res = U.random_chain(a, max_length=max_len, size_list=s if with_sizes else None)
+        cases.append(dict(seed=seed, names=names, sizes=sizes, max_length=max_len, with_sizes=with_sizes,
+                          result=list(res[0]) if with_sizes else list(res), result_sizes=list(res[1]) if with_sizes else None,
+                          alist_after=a, sizes_after=s))
+    meta["random_chain"] = cases
+    x = rand((3, 2, 9, 11), 5100, -2.0, 3.0)
+    out["rescale_in"] = x
+    out["rescale_out"] = U.rescale_intensity(x.clone(), new_min=-1, new_max=2)
+    path = os.path.join(os.environ.get("ADVCHAIN_REFERENCE_ROOT", "/root/reference"), "example", "data", "cardiac", "img.nrrd")
+    blob = open(path, "rb").read()
+    end = blob.find(b"\n\n")
+    header = {}
+    for line in blob[:end].decode("ascii").splitlines()[1:]:
+        if line and not line.startswith("#") and ":" in line:
+            k, v = line.split(":", 1)
+            header[k.strip().lower()] = v.lstrip("=").strip()
+    sizes = [int(t) for t in header["sizes"].split()]
+    dt = {"short": "<i2", "int16": "<i2", "ushort": "<u2", "unsigned short": "<u2", "float": "<f4", "double": "<f8", "uchar": "u1",
+          "unsigned char": "u1", "int": "<i4"}[header["type"].lower()]
+    payload = blob[end + 2:]
+    if header.get("encoding", "raw").lower() in ("gzip", "gz"):
+        import gzip
+        payload = gzip.decompress(payload)
+    vol = np.frombuffer(payload, dtype=dt, count=int(np.prod(sizes))).reshape(sizes[::-1])
+    meta["nrrd"] = dict(relative_path="example/data/cardiac/img.nrrd", header=header, shape=list(vol.shape), dtype=str(vol.dtype),
+                        min=float(vol.min()), max=float(vol.max()), sum=float(vol.astype(np.float64).sum()),
+                        sha256=hashlib.sha256(np.ascontiguousarray(vol).tobytes()).hexdigest())
+    out["nrrd_slice0_patch"] = np.array(vol[0, 40:56, 60:76])
+    # load_image_label semantics (utils.py:29-80) on that array: slice 0, centre crop 192 x 192, min-max to [0, 1]
+    img = vol[0]
+    hd, wd = (img.shape[0] - 192) // 2, (img.shape[1] - 192) // 2
+    crop = img[hd:192 + hd, wd:192 + wd]
+    crop = (crop - crop.min()) / (crop.max() - crop.min() + 1e-10)
+    out["nrrd_loaded_sample"] = np.array(crop[::16, ::16])
+    meta["nrrd"]["loaded_sum"] = float(crop.astype(np.float64).sum())
+    out["meta"] = meta
+    save("g9_utils", out)
+
+
 ONLY = []
 
 
@@ -745,6 +804,8 @@ def main():
         g7_misc(aug)
     if want("g8"):
         g8_kinks(aug)
+    if want("g9"):
+        g9_utils(aug)
     if want("kat"):
         kat(aug)
 

@@ -98,3 +98,42 @@ def test_nrrd_reader_and_image_loading(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.nrrd").write_bytes(b"not a volume")
         read_nrrd(str(tmp_path / "bad.nrrd"))
+
+
+def test_caller_utilities_match_the_reference_golden():
+    """G9: random_chain draw for draw under fixed seeds (incl. the in-place shuffle of its
+    arguments), rescale_intensity, and -- when the reference checkout is mounted -- the NRRD reader and load_image_label
+    on the reference's own example volume against an independent decode of that file."""
+    import os
+    import random
+    import hashlib
+    import numpy as np
+    import torch
+    from tests.helpers import Fixture
+    from advchain_amd.common import utils as U
+    fx = Fixture("g9_utils")
+    meta = fx.json()
+    for c in meta["random_chain"]:
+        np.random.seed(c["seed"])
+        random.seed(1000 + c["seed"])
+        a, s = list(c["names"]), list(c["sizes"])
+        res = U.random_chain(a, max_length=c["max_length"], size_list=s if c["with_sizes"] else None)
+        if c["with_sizes"]:
+            assert list(res[0]) == c["result"] and list(res[1]) == c["result_sizes"], c["seed"]
+            assert s == c["sizes_after"]
+        else:
+            assert list(res) == c["result"], c["seed"]
+        assert a == c["alist_after"]
+    out = U.rescale_intensity(fx.t("rescale_in").clone(), new_min=-1, new_max=2)
+    assert float((out - fx.t("rescale_out")).abs().max()) < 1e-6
+    path = os.path.join(os.environ.get("ADVCHAIN_REFERENCE_ROOT", "/root/reference"), meta["nrrd"]["relative_path"])
+    if not os.path.exists(path):
+        return                      # the reference's data does not travel to the GPU box
+    vol, header = U.read_nrrd(path)
+    m = meta["nrrd"]
+    assert list(vol.shape) == m["shape"] and str(vol.dtype) == m["dtype"]
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).hexdigest() == m["sha256"]
+    assert np.array_equal(vol[0, 40:56, 60:76], fx.arr("nrrd_slice0_patch"))
+    img = U.load_image_label(path, slice_id=0, crop_size=(192, 192))
+    assert img.shape == (192, 192) and abs(float(img.astype(np.float64).sum()) - m["loaded_sum"]) < 1e-6 * m["loaded_sum"]
+    assert np.allclose(img[::16, ::16], fx.arr("nrrd_loaded_sample"), atol=1e-7)
