@@ -36,6 +36,7 @@ namespace advchain {
 enum { kMarchFree = 0, kMarchClamp = 1, kMarchBorder = 2 };
 // timing experiments only (ADVCHAIN_MARCH_DEBUG, results are wrong): switch a phase off
 constexpr int kDbgNoA = 16, kDbgNoB = 32, kDbgNoStore = 64, kDbgNoStage = 128;
+constexpr int kSegOwn = 56;       // owned lanes of an x segment (rows longer than 64 voxels)
 constexpr int kMarchXcd = 256;    // workgroup -> tile map that keeps halo-sharing tiles on one XCD (one L2)
 
 template <int C, bool SELF, bool GG, int NW, int RPW>
@@ -64,7 +65,7 @@ template <int C, bool SELF, bool GG, int MODE, int NW, int RPW>
 __global__ void __launch_bounds__(NW * 64, (MarchCfg<C, SELF, GG, NW, RPW>::MIN_WAVES))
 k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                 float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int flags,
-                int32_t* __restrict__ untracked) {
+                int32_t* __restrict__ untracked, int nseg) {
   using G = MarchCfg<C, SELF, GG, NW, RPW>;
   constexpr int R = G::R, TY = G::TY, RC = G::RING_CH, LC = G::LATE_CH, P = G::PITCH, PS = G::PS, LS = G::LS;
   constexpr bool CLIP = MODE != kMarchFree, BORDER = MODE == kMarchBorder;
@@ -80,7 +81,12 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   int tile = blockIdx.x + gridDim.x * blockIdx.y;
   const int tiles = gridDim.x * gridDim.y;
   if ((flags & kMarchXcd) && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);
-  const int n = tile / (int)gridDim.x, rem = tile - n * (int)gridDim.x;
+  const int n = tile / (int)gridDim.x;
+  int rem = tile - n * (int)gridDim.x;
+  // rows longer than 64 voxels: x segments of 56 owned lanes with 4 halo lanes either side (16-byte aligned staging)
+  const int seg = rem % nseg;
+  rem /= nseg;
+  const int xbase = nseg > 1 ? seg * kSegOwn - 4 : 0;      // x of lane 0
   const int ty = rem % n1, tz = rem / n1;
   const int y0 = ty * TY;
   const int za = tz * zc, zb = min(za + zc, d.s0);
@@ -101,14 +107,14 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
   const bool has_item = threadIdx.x < R * 16;
   const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
-  const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
-  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
-  const int lds_item = r_st * P + 4 + x_st;
+  const int sy_st = y0 - 1 + r_st, x_st = xbase + 4 * q_st;
+  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st >= 0 && x_st < d.s2;
+  const int lds_item = r_st * P + 4 + 4 * q_st;
 
   // Loads are UNCONDITIONAL, from addresses clamped into the volume, and what lies outside is zeroed with selects when
   // the values go to LDS: a load inside `if (inside)` gets its own exec-mask block, and the compiler put a full
   // `s_waitcnt vmcnt(0)` between two such blocks -- one exposed memory round trip per step.
-  const int sy_c = min(max(sy_st, 0), d.s1 - 1), x_c = x_st < d.s2 ? x_st : 0;
+  const int sy_c = min(max(sy_st, 0), d.s1 - 1), x_c = (x_st >= 0 && x_st < d.s2) ? x_st : 0;
   const int row_off = sy_c * d.s2 + x_c;
   auto plane_ok = [&](int p) { return row_ok && p >= 0 && p < d.s0; };
   auto load_rows = [&](const float* base, int nch, int p, float (*v)[4]) {
@@ -198,8 +204,8 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
   for (int o = 0; o < RPW; ++o) gg_hold[o][0] = gg_hold[o][1] = gg_hold[o][2] = 0.f;
 
-  const float flane = (float)lane;
-  const float xlo = -flane, xhi = (float)(d.s2 - 1) - flane;
+  const int xl = xbase + lane;                 // x of this lane
+  const float xlo = -(float)xl, xhi = (float)(d.s2 - 1 - xl);
   const float half_top[3] = {0.5f * (float)(d.s2 - 1), 0.5f * (float)(d.s1 - 1), 0.5f * (float)(d.s0 - 1)};
   float* const tr = trbuf + wave * G::TRW;
   const int own_row0 = wave * RPW;              // first owned output row of this wave within the tile
@@ -225,14 +231,15 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
         const int j = i0 + lane;
         const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
         const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
-        const bool inside = j < ITEMS && 4 * q < d.s2 && (y0 + own_row0 + o) < d.s1;
+        const int xq = xbase + 4 * q;
+        const bool inside = j < ITEMS && xq < d.s2 && (nseg == 1 || (q >= 1 && q <= 14)) && (y0 + own_row0 + o) < d.s1;
         bool valid = false;
         float* p = nullptr;
 #pragma unroll
         for (int aa = 0; aa < NR; ++aa)
           if (a0 + aa < G::NA && a == aa) {
             valid = inside && ok[a0 + aa];
-            p = dst[a0 + aa] + (uint32_t)(row_base[a0 + aa] + o * d.s2 + 4 * q);
+            p = dst[a0 + aa] + (uint32_t)(row_base[a0 + aa] + o * d.s2 + xq);
           }
         if (valid) *reinterpret_cast<float4*>(p) = v4;
       }
@@ -446,10 +453,11 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
   static const int dbg = (getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0) |
                          (getenv("ADVCHAIN_NO_XCD_MAP") ? 0 : kMarchXcd);
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
-  const int zc = march_zc(d, N, G::TY);
+  const int nseg = d.s2 <= 64 ? 1 : (d.s2 + kSegOwn - 1) / kSegOwn;
+  const int zc = march_zc(d, N * nseg, G::TY);
   const int n0 = (d.s0 + zc - 1) / zc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, gout, in, grid, gin, ggrid, d, n1,
-                     zc, dbg, SELF ? ws : (int32_t*)nullptr);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
+                     n1, zc, dbg, SELF ? ws : (int32_t*)nullptr, nseg);
 }
 
 static bool march_shape_ok(const Dims& d, const void* a, const void* b, const void* c, const void* e, const void* f) {
@@ -457,7 +465,7 @@ static bool march_shape_ok(const Dims& d, const void* a, const void* b, const vo
   if (off) return false;
   const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
                        reinterpret_cast<uintptr_t>(e) | reinterpret_cast<uintptr_t>(f);
-  return d.s2 >= 8 && d.s2 <= 64 && (d.s2 & 3) == 0 && (al & 15) == 0 && d.s0 >= 2 && d.voxels() * 4 < (1ll << 31);
+  return d.s2 >= 8 && (d.s2 & 3) == 0 && (al & 15) == 0 && d.s0 >= 2 && d.voxels() * 4 < (1ll << 31);
 }
 
 // Exact-bound (|displacement| < 1 voxel) self-composition backward, 3D.  ADVCHAIN_ERR_UNSUPPORTED: use the tile kernel.

@@ -19,6 +19,7 @@
 
 namespace advchain {
 
+constexpr int kFwdSegOwn = 56;   // owned lanes of an x segment (rows longer than 64 voxels)
 enum { kFwdFree = 0, kFwdClamp = 1, kFwdBorder = 2 };   // zeros padding | zeros padding + clamp(grid, -1, 1) | border padding
 
 template <int C, bool SELF, int NW, int RPW>
@@ -38,7 +39,7 @@ struct FwdMarchCfg {
 template <int C, bool SELF, int MODE, int NW, int RPW>
 __global__ void __launch_bounds__(NW * 64)
 k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
-               const float* __restrict__ phi0, Dims d, int n1, int zc, int final_mode, float* __restrict__ disp_out) {
+               const float* __restrict__ phi0, Dims d, int n1, int zc, int final_mode, float* __restrict__ disp_out, int nseg) {
   using G = FwdMarchCfg<C, SELF, NW, RPW>;
   constexpr int R = G::R, TY = G::TY, P = G::PITCH, PS = G::PS;
   constexpr int PAD = MODE == kFwdBorder ? PAD_BORDER : PAD_ZEROS;
@@ -48,7 +49,14 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  // rows longer than 64 voxels: x segments of 56 owned lanes with 4 halo lanes either side (16-byte aligned staging)
+  int rem = blockIdx.x;
+  const int seg = rem % nseg;
+  rem /= nseg;
+  const int xbase = nseg > 1 ? seg * kFwdSegOwn - 4 : 0;      // x of lane 0
+  const int xl = xbase + lane;                                // x of this lane
+  const bool xowned = nseg > 1 ? (lane >= 4 && lane < 60 && xl < d.s2) : lane < d.s2;
+  const int ty = rem % n1, tz = rem / n1;
   const int y0 = ty * TY;
   const int za = tz * zc, zb = min(za + zc, d.s0);
   const float* inn = in + (int64_t)n * C * V;
@@ -66,12 +74,12 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
   // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
   const bool has_item = threadIdx.x < R * 16;
   const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
-  const int sy_st = y0 - 1 + r_st, x_st = 4 * q_st;
-  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
+  const int sy_st = y0 - 1 + r_st, x_st = xbase + 4 * q_st;
+  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st >= 0 && x_st < d.s2;
   // loads are unconditional, from addresses clamped into the volume; what lies outside is zeroed on the way to LDS (a
   // load inside `if (inside)` gets its own exec-mask block and the compiler serialises such blocks with full waits)
-  const int row_off = min(max(sy_st, 0), d.s1 - 1) * d.s2 + (x_st < d.s2 ? x_st : 0);
-  const int lds_item = r_st * P + 4 + x_st;
+  const int row_off = min(max(sy_st, 0), d.s1 - 1) * d.s2 + ((x_st >= 0 && x_st < d.s2) ? x_st : 0);
+  const int lds_item = r_st * P + 4 + 4 * q_st;
   auto fetch = [&](int p, float (*v)[4]) {
     const uint32_t s = (uint32_t)(min(max(p, 0), d.s0 - 1) * plane_stride + row_off);
 #pragma unroll
@@ -116,7 +124,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
         const int uy = min(y0 + own_row0 + o, d.s1 - 1);
-        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(lane, d.s2 - 1));
+        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(max(xl, 0), d.s2 - 1));
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[o][a] = gn[(size_t)a * V + s];
       }
@@ -124,7 +132,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
         const int uy = min(y0 + own_row0 + o, d.s1 - 1);
-        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(lane, d.s2 - 1));
+        const uint32_t s = (uint32_t)((z * d.s1 + uy) * d.s2 + min(max(xl, 0), d.s2 - 1));
 #pragma unroll
         for (int a = 0; a < 3; ++a) p0v[o][a] = p0n[(size_t)a * V + s];
       }
@@ -162,7 +170,9 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
       const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs;
       const float wy1 = ys - fy, wy0 = (fy + 1.f) - ys;
       const float wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
-      const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)d.s2;
+      // both x corners in the staged 64 columns (a single segment also has the zero columns at x = -1 and x = S2)
+      const bool xin = nseg > 1 ? (unsigned)(ix - xbase) <= 62u : (unsigned)(ix + 1) <= (unsigned)d.s2;
+      const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && xin;
       // lanes whose 8 corners are in the ring take them from LDS; the others (displacement of a voxel or more) gather
       // from global memory with the same arithmetic.  Smooth fields make whole rows one or the other, and the empty
       // side of the branch is skipped (execz).
@@ -170,7 +180,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
         float w[8];
         w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
         w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
-        const int oxy = (r + (iy - uy)) * P + 4 + ix;
+        const int oxy = (r + (iy - uy)) * P + 4 + (ix - xbase);
         const float* q0 = ring + (iz & 3) * PS + oxy;
         const float* q1 = ring + ((iz + 1) & 3) * PS + oxy;
 #pragma unroll
@@ -184,7 +194,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
               for (int cx = 0; cx < 2; ++cx) acc += ((cz ? q1 : q0) + (c * R + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
           res[c][o] = acc;
         }
-      } else if (lane < d.s2) {
+      } else if (xowned) {
         Taps<3, PAD> t;
         t.build(gx, gy, gz, d);
 #pragma unroll
@@ -197,10 +207,10 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           float v = res[c][o];
-          const int sc = c == 0 ? lane : (c == 1 ? uy : z), Sc = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
+          const int sc = c == 0 ? xl : (c == 1 ? uy : z), Sc = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
           if (final_mode == 1) v = (v - p0v[o][c]) + lin_coord(sc, Sc);   // (sample - phi0) + identity (adv_morph.py:143,176 + 474,483)
           res[c][o] = v;
-          if (disp_out && lane < d.s2 && uy < d.s1) dmax = fmaxf(dmax, voxel_displacement(v, Sc, sc));
+          if (disp_out && xowned && uy < d.s1) dmax = fmaxf(dmax, voxel_displacement(v, Sc, sc));
         }
       }
     }
@@ -221,9 +231,10 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
         const int j = i0 + lane;
         const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
         const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
-        const bool valid = j < ITEMS && c0 + a < C && 4 * q < d.s2 && (y0 + own_row0 + o) < d.s1;
+        const int xq = xbase + 4 * q;
+        const bool valid = j < ITEMS && c0 + a < C && xq < d.s2 && (nseg == 1 || (q >= 1 && q <= 14)) && (y0 + own_row0 + o) < d.s1;
         if (valid)
-          *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + (uint32_t)((z * d.s1 + y0 + own_row0 + o) * d.s2 + 4 * q)) = v4;
+          *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + (uint32_t)((z * d.s1 + y0 + own_row0 + o) * d.s2 + xq)) = v4;
       }
       lds_order();
     }
@@ -262,10 +273,11 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
     attr_set = true;
   }
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
-  const int zc = fwd_march_zc(d, N, G::TY, C);
+  const int nseg = d.s2 <= 64 ? 1 : (d.s2 + kFwdSegOwn - 1) / kFwdSegOwn;
+  const int zc = fwd_march_zc(d, N * nseg, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
-                     final_mode, disp_out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
+                     final_mode, disp_out, nseg);
 }
 
 template <int C>
@@ -282,7 +294,7 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
   static const bool off = getenv("ADVCHAIN_NO_MARCH_FWD") != nullptr;   // A/B knob
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out);
-  if (d.s2 < 8 || d.s2 > 64 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
+  if (d.s2 < 8 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
     return ADVCHAIN_ERR_UNSUPPORTED;
   if (self) {
     if (C != 3) return ADVCHAIN_ERR_UNSUPPORTED;

@@ -361,6 +361,49 @@ def test_demons_field_backward_across_the_gather_threshold(dims, vs, window):
     assert err < 1e-4, (dims, window, scale, dm, err)
 
 
+@pytest.mark.parametrize("dims", [(6, 10, 72), (5, 9, 80), (4, 6, 132), (10, 12, 64), (5, 7, 16)])
+@pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
+def test_march_kernels_rows_of_any_length(dims, pad, clamp):
+    """The z-marching forward sampler and exact-bound adjoint (sample_march.hip / adjoint_march.hip) on rows longer than
+    64 voxels (x segments of 56 owned lanes + 4 halo lanes), on short rows and on the 64-voxel rows they were written
+    for: sub-voxel fields (everything from the LDS ring) and a field with a few samples beyond a voxel (per-lane
+    fallback to global gathers in the forward), against ATen / the oracle."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = 3
+    perm = (0, 2, 3, 4, 1)
+    for amp_vox, exact in ((0.45, True), (1.6, False)):
+        g = torch.Generator().manual_seed(9)
+        disp = (torch.rand((2, d) + dims, generator=g) * 2 - 1) * amp_vox
+        scale = torch.tensor([2.0 / (dims[d - 1 - a] - 1) for a in range(d)]).view(1, d, 1, 1, 1)
+        grid = (O.identity_grid(2, dims) * 1.01 + disp * scale).contiguous()
+        for C in (1, 4):
+            inp, w = rand((2, C) + dims, 81), rand((2, C) + dims, 82)
+            a, gr = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+            gp = torch.clamp(gr, -1, 1) if clamp else gr
+            ref = F.grid_sample(a, gp.permute(*perm), padding_mode=pad, align_corners=True)
+            (ref * w).sum().backward()
+            out = ops.raw_grid_sample_fwd(inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp)
+            assert maxdiff(out.cpu(), ref) < TOL, (C, amp_vox)
+            if exact and float(ops.raw_max_displacement(grid.to(DEV)).item()) < 0.999:
+                gin, ggrid = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, True, -1)
+                assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max())), C
+                assert maxdiff(ggrid.cpu(), gr.grad) < 5e-5 * max(1.0, float(gr.grad.abs().max())), C
+        # self-composition (border padding), forward with displacement slots and exact-bound backward
+        phi = (O.identity_grid(2, dims) + disp * scale).contiguous()
+        p = phi.clone().requires_grad_(True)
+        q = O.compose_fields(p, p)
+        wq = rand((2, d) + dims, 83)
+        (q * wq).sum().backward()
+        slots = torch.zeros(ops.DISP_SLOTS, device=DEV)
+        out = ops.raw_compose_self_fwd(phi.to(DEV), disp_out=slots)
+        assert maxdiff(out.cpu(), q) < TOL
+        if exact:
+            ws = ops._scatter_workspace(2, dims, DEV)
+            got = ops.raw_compose_self_bwd(wq.to(DEV), phi.to(DEV), ws, chain=False, halo=-1)
+            assert maxdiff(got.cpu(), p.grad) < 5e-5 * max(1.0, float(p.grad.abs().max()))
+
+
 def _smooth_field(dims, amp_vox, seed):
     """identity + a smooth displacement of up to ~amp_vox voxels (low-resolution noise, upsampled)."""
     from oracle import advchain_oracle as O
