@@ -512,6 +512,54 @@ def kat(aug):
     save("kat_2d", out)
 
 
+JIT = 4e-6
+
+
+def g6_sensitivity(aug):
+    """The N-step ascent map amplifies rounding differences (chaotic for n_iter >= 3).  For the
+    free-running fixtures with n_iter >= 3 this records how far the REFERENCE's own results move when the output of
+    every DemonsCompose is jittered by 4e-6 (normalised units: what another correct implementation's deformation field
+    differs by, cf. g8_kinks): a free-running comparison over that horizon cannot be tighter than this spread."""
+    import io
+    import contextlib
+    out = {}
+    cases = {"2d_full_n3": dict(sd=2, ds=[2, 1, 32, 32], names=["noise", "bias", "morph", "affine"], n_iter=3)}
+    for tag, c in cases.items():
+        base = np.load(os.path.join(OUT, "g6_%s.npz" % tag))
+        spread = dict(loss_rel=0.0, adv_data=0.0, warped_back=0.0)
+        pspread = None
+        for trial in range(3):
+            chain, spec = build_chain(aug, c["sd"], c["ds"], c["names"])
+            for i, t in enumerate(chain):
+                t.init_parameters()
+                t.set_parameters(torch.from_numpy(base["init_param_%d" % i]))
+                if t.get_name() == "morph":
+                    orig = t.DemonsCompose
+                    calls = [0]
+
+                    def jittered(*a, _orig=orig, _calls=calls, **k):
+                        _calls[0] += 1
+                        q = _orig(*a, **k)
+                        g = torch.Generator().manual_seed(7000 + 100 * trial + _calls[0])
+                        return q + (torch.rand(q.shape, generator=g) * 2 - 1) * JIT
+                    t.DemonsCompose = jittered
+            solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
+                                                           divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
+            with contextlib.redirect_stdout(io.StringIO()):
+                loss = solver.adversarial_training(data=torch.from_numpy(base["data"]), model=make_model(c["sd"]),
+                                                   n_iter=c["n_iter"], lazy_load=True, power_iteration=False, step_sizes=1)
+            ref = float(base["final_loss"])
+            spread["loss_rel"] = max(spread["loss_rel"], abs(float(loss) - ref) / abs(ref))
+            spread["adv_data"] = max(spread["adv_data"], float((solver.adv_data.detach() - torch.from_numpy(base["adv_data"])).abs().max()))
+            spread["warped_back"] = max(spread["warped_back"],
+                                        float((solver.warped_back_adv_output.detach() - torch.from_numpy(base["warped_back"])).abs().max()))
+            ps = [float((t.param.detach() - torch.from_numpy(base["final_param_%d" % i])).abs().max()) for i, t in enumerate(chain)]
+            pspread = ps if pspread is None else [max(a, b) for a, b in zip(pspread, ps)]
+        out.setdefault(tag, {})["jitter_%g" % JIT] = dict(jitter=JIT, trials=3, params=pspread, **spread)
+        print("  sensitivity %s @%g: %s params %s" % (tag, JIT, {k: "%.1e" % v for k, v in spread.items()}, ["%.1e" % v for v in pspread]))
+    return out
+
+
 # ----------------------------------------------------------------------------- G7: sub-features without a pin so far
 def g7_misc(aug):
     """ignore_values of AdvNoise / AdvBias (adv_noise.py:85-89, adv_bias.py:176-184), AdvBias init modes
@@ -800,6 +848,13 @@ def main():
         g5_loss()
     if want("g6"):
         g6_solver(aug)
+    if want("g6s"):
+        global JIT
+        merged = {}
+        for JIT in (1e-7, 4e-6):
+            for tag, rec in g6_sensitivity(aug).items():
+                merged.setdefault(tag, {}).update(rec)
+        save("g6s_sensitivity", dict(meta=merged))
     if want("g7"):
         g7_misc(aug)
     if want("g8"):

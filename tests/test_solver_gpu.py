@@ -82,17 +82,25 @@ def test_free_running(case):
         # fp32 rounding noise there.  Only sanity is asserted for the free-running result.
         assert torch.isfinite(loss) and abs(float(loss) - ref) < 0.25 * abs(ref)
         return
-    # rounding-level differences are amplified by the ascent map (chaotic for n_iter >= 3)
-    ltol = 2e-4 if n_iter <= 2 else 2e-2
-    assert abs(float(loss) - ref) < 1e-6 + ltol * abs(ref), (float(loss), ref)
     if n_iter >= 3:
-        return  # trajectories have split at rounding level by step 3; per-step parity is test_teacher_forced_steps
-    tol = TOL if n_iter <= 1 else 5 * TOL
-    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data")) < tol
-    assert maxdiff(solver.warped_back_adv_output.cpu(), fx.t("warped_back")) < tol * 3
+        # The ascent map is chaotic over this horizon IN THE REFERENCE ITSELF: tests/golden/g6s_sensitivity.npz records
+        # how far the reference's own free-running result moves when its deformation fields are jittered by 1e-7
+        # (normalised units, ~1 ulp) -- sign(grad) updates of near-zero affine gradients flip.  The GPU run has to stay
+        # inside that spread; per-step parity at 1e-4 is test_teacher_forced_steps.
+        sens = Fixture("g6s_sensitivity").json()[case]["jitter_1e-07"]
+        assert abs(float(loss) - ref) <= sens["loss_rel"] * abs(ref), (float(loss), ref)
+        assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data")) <= sens["adv_data"]
+        for i, t in enumerate(solver.chain_of_transforms[:len(chain)]):
+            assert maxdiff(t.param.cpu(), fx.t("final_param_%d" % i)) <= max(sens["params"][i], TOL), (case, i)
+        return
+    # horizons of at most two steps: the 1e-4 contract on everything (scale-relative for logits and parameters)
+    assert abs(float(loss) - ref) < 1e-7 + TOL * abs(ref), (float(loss), ref)
+    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data")) < TOL
+    wb = fx.t("warped_back")
+    assert maxdiff(solver.warped_back_adv_output.cpu(), wb) < TOL * max(1.0, float(wb.abs().max())), case
     for i, t in enumerate(solver.chain_of_transforms[:len(chain)]):
         ref_p = fx.t("final_param_%d" % i)
-        assert maxdiff(t.param.cpu(), ref_p) < tol * max(1.0, float(ref_p.abs().max())), (case, i)
+        assert maxdiff(t.param.cpu(), ref_p) < TOL * max(1.0, float(ref_p.abs().max())), (case, i)
 
 
 @pytest.mark.parametrize("case", [c for c in G6_CASES if c not in ("2d_n0",)])
@@ -215,7 +223,7 @@ def test_kat_appendix_b():
     assert abs(float(l0) - 2.503928030e-03) < 2e-7
     l2 = solver.adversarial_training(data=data, model=model, n_iter=2, lazy_load=True, step_sizes=1)
     assert abs(float(l2) - 3.633607877e-03) < 1e-6
-    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data_n2")) < 5e-4
+    assert maxdiff(solver.adv_data.cpu(), fx.t("adv_data_n2")) < TOL
 
 
 def test_cpu_tensor_is_rejected():

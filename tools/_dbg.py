@@ -1,18 +1,18 @@
-import torch, torch.nn.functional as F, sys
+import io, contextlib, sys
 sys.path.insert(0,'.')
-from advchain_amd import ops
-from tests.helpers import rand
-def to_planar(g):
-    d=g.shape[-1]; return g.permute(0,d+1,*range(1,d+1)).contiguous()
-C=4; dims=(8,12,16)
-inp=rand((2,C)+dims,1); grid=rand((2,)+dims+(3,),2,-1.3,1.3)
-ref=F.grid_sample(inp,grid,mode='bilinear',padding_mode='zeros',align_corners=True)
-out=ops.raw_grid_sample_fwd(inp.cuda(),to_planar(grid).cuda(),0,0,False).cpu()
-torch.set_printoptions(precision=4, linewidth=200)
-for c in range(4):
-    print('c',c,'out',out[0,c,0,0]); print('    ref',ref[0,c,0,0])
-# search: where does out[0,0,0,0,4] appear in ref?
-v=out[0,0,0,0,4]
-print('match', ((ref-v).abs()<1e-6).nonzero().tolist())
-v=out[0,0,0,0,5]
-print('match', ((ref-v).abs()<1e-6).nonzero().tolist())
+import torch
+from tests.helpers import Fixture, counted_torch_seed, maxdiff
+from tests.test_solver_gpu import make_solver, _kwargs, G6_CASES, DEV
+for case in G6_CASES:
+    fx = Fixture("g6_" + case)
+    solver, chain, meta, model = make_solver(fx)
+    with contextlib.redirect_stdout(io.StringIO()), counted_torch_seed(1000):
+        loss = solver.adversarial_training(data=fx.t("data", DEV), model=model, **_kwargs(fx, meta))
+    ref = fx.f("final_loss")
+    errs = dict(loss_rel=abs(float(loss)-ref)/abs(ref), adv=maxdiff(solver.adv_data.cpu(), fx.t("adv_data")),
+                wb=maxdiff(solver.warped_back_adv_output.cpu(), fx.t("warped_back")))
+    ps=[]
+    for i, t in enumerate(solver.chain_of_transforms[:len(chain)]):
+        rp = fx.t("final_param_%d" % i)
+        ps.append(maxdiff(t.param.cpu(), rp)/max(1.0, float(rp.abs().max())))
+    print("%-22s n=%d loss_rel %.1e adv %.1e wb %.1e params %s" % (case, meta["train"]["n_iter"], errs['loss_rel'], errs['adv'], errs['wb'], ["%.1e"%p for p in ps]))
