@@ -660,6 +660,11 @@ int advchain_warp_adjoint_gather_launch(const float* gout, const float* in, cons
                                         int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                         int32_t* workspace, int halo, hipStream_t st);
 
+// scatter_march.hip: owner-computes z-march for exact bounds of 2..4 voxels (3D)
+int advchain_scatter_march_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                  int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
+                                  hipStream_t st);
+
 // scatter_window.hip
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
@@ -804,11 +809,16 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
     const int rc = advchain_warp_adjoint_gather_launch(grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                                        clamp_grid, workspace, halo, (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+    if (ndim == 3 && halo <= -2) {   // exact bound of 2..4 voxels: owner-computes march, no global atomics
+      const int rm = advchain_scatter_march_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, id, padding, clamp_grid,
+                                                   -halo, workspace, (hipStream_t)stream);
+      if (rm != ADVCHAIN_ERR_UNSUPPORTED) return rm;
+    }
     const int rw = advchain_scatter_window_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                                   clamp_grid, halo, nullptr, (hipStream_t)stream);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                         clamp_grid, workspace, 0, halo, (hipStream_t)stream);
+                                         clamp_grid, workspace, 0, halo < 0 ? -halo : halo, (hipStream_t)stream);
   }
   if (workspace && grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
@@ -867,11 +877,16 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
     const int rc = advchain_self_adjoint_gather_launch(grad_out, phi, grad_phi, N, ndim, d, workspace, chain, halo,
                                                        (hipStream_t)stream);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+    if (ndim == 3 && halo <= -2) {   // exact bound of 2..4 voxels: owner-computes march, no global atomics
+      const int rm = advchain_scatter_march_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, d, PAD_BORDER, 0, -halo,
+                                                   workspace, (hipStream_t)stream);
+      if (rm != ADVCHAIN_ERR_UNSUPPORTED) return rm;
+    }
     const int rw = advchain_scatter_window_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER,
                                                   0, halo, workspace, (hipStream_t)stream);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
-                                         workspace, chain, halo, (hipStream_t)stream);
+                                         workspace, chain, ndim == 3 && halo < 0 ? -halo : halo, (hipStream_t)stream);
   }
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);

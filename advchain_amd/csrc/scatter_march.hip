@@ -1,0 +1,283 @@
+// z-marching owner-computes scatter for the 3D sampler backward with an EXACT displacement bound of 2..4 voxels (gfx950).
+//
+// Above one voxel the gather form is too expensive ((2H+1)^3 tent products per output) and the source-tiled window
+// scatter (scatter_window.hip) pays for its freedom from any bound with global float atomics: every window cell is
+// flushed with one (4.2 per sample and channel for its 4 x 8 x 32 tiles), the destination has to be zero-filled first,
+// and the coordinate path of a self-composition goes through three more atomics per sample.  With the bound H the
+// forward MEASURED (ops.squaring_halo / ops.warp_halo) the owner can do everything itself:
+//   * a workgroup owns TY output rows (whole x rows, lane <-> x) and walks a chunk of planes; at step zp it takes the
+//     samples of plane zp in rows y0-H .. y0+TY+H-1 straight from global memory (coalesced 4-byte loads: a sample row
+//     is read once per workgroup, nothing to stage), builds their taps with the sampler's own arithmetic and deposits
+//     the corners that fall in ITS rows and ITS chunk into a ring of 2H+3 accumulator planes in LDS -- 32-bit fixed
+//     point, value * 2^20 / max|grad_out| (LDS integer atomics run at LDS rate, LDS float atomics do not);
+//   * after plane zp the output plane zp-H has seen every sample that can reach it: it is converted, the coordinate
+//     path of its own samples is added (self-composition) or stored (grad_grid), and it leaves with PLAIN stores.
+// No global atomic, no zero-fill, fixed summation order up to the commutativity of integer adds: deterministic.
+// The price is halo work: samples are visited (TY+2H)/TY x (ZC+2H)/ZC times (loads, taps, range tests -- not atomics).
+//
+// Contract: |unnormalize(grid) - s| < H voxels for every sample, guaranteed by the caller (negative `halo`).
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+constexpr float kFixScale = 1048576.f;   // 2^20: up to 2047 deposits of weight <= 1 per cell stay below 2^31
+
+__global__ void k_march_scatter_prepare(int32_t* ws) { ws[2] = 0; }
+
+// max |x| -> ws[2] (float bits; non-negative floats order like their bit patterns)
+__global__ void __launch_bounds__(kBlock) k_march_absmax(const float* __restrict__ x, int64_t n4, int32_t* __restrict__ ws) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 q = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float sm[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, sm[w]);
+    if (m > 0.f && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned int*>(ws + 2), __float_as_uint(m));
+  }
+}
+
+// SELF : in == grid == phi (C == 3); gin receives value path + coordinate path     (advchain_compose_self_bwd)
+// !SELF: gin <- value path; GG: ggrid <- coordinate path                            (advchain_grid_sample_bwd)
+// NWV waves per workgroup share one accumulator tile, so LDS does not cap the waves of a CU: 8 for 8 owned rows, 4 for 4
+// (with 8 waves on 4 + 2H rows half of them idle in the second round of a step: measured 380 vs 252 us, C = 4, H = 4).
+template <int PAD, int C, bool SELF, bool GG, int NWV>
+__global__ void __launch_bounds__(NWV * 64)
+k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                  float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int TY, int H, int NS,
+                  int clamp_grid, int32_t* __restrict__ ws) {
+  extern __shared__ int acc[];                   // [slot 2H+3][C][TY][64]
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  const int y0 = ty * TY;
+  const int za = tz * zc, zb = min(za + zc, d.s0);
+  const int plane_cells = C * TY * 64;
+  const float* gn = grid + (int64_t)n * 3 * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  const float* inn = in + (int64_t)n * C * V;
+  float* ginn = gin + (int64_t)n * C * V;
+  const float gmax = __int_as_float(ws[2]);
+  const float scale = gmax > 0.f ? kFixScale / gmax : 0.f, inv = gmax * (1.f / kFixScale);
+  for (int i = threadIdx.x; i < NS * plane_cells; i += NWV * 64) acc[i] = 0;
+  if (SELF && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
+  const bool xin = lane < d.s2;
+  const int xl = xin ? lane : 0;
+  const int yend = min(y0 + TY, d.s1);
+
+  constexpr int MAXR = NWV == 8 ? 2 : 3;         // sample rows per wave and step: TY + 2H <= 8 + 8 (8 waves), 4 + 8 (4)
+  constexpr int MAXF = 1;                        // output rows per wave and step: TY <= NWV
+  // requests one step ahead; not for C = 4 on 4 waves: 181 VGPRs, two workgroups a CU, 414 us where 252 is possible
+  constexpr bool PF = C < 4 || NWV == 8;
+  const int nrows = TY + 2 * H;
+  // Everything a step needs from global memory is requested one step ahead (a step at a time the kernel was a chain of
+  // exposed memory round trips: 16 waves a CU do not hide them).
+  auto load_samples = [&](int zp, float (&g)[MAXR][3], float (&go)[MAXR][C]) {
+    const int zq = min(max(zp, 0), d.s0 - 1);
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int r = wave + k * NWV;
+      if (r >= nrows) continue;                                      // wave-uniform
+      const int ys = min(max(y0 - H + r, 0), d.s1 - 1);              // clamped: no per-lane branch around the loads
+      const int s = (zq * d.s1 + ys) * d.s2 + xl;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = gn[(int64_t)a * V + s];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = gon[(int64_t)c * V + s];
+    }
+  };
+  auto load_own = [&](int zt, float (&g)[MAXF][3], float (&go)[MAXF][C]) {
+    if (!(SELF || GG)) return;
+    const int zq = min(max(zt, 0), d.s0 - 1);
+#pragma unroll
+    for (int k = 0; k < MAXF; ++k) {
+      const int uy = min(y0 + wave + k * NWV, d.s1 - 1);
+      const int s = (zq * d.s1 + uy) * d.s2 + xl;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = gn[(int64_t)a * V + s];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = gon[(int64_t)c * V + s];
+    }
+  };
+  float g[MAXR][3], go[MAXR][C], fg[MAXF][3], fgo[MAXF][C];
+  if (PF) {
+    load_samples(za - H, g, go);
+    load_own(za - 2 * H, fg, fgo);
+  }
+  __syncthreads();                               // accumulator planes are zero
+  for (int zp = za - H; zp < zb + H; ++zp) {
+    float g1[PF ? MAXR : 1][3], go1[PF ? MAXR : 1][C], fg1[MAXF][3], fgo1[MAXF][C];
+    if constexpr (PF) {
+      load_samples(zp + 1, g1, go1);
+      load_own(zp + 1 - H, fg1, fgo1);
+    } else {
+      load_samples(zp, g, go);
+      load_own(zp - H, fg, fgo);
+    }
+    // ---- deposits of sample plane zp (rows y0-H .. y0+TY+H-1): only what lands in the owned rows and planes is kept
+    if (zp >= 0 && zp < d.s0) {
+      const int sz = ((zp % NS) + NS) % NS;                          // slot of plane zp (scalar)
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        const int r = wave + k * NWV;
+        const int ys = y0 - H + r;
+        if (r >= nrows || ys < 0 || ys >= d.s1) continue;            // wave-uniform
+        if (clamp_grid) { g[k][0] = clamp_unit(g[k][0]); g[k][1] = clamp_unit(g[k][1]); g[k][2] = clamp_unit(g[k][2]); }
+        Taps<3, PAD> t;
+        t.build(g[k][0], g[k][1], g[k][2], d);
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz) {
+          const int pz = t.z.i0 + cz;
+          const bool okz = pz >= za && pz < zb && pz >= zp - H && pz <= zp + H + 1;
+          int slot = sz + (pz - zp);
+          slot += slot < 0 ? NS : 0;
+          slot -= slot >= NS ? NS : 0;
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const int py = t.y.i0 + cy;
+            const bool oky = py >= y0 && py < yend;
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+              const int pxx = t.x.i0 + cx;
+              if (!(xin && okz && oky && t.ok(cz, cy, cx))) continue;
+              const float wsc = t.w(cz, cy, cx) * scale;
+              int* cell = acc + slot * plane_cells + (py - y0) * 64 + pxx;
+#pragma unroll
+              for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * 64, __float2int_rn(wsc * go[k][c]));
+            }
+          }
+        }
+      }
+    }
+    // ---- coordinate path of the rows this wave finishes below (independent of the accumulator: before the barrier)
+    const int zt = zp - H;
+    const bool fin = zt >= za && zt < zb;
+    float gg[MAXF][3];
+    if (fin && (SELF || GG)) {
+#pragma unroll
+      for (int k = 0; k < MAXF; ++k) {
+        float q[3] = {fg[k][0], fg[k][1], fg[k][2]};
+        bool pass[3] = {true, true, true};
+        if (clamp_grid) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { pass[a] = q[a] >= -1.f && q[a] <= 1.f; q[a] = clamp_unit(q[a]); }
+        }
+        Taps<3, PAD> t;
+        t.build(q[0], q[1], q[2], d);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) sample_linear_bwd<3, PAD, false, true>(inn + (int64_t)c * V, nullptr, fgo[k][c], t, d, ax, ay, az);
+        gg[k][0] = pass[0] ? t.x.mult * ax : 0.f;
+        gg[k][1] = pass[1] ? t.y.mult * ay : 0.f;
+        gg[k][2] = pass[2] ? t.z.mult * az : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- output plane zp-H has seen every sample that can reach it: convert, add / store the coordinate path, store.
+    // With a ring of 2H+3 planes (one more than the reach of a step) the deposits of the NEXT step cannot touch the
+    // plane being emptied here: one barrier per step.  With 2H+2 (when LDS is short) a second one closes the step.
+    if (fin) {
+      const int slot = ((zt % NS) + NS) % NS;
+#pragma unroll
+      for (int k = 0; k < MAXF; ++k) {
+        const int row = wave + k * NWV;
+        const int uy = y0 + row;
+        if (row >= TY || uy >= d.s1) continue;                       // wave-uniform
+        int* cell = acc + slot * plane_cells + row * 64 + lane;
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          v[c] = (float)cell[c * TY * 64] * inv;
+          cell[c * TY * 64] = 0;
+        }
+        const int s = (zt * d.s1 + uy) * d.s2 + xl;
+        if (SELF) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) v[c] += gg[k][c < 3 ? c : 0];
+        } else if (GG && xin) {
+          float* gq = ggrid + (int64_t)n * 3 * V + s;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) gq[(int64_t)a * V] = gg[k][a];
+        }
+        if (xin) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
+        }
+      }
+    }
+    if (NS == 2 * H + 2) __syncthreads();
+    if constexpr (PF) {
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = g1[k][a];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = go1[k][c];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXF; ++k) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) fg[k][a] = fg1[k][a];
+#pragma unroll
+      for (int c = 0; c < C; ++c) fgo[k][c] = fgo1[k][c];
+    }
+    }
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+// Exact bound of H = 2..4 voxels, 3D, rows of at most 64 voxels.  ADVCHAIN_ERR_UNSUPPORTED: use the window scatter.
+int advchain_scatter_march_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                  int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
+                                  hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_SCATTER_MARCH") != nullptr;   // A/B knob
+  static const int hmax = getenv("ADVCHAIN_SCATTER_MARCH_HMAX") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_HMAX")) : 4;   // tuning knob
+  if (off || !workspace || !gin || padding == PAD_REFLECTION || H < 2 || H > hmax || H > 4) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s2 > 64 || d.s2 < 8 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (self ? C != 3 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const int64_t total = N * C * d.voxels();
+  if ((total & 3) != 0 || (reinterpret_cast<uintptr_t>(gout) & 15) != 0) return ADVCHAIN_ERR_UNSUPPORTED;
+  // rows per workgroup: as many as 60 KiB of accumulator planes allow, at most 8
+  static const int ty_forced = getenv("ADVCHAIN_SCATTER_MARCH_TY") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_TY")) : 0;
+  int NS = 2 * H + 3;
+  int TY = 8;    // (16 halves the y halo work but leaves 512 workgroups at 4 x 128 x 128 x 64)
+  if ((size_t)NS * C * TY * 64 * 4 > 65536) NS = 2 * H + 2;
+  while (TY > 4 && (size_t)NS * C * TY * 64 * 4 > 65536) TY >>= 1;
+  if (ty_forced == 4 || ty_forced == 8) TY = ty_forced;
+  const size_t lds = (size_t)NS * C * TY * 64 * sizeof(int);
+  if (lds > 65536) return ADVCHAIN_ERR_UNSUPPORTED;
+  const int n1 = (d.s1 + TY - 1) / TY;
+  static const int zc_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+  int zc = d.s0;
+  while (zc > 8 && N * n1 * ((d.s0 + zc - 1) / zc) < 512) zc = (zc + 1) / 2;   // (16 planes: 1003 GB/s, 8: 942, 32: 834)
+  if (zc_forced > 0) zc = zc_forced;
+  const int n0 = (d.s0 + zc - 1) / zc;
+  hipLaunchKernelGGL(k_march_scatter_prepare, dim3(1), dim3(1), 0, st, workspace);
+  int blocks = (int)((total / 4 + kBlock - 1) / kBlock);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_march_absmax, dim3(blocks), dim3(kBlock), 0, st, gout, total / 4, workspace);
+  const int nwv = TY > 4 ? 8 : 4;
+  dim3 g((unsigned)(n1 * n0), (unsigned)N), b(nwv * 64);
+  const bool gg = ggrid != nullptr;
+#define GO(PAD_, C_, SELF_, GG_) \
+  do { if (nwv == 8) hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 8>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace); \
+  else hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 4>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace); } while (0)
+#define GO_PAD(C_, GG_) do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, false, GG_); else GO(PAD_ZEROS, C_, false, GG_); } while (0)
+  if (self) GO(PAD_BORDER, 3, true, false);
+  else if (C == 1) { if (gg) GO_PAD(1, true); else GO_PAD(1, false); }
+  else { if (gg) GO_PAD(4, true); else GO_PAD(4, false); }
+#undef GO_PAD
+#undef GO
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}

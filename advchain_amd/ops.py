@@ -171,8 +171,8 @@ def squaring_halo(disp, d):
         return 0                 # NaN field: nothing to tune
     if disp < 0.999:
         return -1
-    if d == 3:       # >= 2: source-tiled window scatter (2..4 size the owner-computes tiles when that is switched off)
-        return 2 if disp < 1.999 else (3 if disp < 2.999 else (4 if disp < 3.999 else 8))
+    if d == 3:       # exact bounds of 2..4 voxels: owner-computes march (scatter_march.hip); beyond: window scatter
+        return -2 if disp < 1.999 else (-3 if disp < 2.999 else (-4 if disp < 3.999 else 8))
     if disp < 1.999:
         return -2
     if disp < 3.999:
@@ -310,7 +310,7 @@ def warp_halo(entry, d):
     if not est == est:
         return 0
     if d == 3:
-        return -1 if est < 0.999 else (2 if est < 1.999 else (3 if est < 2.999 else (4 if est < 3.999 else 8)))
+        return -1 if est < 0.999 else (-2 if est < 1.999 else (-3 if est < 2.999 else (-4 if est < 3.999 else 8)))
     if est < 1.999:
         return -2
     if est < 3.999:

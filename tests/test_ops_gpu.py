@@ -351,7 +351,7 @@ def test_demons_field_backward_across_the_gather_threshold(dims, vs, window):
         else:
             hi = mid
     assert scale is not None, (lo, hi)
-    assert ops.squaring_halo(dm, d) == (-1 if window[1] <= 0.9991 else (2 if d == 3 else -2))
+    assert ops.squaring_halo(dm, d) == (-1 if window[1] <= 0.9991 else -2)
     gq = rand((2, d) + tuple(dims), 72)
     pc = vel.clone().requires_grad_(True)
     O.demons_compose(scale * pc, dims, final_clamp=False).backward(gq)
@@ -456,6 +456,54 @@ def test_window_scatter_3d(dims, amp_vox, halo):
             assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max())), (C, pad, clamp)
             gin2, none = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
                                                  True, False, halo)
+            assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32)])
+@pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4)])
+def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
+    """3D sampler backward with an EXACT displacement bound of 2..4 voxels (negative halo): the owner-computes z-march of
+    scatter_march.hip (LDS integer accumulator planes, plain stores, no zero-fill).  Smooth fields whose measured
+    displacement sits below the bound: self-composition (value + coordinate path, then chained owner-computes steps that
+    must find out on the device that no max|grad| was left behind), image warps (C = 1, 4, both paddings, clamped grid,
+    with and without grad_grid) against autograd through F.grid_sample; run-to-run bitwise determinism."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = 3
+    phi = _smooth_field(dims, amp_vox, 61)
+    measured = float(ops.raw_max_displacement(phi.to(DEV)).item())
+    assert bound - 1 <= measured < bound - 0.001, measured
+    assert ops.squaring_halo(measured, 3) == -bound and ops.warp_halo([None, measured, 0, 0], 3) == -bound
+    w = rand((2, d) + dims, 62)
+    p = phi.clone().requires_grad_(True)
+    (O.compose_fields(p, p) * w).sum().backward()
+    pd = phi.to(DEV)
+    ws = ops._scatter_workspace(2, dims, DEV)
+    g1 = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-bound)
+    assert maxdiff(g1.cpu(), p.grad) < 5e-5 * max(1.0, float(p.grad.abs().max()))
+    assert torch.equal(g1, ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-bound))     # deterministic
+    g2 = ops.raw_compose_self_bwd(g1, pd, ws, chain=True, halo=0)          # owner-computes tiles after a march launch
+    p2 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p2, p2) * p.grad).sum().backward()
+    assert maxdiff(g2.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
+    g3 = ops.raw_compose_self_bwd(g2, pd, ws, chain=True, halo=-bound)     # ... and a chained march step after that
+    p3 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p3, p3) * p2.grad).sum().backward()
+    assert maxdiff(g3.cpu(), p3.grad) < 5e-4 * max(1.0, float(p3.grad.abs().max()))
+    for C in (1, 4):
+        for pad, clamp in (("zeros", True), ("zeros", False), ("border", False)):
+            grid = phi.contiguous()
+            inp, wv = rand((2, C) + dims, 63 + C), rand((2, C) + dims, 73 + C)
+            a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+            gp = torch.clamp(g, -1, 1) if clamp else g
+            ref = F.grid_sample(a, gp.permute(0, 2, 3, 4, 1), padding_mode=pad, align_corners=True)
+            (ref * wv).sum().backward()
+            gin, ggrid = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, True, -bound)
+            assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max())), (C, pad, clamp)
+            assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max())), (C, pad, clamp)
+            gin2, none = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, False, -bound)
             assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
