@@ -121,6 +121,13 @@ class AdvMorph(AdvTransformBase):
         if hit is not None and hit[0] is p and hit[1] == p._version and (hit[3] or not want_grad):
             q = hit[2]
             return q if want_grad else q.detach()
+        if ops.PAIR_FIELDS:
+            # a solver step warps forward with field(+s) and back with field(-s): integrate both as one batch
+            s = self._scale()
+            qp, qm = ops.demons_field_pair(p, s, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
+            self._field_cache[(s,)] = (p, p._version, qp, want_grad)
+            self._field_cache[(-s,)] = (p, p._version, qm, want_grad)
+            return self._field_cache[key][2]
         q = ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
         self._field_cache[key] = (p, p._version, q, want_grad)
         return q

@@ -101,6 +101,7 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
 
 DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
 ADAPTIVE_HALO = os.environ.get("ADVCHAIN_NO_ADAPTIVE_HALO") is None   # measure the displacement in forward and size the backward halos from it
+PAIR_FIELDS = os.environ.get("ADVCHAIN_NO_PAIR_FIELDS") is None       # a solver step integrates field(+v) and field(-v) as one batch
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 
 
@@ -532,14 +533,15 @@ class _DemonsField(torch.autograd.Function):
     backward: the hand-written adjoint of the same chain (saved: phi_0..phi_{n-1}, pos)."""
 
     @staticmethod
-    def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq):
+    def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False):
         vel = _dev(vel, "velocity")
         N, d = vel.shape[:2]
         s1 = raw_gauss(vel, d, pre=1, scale=scale)
         n = 8
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
             slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
-            raw_tp_interp(s1, tables, d, want_out=False, sumsq=slots)
+            # pair: the batch is [v; -v] -- the rule is the reference's, over ONE field's batch (both halves agree)
+            raw_tp_interp(s1[:N // 2] if pair else s1, tables, d, want_out=False, sumsq=slots)
             ss = slots.sum().reshape(1)
             if reduce_sumsq is not None:
                 ss = reduce_sumsq(ss)
@@ -589,7 +591,7 @@ class _DemonsField(torch.autograd.Function):
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)
-        return gvel, None, None, None, None
+        return gvel, None, None, None, None, None
 
 
 _LAST_FIELD_BOUND = None
@@ -599,12 +601,31 @@ _LAST_FIELD_BOUND = None
 def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
-    q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq)
+    q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, False)
     if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
         rb, idx = _LAST_FIELD_BOUND
         q._advchain_disp = [rb, None, q._version, idx]
         _LAST_FIELD_BOUND = None
     return q
+
+
+@_on_tensor_device
+def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+    """(field(+scale * vel), field(-scale * vel)): the deformation and its approximate inverse, which one solver step
+    always needs together (adv_morph.py:285-331), integrated as ONE batch [v; -v] -- half the launches, each twice the
+    size (the 2D kernels of a 40-image batch are too small to fill 256 CUs).  Per sample the arithmetic is that of two
+    separate calls: -(s*v) == (-s)*v exactly, so the results are bit-identical to demons_field(vel, +-scale)."""
+    global _LAST_FIELD_BOUND
+    _LAST_FIELD_BOUND = None
+    N = vel.shape[0]
+    q2 = _DemonsField.apply(torch.cat([vel, -vel], 0), float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
+    qp, qm = q2[:N], q2[N:]
+    if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
+        rb, idx = _LAST_FIELD_BOUND
+        qp._advchain_disp = [rb, None, qp._version, idx]
+        qm._advchain_disp = [rb, None, qm._version, idx]
+        _LAST_FIELD_BOUND = None
+    return qp, qm
 
 
 _COEF_CACHE = {}

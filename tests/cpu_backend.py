@@ -87,6 +87,11 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     return O.gaussian_smooth(composed - base) + base
 
 
+def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+    return (demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq),
+            demons_field(vel, -scale, tables, nsteps_rule, reduce_sumsq))
+
+
 def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
     """[S_mse, S_edgeA, S_edgeB] raw sums as the HIP kernels define them (advchain_amd/csrc/loss.hip)."""
     K = pred.shape[1]
@@ -118,7 +123,7 @@ def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
 
 
 PATCHED = ["grid_sample", "affine_warp", "affine_theta", "axpy", "normalized_axpy", "bias_apply", "bias_field_only",
-           "demons_field", "consistency_sums"]
+           "demons_field", "demons_field_pair", "consistency_sums"]
 
 
 def install(monkeypatch):

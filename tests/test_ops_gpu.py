@@ -361,6 +361,32 @@ def test_demons_field_backward_across_the_gather_threshold(dims, vs, window):
     assert err < 1e-4, (dims, window, scale, dm, err)
 
 
+@pytest.mark.parametrize("dims,vs,scale", [((32, 48), [4, 6], 1.5), ((32, 48), [4, 6], 12.0), ((16, 20, 24), [4, 5, 6], 1.0),
+                                           ((16, 20, 24), [4, 5, 6], 9.0)])
+def test_demons_field_pair_is_the_two_single_fields(dims, vs, scale):
+    """ops.demons_field_pair integrates [v; -v] as one batch (what a solver step uses, AdvMorph._field): values are
+    BIT-identical to demons_field(v, +scale) / demons_field(v, -scale) (same per-sample arithmetic, and in 3D the same
+    number of squarings: the step rule looks at one half), gradients agree to rounding (atomics in the large-
+    displacement backward are not ordered)."""
+    from oracle import advchain_oracle as O
+    from advchain_amd import bands
+    ops = _ops()
+    d = len(dims)
+    vel = O.unit_normalize(rand((3, d) + tuple(vs), 91)).to(DEV)
+    tables = bands.upsample_tables(list(vs), list(dims), torch.device(DEV))
+    gp, gm = rand((3, d) + tuple(dims), 92).to(DEV), rand((3, d) + tuple(dims), 93).to(DEV)
+    a = vel.clone().requires_grad_(True)
+    qp, qm = ops.demons_field_pair(a, scale, tables, d == 3)
+    b = vel.clone().requires_grad_(True)
+    sp, sm = ops.demons_field(b, scale, tables, d == 3), ops.demons_field(b, -scale, tables, d == 3)
+    assert torch.equal(qp, sp) and torch.equal(qm, sm)
+    assert qp._advchain_disp[0].values()[qp._advchain_disp[3]] == max(sp._advchain_disp[0].values()[sp._advchain_disp[3]],
+                                                                      sm._advchain_disp[0].values()[sm._advchain_disp[3]])
+    ((qp * gp).sum() + (qm * gm).sum()).backward()
+    ((sp * gp).sum() + (sm * gm).sum()).backward()
+    assert maxdiff(a.grad, b.grad) <= 2e-6 * float(b.grad.abs().max()), (dims, scale)
+
+
 @pytest.mark.parametrize("dims", [(6, 10, 72), (5, 9, 80), (4, 6, 132), (10, 12, 64), (5, 7, 16)])
 @pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
 def test_march_kernels_rows_of_any_length(dims, pad, clamp):
