@@ -400,6 +400,75 @@ k_affine_warp_fwd(const float* __restrict__ in, const float* __restrict__ theta,
   }
 }
 
+// The same map with the voxel coordinates of wave `w` returned directly (32-bit arithmetic: the 64-bit `%` and `/` of
+// affine_position() are ~100 instructions each).
+__device__ __forceinline__ bool mapped_wave_coords(float slope, const Dims& d, unsigned w, int lane, float thr, int& ix, int& iy,
+                                                   int& iz) {
+  const bool patch = 64.f * slope > thr && d.s1 >= kPatch && d.s2 >= kPatch;
+  if (!patch) {
+    const unsigned v = w * 64u + (unsigned)lane;
+    const unsigned r = v / (unsigned)d.s2;
+    ix = (int)(v - r * (unsigned)d.s2);
+    iz = (int)(r / (unsigned)d.s1);
+    iy = (int)(r - (unsigned)iz * (unsigned)d.s1);
+    return v < (unsigned)d.voxels();
+  }
+  const unsigned nx = (unsigned)(d.s2 + kPatch - 1) / kPatch, ny = (unsigned)(d.s1 + kPatch - 1) / kPatch;
+  const unsigned r = w / nx;
+  iz = (int)(r / ny);
+  ix = (int)(w - r * nx) * kPatch + (lane & (kPatch - 1));
+  iy = (int)(r - (unsigned)iz * ny) * kPatch + lane / kPatch;
+  return ix < d.s2 && iy < d.s1 && iz < d.s0;
+}
+
+// Linear forward with CT channels known at compile time and VEC voxels per thread (consecutive waves of the mapping
+// above): every corner load of every channel and voxel of a thread is issued before the first is consumed.  The
+// one-voxel kernel above with its run-time channel loop made 1 (C = 1) to 4 serial round trips of 2^d loads and spent
+// 61% of its wave-cycles waiting (profiles/r02/sq_issue_summary.txt).
+template <int DIM, int PAD, int CT, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_affine_warp_fwd_v(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, Dims d, float thr,
+                    unsigned nwaves) {
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  Theta<DIM> th;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * DIM * (DIM + 1) + r * (DIM + 1) + c];
+  const float den = (float)max(d.s2 - 1, 1);
+  float slope = fabsf(th.m[1][0]) * (float)(d.s1 - 1) / den;
+  if (DIM == 3) slope += fabsf(th.m[DIM - 1][0]) * (float)(d.s0 - 1) / den;
+  const unsigned w0 = ((unsigned)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * VEC;
+  const int lane = threadIdx.x & 63;
+  const float* inn = in + (int64_t)n * CT * V;
+  float* on = out + (int64_t)n * CT * V;
+  Taps<DIM, PAD> t[VEC];
+  int off[VEC];
+  bool ok[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    int ix, iy, iz;
+    ok[k] = w0 + k < nwaves && mapped_wave_coords(slope, d, w0 + k, lane, thr, ix, iy, iz);
+    if (!ok[k]) { ix = iy = iz = 0; }
+    off[k] = (iz * d.s1 + iy) * d.s2 + ix;
+    float bx, by, bz, gx, gy, gz;
+    affine_position_xyz<DIM>(th, ix, iy, iz, d, bx, by, bz, gx, gy, gz);
+    t[k].build(gx, gy, gz, d);
+  }
+  float r[VEC][CT];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) r[k][c] = sample_linear<DIM, PAD>(inn + (int64_t)c * V, t[k], d);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    if (!ok[k]) continue;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) on[(int64_t)c * V + off[k]] = r[k][c];
+  }
+}
+
 // gtheta_partial: (N, gridDim.x, DIM*(DIM+1)) block partial sums, reduced by k_reduce_partials.
 template <int DIM, int INTERP, int PAD, bool NEED_GIN, bool NEED_GTHETA>
 __global__ void __launch_bounds__(kBlock)
@@ -669,6 +738,9 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                    int halo, int32_t* workspace, hipStream_t st);
+int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
+                                   hipStream_t st);
 
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
@@ -805,6 +877,11 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_bwd: per-sample volume too large");
   const bool same = id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2;
   if (workspace && grad_in && same && interp == INTERP_LINEAR && C <= 4) {
+    if (ndim == 2 && halo <= -2) {   // exact bound of a few pixels: whole-row owner-computes scatter (scatter_march.hip)
+      const int rr = advchain_scatter_rows2d_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, id, padding, clamp_grid,
+                                                    -halo, workspace, (hipStream_t)stream);
+      if (rr != ADVCHAIN_ERR_UNSUPPORTED) return rr;
+    }
     // small displacement bound: gather form (adjoint_gather.hip); otherwise the LDS-tiled owner-computes scatter
     const int rc = advchain_warp_adjoint_gather_launch(grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                                        clamp_grid, workspace, halo, (hipStream_t)stream);
@@ -873,6 +950,11 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_bwd: per-sample volume too large");
   if (workspace) {
+    if (ndim == 2 && halo <= -2) {   // exact bound of a few pixels: whole-row owner-computes scatter (scatter_march.hip)
+      const int rr = advchain_scatter_rows2d_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, d, PAD_BORDER, 0, -halo,
+                                                    workspace, (hipStream_t)stream);
+      if (rr != ADVCHAIN_ERR_UNSUPPORTED) return rr;
+    }
     // sub-voxel steps of the squaring chain: gather form (adjoint_gather.hip); otherwise the LDS-tiled scatter
     const int rc = advchain_self_adjoint_gather_launch(grad_out, phi, grad_phi, N, ndim, d, workspace, chain, halo,
                                                        (hipStream_t)stream);
@@ -886,7 +968,7 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
                                                   0, halo, workspace, (hipStream_t)stream);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
-                                         workspace, chain, ndim == 3 && halo < 0 ? -halo : halo, (hipStream_t)stream);
+                                         workspace, chain, halo < 0 ? -halo : halo, (hipStream_t)stream);
   }
   const bool vec4 = use_unroll(V, ndim);
   dim3 g(advchain_blocks(V, kBlock * (vec4 ? 4 : 1)), (unsigned)N), b(kBlock);
@@ -915,6 +997,21 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   dim3 g(affine_grid_blocks(d), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
   static const float thr = getenv("ADVCHAIN_PATCH_THR") ? (float)atof(getenv("ADVCHAIN_PATCH_THR")) : 7.f;   // tuning knob (break-even measured at ~6 degrees)
+  static const bool no_v = getenv("ADVCHAIN_NO_AFFINE_V") != nullptr;   // A/B knob
+  if (interp == INTERP_LINEAR && C <= 4 && !no_v) {
+    const unsigned nw = (unsigned)affine_waves(d);
+#define GO_V(DIM_, CT_, VEC_) do { \
+    dim3 gv((nw + (kBlock / 64) * VEC_ - 1) / ((kBlock / 64) * VEC_), (unsigned)N); \
+    DISPATCH_PAD(padding, { hipLaunchKernelGGL((k_affine_warp_fwd_v<DIM_, PAD, CT_, VEC_>), gv, b, 0, st, in, theta, out, d, thr, nw); }); } while (0)
+    if (ndim == 3) {
+      switch (C) { case 1: GO_V(3, 1, 2); break; case 2: GO_V(3, 2, 2); break; case 3: GO_V(3, 3, 1); break; default: GO_V(3, 4, 1); break; }
+    } else {
+      switch (C) { case 1: GO_V(2, 1, 4); break; case 2: GO_V(2, 2, 2); break; case 3: GO_V(2, 3, 2); break; default: GO_V(2, 4, 2); break; }
+    }
+#undef GO_V
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   DISPATCH_PAD(padding, {
     if (ndim == 3) {
       if (interp == INTERP_LINEAR) hipLaunchKernelGGL((k_affine_warp_fwd<3, INTERP_LINEAR, PAD>), g, b, 0, st, in, theta, out, (int)C, d, thr);

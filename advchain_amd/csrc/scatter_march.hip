@@ -39,9 +39,9 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
   const int V = (int)d.voxels();
   const float* p = x + (int64_t)n * C * V + (int64_t)row * d.s2;
   float m = 0.f;
-  if (lane < d.s2) {
+  for (int x = lane; x < d.s2; x += 64) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) m = fmaxf(m, fabsf(p[(int64_t)c * V + lane]));
+    for (int c = 0; c < C; ++c) m = fmaxf(m, fabsf(p[(int64_t)c * V + x]));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -258,9 +258,191 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 2D: the same owner-computes scatter without a march.  A workgroup owns TY whole rows of one image (an accumulator of
+// C x TY x W 32-bit cells in LDS), visits the sample rows y0-H .. y0+TY+H-1 in 64-lane segments and keeps what lands in
+// its rows; then every output leaves with a plain store, the coordinate path of its own sample added (self-composition)
+// or stored (grad_grid).  Whole rows: the halo work is in y only, (TY+2H)/TY (the 2D tiles of scatter_tiled.hip pay it
+// on both axes and need an overflow list; the window scatter pays 1.7 global float atomics per sample and channel).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rows2d_fix_scale(int H) {   // (2H+2)^2 deposits of weight <= 1 stay below 2^31
+  return H <= 2 ? 33554432.f : (H <= 4 ? 16777216.f : (H <= 8 ? 4194304.f : 1048576.f));
+}
+
+template <int PAD, int C, bool SELF, bool GG>
+__global__ void __launch_bounds__(512)
+k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                 float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int TY, int H, int clamp_grid,
+                 int32_t* __restrict__ ws) {
+  extern __shared__ int acc[];                   // [C][TY][W]
+  constexpr int NWV = 8;
+  const int W = d.s2, V = d.s1 * d.s2;
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = blockIdx.x * TY, yend = min(y0 + TY, d.s1);
+  const int nseg = (W + 63) >> 6;
+  const float* gn = grid + (int64_t)n * 2 * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  const float* inn = in + (int64_t)n * C * V;
+  float* ginn = gin + (int64_t)n * C * V;
+  const int ya = max(y0 - H, 0), yb = min(y0 + TY + H, d.s1);
+  __shared__ float wmax[NWV];
+  {
+    const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s1;
+    float m = 0.f;
+    for (int y = ya + (int)threadIdx.x; y < yb; y += NWV * 64) m = fmaxf(m, rowmax[y]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) wmax[wave] = m;
+  }
+  for (int i = threadIdx.x; i < C * TY * W; i += NWV * 64) acc[i] = 0;
+  if (SELF && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
+  __syncthreads();
+  float gmax = wmax[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) gmax = fmaxf(gmax, wmax[w]);
+  const float fix = rows2d_fix_scale(H);
+  const float scale = gmax > 0.f ? fix / gmax : 0.f, inv = gmax / fix;
+
+  // ---- deposits: (row, segment) items, two per wave and round with their loads issued together
+  constexpr int U = 2;
+  const int items = (yb - ya) * nseg;
+  for (int it0 = wave * U; it0 < items; it0 += NWV * U) {
+    float g[U][2], go[U][C];
+    int xs[U], ys[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = min(it0 + u, items - 1);
+      const int r = it / nseg;
+      ys[u] = ya + r;
+      xs[u] = (it - r * nseg) * 64 + lane;
+      const int s = ys[u] * W + min(xs[u], W - 1);
+      g[u][0] = gn[s];
+      g[u][1] = gn[V + s];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[u][c] = gon[(int64_t)c * V + s];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (it0 + u >= items) continue;                                 // wave-uniform
+      const bool xin = xs[u] < W;
+      if (clamp_grid) { g[u][0] = clamp_unit(g[u][0]); g[u][1] = clamp_unit(g[u][1]); }
+      Taps<2, PAD> t;
+      t.y = make_tap<PAD>(g[u][1], d.s1);
+      if (__ballot(xin && t.y.i0 + 1 >= y0 && t.y.i0 < yend) == 0) continue;
+      t.x = make_tap<PAD>(g[u][0], d.s2);
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
+        const int py = t.y.i0 + cy;
+        const bool oky = xin && py >= y0 && py < yend && (cy ? t.y.v1 : t.y.v0);
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          if (!(oky && (cx ? t.x.v1 : t.x.v0))) continue;
+          const float wsc = (cx ? t.x.w1 : t.x.w0) * (cy ? t.y.w1 : t.y.w0) * scale;
+          int* cell = acc + (py - y0) * W + t.x.i0 + cx;
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, __float2int_rn(wsc * go[u][c]));
+        }
+      }
+    }
+  }
+  // ---- the coordinate path of the own samples needs nothing from the accumulator: before the barrier
+  const int oitems = (yend - y0) * nseg;
+  constexpr int MAXO = 8;                         // own items per wave: TY * nseg / 8 <= 32 * 4 / 8... capped by the launcher
+  float ggv[MAXO][2];
+  if (SELF || GG) {
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+      const int it = wave + k * NWV;
+      ggv[k][0] = ggv[k][1] = 0.f;
+      if (it >= oitems) continue;                                     // wave-uniform
+      const int r = it / nseg;
+      const int x = (it - r * nseg) * 64 + lane;
+      const int s = (y0 + r) * W + min(x, W - 1);
+      float q[2] = {gn[s], gn[V + s]};
+      float o[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) o[c] = gon[(int64_t)c * V + s];
+      bool pass[2] = {true, true};
+      if (clamp_grid) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { pass[a] = q[a] >= -1.f && q[a] <= 1.f; q[a] = clamp_unit(q[a]); }
+      }
+      Taps<2, PAD> t;
+      t.build(q[0], q[1], 0.f, d);
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) sample_linear_bwd<2, PAD, false, true>(inn + (int64_t)c * V, nullptr, o[c], t, d, ax, ay, az);
+      ggv[k][0] = pass[0] ? t.x.mult * ax : 0.f;
+      ggv[k][1] = pass[1] ? t.y.mult * ay : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- every owned output: convert, add / store the coordinate path, plain stores
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) {
+    const int it = wave + k * NWV;
+    if (it >= oitems) continue;                                       // wave-uniform
+    const int r = it / nseg;
+    const int x = (it - r * nseg) * 64 + lane;
+    if (x >= W) continue;
+    const int s = (y0 + r) * W + x;
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = (float)acc[(c * TY + r) * W + x] * inv;
+    if (SELF) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) v[c] += ggv[k][c < 2 ? c : 0];
+    } else if (GG) {
+      float* gq = ggrid + (int64_t)n * 2 * V + s;
+      gq[0] = ggv[k][0];
+      gq[V] = ggv[k][1];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
+
+// 2D, exact bound of H = 2..16 pixels.  ADVCHAIN_ERR_UNSUPPORTED: use the gather form / the window scatter.
+int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
+                                   hipStream_t st) {
+  static const bool off = getenv("ADVCHAIN_NO_SCATTER_ROWS2D") != nullptr;   // A/B knob
+  static const int hmin = getenv("ADVCHAIN_SCATTER_ROWS2D_HMIN") ? atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_HMIN")) : 3;   // tuning knob
+  if (off || !workspace || !gin || padding == PAD_REFLECTION || H < hmin || H > 16 || d.s0 != 1) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s2 < 16 || d.s2 > 512 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (self ? C != 2 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
+  static const int ty_forced = getenv("ADVCHAIN_SCATTER_ROWS2D_TY") ? atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_TY")) : 0;
+  const int nseg = (d.s2 + 63) / 64;
+  int TY = H >= 8 ? 32 : 16;
+  if (ty_forced > 0) TY = ty_forced;
+  while (TY > 4 && ((size_t)C * TY * d.s2 * 4 > 49152 || TY * nseg > 64)) TY >>= 1;   // 48 KiB of cells, 8 own items a wave
+  const size_t lds = (size_t)C * TY * d.s2 * sizeof(int);
+  if (lds > 65536 - 64 || TY * nseg > 64) return ADVCHAIN_ERR_UNSUPPORTED;
+  {
+    dim3 rg((unsigned)((d.s1 + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)N);
+    float* rowmax = reinterpret_cast<float*>(workspace + 4);       // the overflow list of the tiled kernels: unused here
+    if (C == 1) hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
+    else if (C == 2) hipLaunchKernelGGL(k_march_rowmax<2>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
+    else hipLaunchKernelGGL(k_march_rowmax<4>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
+  }
+  dim3 g((unsigned)((d.s1 + TY - 1) / TY), (unsigned)N), b(512);
+  const bool gg = ggrid != nullptr;
+#define GO(PAD_, C_, SELF_, GG_) \
+  hipLaunchKernelGGL((k_scatter_rows2d<PAD_, C_, SELF_, GG_>), g, b, lds, st, gout, in, grid, gin, ggrid, d, TY, H, clamp_grid, workspace)
+#define GO_PAD(C_, GG_) do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, false, GG_); else GO(PAD_ZEROS, C_, false, GG_); } while (0)
+  if (self) GO(PAD_BORDER, 2, true, false);
+  else if (C == 1) { if (gg) GO_PAD(1, true); else GO_PAD(1, false); }
+  else { if (gg) GO_PAD(4, true); else GO_PAD(4, false); }
+#undef GO_PAD
+#undef GO
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
 
 // Exact bound of H = 2..4 voxels, 3D, rows of at most 64 voxels.  ADVCHAIN_ERR_UNSUPPORTED: use the window scatter.
 int advchain_scatter_march_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,

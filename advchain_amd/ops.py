@@ -174,11 +174,16 @@ def squaring_halo(disp, d):
         return -1
     if d == 3:       # exact bounds of 2..4 voxels: owner-computes march (scatter_march.hip); beyond: window scatter
         return -2 if disp < 1.999 else (-3 if disp < 2.999 else (-4 if disp < 3.999 else 8))
-    if disp < 1.999:
-        return -2
-    if disp < 3.999:
-        return -4
-    return 8 if disp < 7.0 else 16   # beyond 16 voxels the overflow list is cheaper than a wider halo
+    return _halo_2d(disp)
+
+
+def _halo_2d(disp):
+    """2D: exact bounds of 2 (gather form) and 4 / 8 / 16 pixels (whole-row owner-computes scatter); beyond: a hint for
+    the window scatter."""
+    for h in (2, 4, 8, 16):
+        if disp < h - 0.001:
+            return -h
+    return 16
 
 
 def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
@@ -312,11 +317,7 @@ def warp_halo(entry, d):
         return 0
     if d == 3:
         return -1 if est < 0.999 else (-2 if est < 1.999 else (-3 if est < 2.999 else (-4 if est < 3.999 else 8)))
-    if est < 1.999:
-        return -2
-    if est < 3.999:
-        return -4
-    return 8 if est < 7.0 else 16
+    return _halo_2d(est)
 
 
 class _GridSample(torch.autograd.Function):

@@ -226,9 +226,10 @@ def test_grid_sample_bwd_gather_form(dims, C, pad, clamp, amp):
         assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
         if float(ops.raw_max_displacement(grid.to(DEV)).item()) < halo:   # bound holds: the exact (single-launch) form agrees
             gin3, ggrid3 = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, True, -halo)
-            if d == 2:
+            if d == 2 and halo == 2:
                 assert torch.equal(gin3, gin) and torch.equal(ggrid3, ggrid)
-            else:      # 3D exact bound: the z-marching kernel (adjoint_march.hip) sums in another order
+            else:      # 3D exact bound: the z-marching kernel (adjoint_march.hip) sums in another order; 2D exact bound
+                #        of 4 px: the whole-row owner-computes scatter (k_scatter_rows2d), fixed point
                 assert maxdiff(gin3.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
                 assert maxdiff(ggrid3.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max()))
             gin4, none4 = ops.raw_grid_sample_bwd(w.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp, True, False, -halo)
@@ -359,6 +360,50 @@ def test_demons_field_backward_across_the_gather_threshold(dims, vs, window):
     ops.demons_field(pg, scale, tables, d == 3).backward(gq.to(DEV))
     err = maxdiff(pg.grad.cpu(), pc.grad) / float(pc.grad.abs().max())
     assert err < 1e-4, (dims, window, scale, dm, err)
+
+
+@pytest.mark.parametrize("dims", [(24, 40), (50, 192), (37, 100), (70, 256), (33, 300)])
+@pytest.mark.parametrize("amp_px,bound", [(3.3, 4), (6.5, 8), (13.0, 16)])
+def test_scatter_rows_2d_exact_bounds(dims, amp_px, bound):
+    """2D sampler backward with an EXACT displacement bound of 4 / 8 / 16 pixels (negative halo): the whole-row
+    owner-computes scatter (k_scatter_rows2d: LDS integer accumulator of TY x W cells, plain stores, no zero-fill), on
+    rows of one to five 64-lane segments.  Self-composition (value + coordinate path, then a chained step that must find
+    out on the device that no max|grad| was left behind) and image warps (C = 1, 4, both paddings, clamped grid, with and
+    without grad_grid) against autograd through F.grid_sample; run-to-run bitwise determinism."""
+    from oracle import advchain_oracle as O
+    ops = _ops()
+    d = 2
+    phi = _smooth_field(dims, amp_px, 61)
+    measured = float(ops.raw_max_displacement(phi.to(DEV)).item())
+    assert bound / 2 <= measured < bound - 0.001, measured
+    assert ops.squaring_halo(measured, 2) == -bound and ops.warp_halo([None, measured, 0, 0], 2) == -bound
+    w = rand((2, d) + dims, 62)
+    p = phi.clone().requires_grad_(True)
+    (O.compose_fields(p, p) * w).sum().backward()
+    pd = phi.to(DEV)
+    ws = ops._scatter_workspace(2, dims, DEV)
+    g1 = ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-bound)
+    assert maxdiff(g1.cpu(), p.grad) < 5e-5 * max(1.0, float(p.grad.abs().max()))
+    assert torch.equal(g1, ops.raw_compose_self_bwd(w.to(DEV), pd, ws, chain=False, halo=-bound))     # deterministic
+    g2 = ops.raw_compose_self_bwd(g1, pd, ws, chain=True, halo=0)          # owner-computes tiles after a rows launch
+    p2 = phi.clone().requires_grad_(True)
+    (O.compose_fields(p2, p2) * p.grad).sum().backward()
+    assert maxdiff(g2.cpu(), p2.grad) < 2e-4 * max(1.0, float(p2.grad.abs().max()))
+    for C in (1, 4):
+        for pad, clamp in (("zeros", True), ("zeros", False), ("border", False)):
+            grid = phi.contiguous()
+            inp, wv = rand((2, C) + dims, 63 + C), rand((2, C) + dims, 73 + C)
+            a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+            gp = torch.clamp(g, -1, 1) if clamp else g
+            ref = F.grid_sample(a, gp.permute(0, 2, 3, 1), padding_mode=pad, align_corners=True)
+            (ref * wv).sum().backward()
+            gin, ggrid = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, True, -bound)
+            assert maxdiff(gin.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max())), (C, pad, clamp)
+            assert maxdiff(ggrid.cpu(), g.grad) < 5e-5 * max(1.0, float(g.grad.abs().max())), (C, pad, clamp)
+            gin2, none = ops.raw_grid_sample_bwd(wv.to(DEV), inp.to(DEV), grid.to(DEV), 0, ops.pad_code(pad), clamp,
+                                                 True, False, -bound)
+            assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
 @pytest.mark.parametrize("dims,vs,scale", [((32, 48), [4, 6], 1.5), ((32, 48), [4, 6], 12.0), ((16, 20, 24), [4, 5, 6], 1.0),
