@@ -118,12 +118,19 @@ template <int PAD, int C, bool SELF, bool GG, int NWV>
 __global__ void __launch_bounds__(NWV * 64)
 k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int TY, int H, int NS,
-                  int clamp_grid, int32_t* __restrict__ ws) {
+                  int clamp_grid, int32_t* __restrict__ ws, int nseg) {
   extern __shared__ int acc[];                   // [slot 2H+3][C][TY][64]
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  // rows longer than 64 voxels: x segments of 64 - 2H owned lanes with H halo lanes either side (a sample in a halo lane
+  // is visited by both neighbours; each keeps what lands in its own columns)
+  int rem = blockIdx.x;
+  const int seg = rem % nseg;
+  rem /= nseg;
+  const int ty = rem % n1, tz = rem / n1;
+  const int xbase = nseg > 1 ? seg * (64 - 2 * H) - H : 0;                      // x of lane 0
+  const int xo0 = nseg > 1 ? xbase + H : 0, xo1 = nseg > 1 ? min(xbase + 64 - H, d.s2) : d.s2;   // owned columns
   const int y0 = ty * TY;
   const int za = tz * zc, zb = min(za + zc, d.s0);
   const int plane_cells = C * TY * 64;
@@ -151,8 +158,9 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
   const float fix = march_fix_scale(H);
   const float scale = gmax > 0.f ? fix / gmax : 0.f, inv = gmax / fix;
   if (SELF && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
-  const bool xin = lane < d.s2;
-  const int xl = xin ? lane : 0;
+  const int xs = xbase + lane;
+  const bool xin = xs >= 0 && xs < d.s2, xown = xs >= xo0 && xs < xo1;
+  const int xl = min(max(xs, 0), d.s2 - 1);
   const int yend = min(y0 + TY, d.s1);
 
   constexpr int MAXR = NWV == 8 ? 2 : 3;         // sample rows per wave and step: TY + 2H <= 8 + 8 (8 waves), 4 + 8 (4)
@@ -234,9 +242,9 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx) {
               const int pxx = t.x.i0 + cx;
-              if (!(xin && okz && oky && t.ok(cz, cy, cx))) continue;
+              if (!(xin && okz && oky && t.ok(cz, cy, cx) && pxx >= xo0 && pxx < xo1)) continue;
               const float wsc = t.w(cz, cy, cx) * scale;
-              int* cell = acc + slot * plane_cells + (py - y0) * 64 + pxx;
+              int* cell = acc + slot * plane_cells + (py - y0) * 64 + (pxx - xbase);
 #pragma unroll
               for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * 64, __float2int_rn(wsc * go[k][c]));
             }
@@ -289,12 +297,12 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         if (SELF) {
 #pragma unroll
           for (int c = 0; c < C; ++c) v[c] += gg[k][c < 3 ? c : 0];
-        } else if (GG && xin) {
+        } else if (GG && xown) {
           float* gq = ggrid + (int64_t)n * 3 * V + s;
 #pragma unroll
           for (int a = 0; a < 3; ++a) gq[(int64_t)a * V] = gg[k][a];
         }
-        if (xin) {
+        if (xown) {
 #pragma unroll
           for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
         }
@@ -513,7 +521,8 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_MARCH") != nullptr;   // A/B knob
   static const int hmax = getenv("ADVCHAIN_SCATTER_MARCH_HMAX") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_HMAX")) : 4;   // tuning knob
   if (off || !workspace || !gin || padding == PAD_REFLECTION || H < 2 || H > hmax || H > 4) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (d.s2 > 64 || d.s2 < 8 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s2 > 1024 || d.s2 < 8 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const int nseg = d.s2 <= 64 ? 1 : (int)((d.s2 + (64 - 2 * H) - 1) / (64 - 2 * H));
   if (self ? C != 3 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
   // rows per workgroup: as many as 60 KiB of accumulator planes allow, at most 8
   static const int ty_forced = getenv("ADVCHAIN_SCATTER_MARCH_TY") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_TY")) : 0;
@@ -527,7 +536,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
   const int n1 = (d.s1 + TY - 1) / TY;
   static const int zc_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
   int zc = d.s0;
-  while (zc > 8 && N * n1 * ((d.s0 + zc - 1) / zc) < 512) zc = (zc + 1) / 2;   // (16 planes: 1003 GB/s, 8: 942, 32: 834)
+  while (zc > 8 && N * n1 * nseg * ((d.s0 + zc - 1) / zc) < 512) zc = (zc + 1) / 2;   // (16 planes: 1003 GB/s, 8: 942, 32: 834)
   if (zc_forced > 0) zc = zc_forced;
   const int n0 = (d.s0 + zc - 1) / zc;
   {
@@ -539,11 +548,11 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     else hipLaunchKernelGGL(k_march_rowmax<4>, rg, dim3(kBlock), 0, st, gout, rowmax, d, rows);
   }
   const int nwv = TY > 4 ? 8 : 4;
-  dim3 g((unsigned)(n1 * n0), (unsigned)N), b(nwv * 64);
+  dim3 g((unsigned)(n1 * n0 * nseg), (unsigned)N), b(nwv * 64);
   const bool gg = ggrid != nullptr;
 #define GO(PAD_, C_, SELF_, GG_) \
-  do { if (nwv == 8) hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 8>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace); \
-  else hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 4>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace); } while (0)
+  do { if (nwv == 8) hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 8>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg); \
+  else hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 4>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg); } while (0)
 #define GO_PAD(C_, GG_) do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, false, GG_); else GO(PAD_ZEROS, C_, false, GG_); } while (0)
   if (self) GO(PAD_BORDER, 3, true, false);
   else if (C == 1) { if (gg) GO_PAD(1, true); else GO_PAD(1, false); }

@@ -530,11 +530,12 @@ def test_window_scatter_3d(dims, amp_vox, halo):
             assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
-@pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32)])
+@pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32), (10, 12, 80), (9, 10, 132)])
 @pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4)])
 def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
     """3D sampler backward with an EXACT displacement bound of 2..4 voxels (negative halo): the owner-computes z-march of
-    scatter_march.hip (LDS integer accumulator planes, plain stores, no zero-fill).  Smooth fields whose measured
+    scatter_march.hip (LDS integer accumulator planes, plain stores, no zero-fill; rows longer than 64 voxels in x
+    segments of 64 - 2H owned lanes).  Smooth fields whose measured
     displacement sits below the bound: self-composition (value + coordinate path, then chained owner-computes steps that
     must find out on the device that no max|grad| was left behind), image warps (C = 1, 4, both paddings, clamped grid,
     with and without grad_grid) against autograd through F.grid_sample; run-to-run bitwise determinism."""
