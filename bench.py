@@ -355,8 +355,10 @@ def grid_sample3d_roofline(device, reps=20):
 
 
 def _bwd_form(halo):
+    if halo == -1:
+        return "gather-form adjoint (z-march), exact bound 1 voxel, one launch"
     if halo < 0:
-        return "gather-form adjoint, exact bound %d voxel(s), one launch" % -halo
+        return "owner-computes z-march scatter (LDS int32 accumulators), exact bound %d voxels, row-maxima pre-pass + one launch" % -halo
     return "scatter (displacement hint %d voxels)" % halo
 
 
@@ -506,7 +508,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rec["workload"], "global_batch": rec["global_batch"],
                        "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
-                       "model": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},
+                       "segmentation_net": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},
             "roofline": roof,
             "kernel_time_ms_first_step": breakdown,
         }

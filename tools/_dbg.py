@@ -1,18 +1,26 @@
-import io, contextlib, sys
-sys.path.insert(0,'.')
-import torch
-from tests.helpers import Fixture, counted_torch_seed, maxdiff
-from tests.test_solver_gpu import make_solver, _kwargs, G6_CASES, DEV
-for case in G6_CASES:
-    fx = Fixture("g6_" + case)
-    solver, chain, meta, model = make_solver(fx)
-    with contextlib.redirect_stdout(io.StringIO()), counted_torch_seed(1000):
-        loss = solver.adversarial_training(data=fx.t("data", DEV), model=model, **_kwargs(fx, meta))
-    ref = fx.f("final_loss")
-    errs = dict(loss_rel=abs(float(loss)-ref)/abs(ref), adv=maxdiff(solver.adv_data.cpu(), fx.t("adv_data")),
-                wb=maxdiff(solver.warped_back_adv_output.cpu(), fx.t("warped_back")))
-    ps=[]
-    for i, t in enumerate(solver.chain_of_transforms[:len(chain)]):
-        rp = fx.t("final_param_%d" % i)
-        ps.append(maxdiff(t.param.cpu(), rp)/max(1.0, float(rp.abs().max())))
-    print("%-22s n=%d loss_rel %.1e adv %.1e wb %.1e params %s" % (case, meta["train"]["n_iter"], errs['loss_rel'], errs['adv'], errs['wb'], ["%.1e"%p for p in ps]))
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from advchain_amd import ops
+from oracle import advchain_oracle as O
+torch.manual_seed(0)
+dev = "cuda"
+dims = (40, 36, 48); N = 2; d = 3
+for amp in (1.6, 3.6):
+    low = torch.rand(N, d, 5, 5, 6) * 2 - 1
+    up = F.interpolate(low, size=dims, mode="trilinear", align_corners=True); up = up / up.abs().max()
+    sc = torch.tensor([2.0 * amp / (dims[d - 1 - a] - 1) for a in range(d)]).view(1, d, 1, 1, 1)
+    phi = (O.identity_grid(N, dims) + up * sc).contiguous()
+    for name, w in (("uniform", torch.rand(N, d, *dims)), ("heavy", torch.randn(N, d, *dims) ** 5)):
+        p = phi.double().clone().requires_grad_(True)
+        perm = (0, 2, 3, 4, 1)
+        out = F.grid_sample(p, p.permute(*perm), padding_mode="border", align_corners=True)
+        (out * w.double()).sum().backward()
+        ref = p.grad
+        ws = ops._scatter_workspace(N, dims, dev)
+        H = int(amp + 1)
+        for nm, halo in (("march", -H), ("window", 8)):
+            g = ops.raw_compose_self_bwd(w.to(dev), phi.to(dev), ws, False, halo).cpu().double()
+            e = (g - ref).abs()
+            print("amp %.1f gout %-7s %-6s max err / max|ref| %.2e   rel L2 %.2e   median rel err %.2e" % (
+                amp, name, nm, e.max() / ref.abs().max(), (e.pow(2).sum() / ref.pow(2).sum()).sqrt(), (e / ref.abs().clamp_min(1e-30)).median()))

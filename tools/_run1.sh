@@ -1,8 +1,5 @@
-python -m pytest tests/test_ops_gpu.py tests/test_solver_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x 2>&1 | tail -4 > gpurun_out/r02_t1.log
-rm -f gpurun_out/r02_kb1.log
-for v in "" "ADVCHAIN_STREAM2D_YC=8" "ADVCHAIN_STREAM2D_YC=32" "ADVCHAIN_NO_STREAM2D=1"; do
-  echo "== $v" >> gpurun_out/r02_kb1.log
-  env $v python tools/kernel_bench.py --shape 2d --only "compose_self bwd" 2>/dev/null | grep -E "compose_self" >> gpurun_out/r02_kb1.log
+export TMPDIR=/tmp; cd /tmp
+for w in cfg5; do
+rm -rf /tmp/rp1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp1 -o c2 -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --only-workload > /tmp/b_$w.log 2>&1
+python $GRAFT_REPO_ROOT/tools/stats_per_call.py $(find /tmp/rp1 -name "c2_kernel_stats.csv" | head -1) 4 12
 done
-python bench.py --only-workload 2>/dev/null | tail -1 | cut -c1-330 >> gpurun_out/r02_kb1.log
-cat gpurun_out/r02_t1.log gpurun_out/r02_kb1.log

@@ -1,10 +1,12 @@
-mkdir -p gpurun_out/r02c
-python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/r02c/pytest_gpu.log
-python bench.py > gpurun_out/r02c/bench_cfg2_default.json 2> gpurun_out/r02c/bench_cfg2_default.err
-python bench.py --workload cfg1 --steps 50 --warmup 5 --only-workload > gpurun_out/r02c/bench_cfg1.json 2>/dev/null
-bash tools/profile_bench.sh r02c > gpurun_out/r02c/per_call_summary.txt 2>&1
-python tools/kernel_bench.py --shape 3d > gpurun_out/r02c/kernel_bench_3d.log 2>/dev/null
-python tools/kernel_bench.py --shape 2d > gpurun_out/r02c/kernel_bench_2d.log 2>/dev/null
-bash tools/profile_pmc.sh r02c > gpurun_out/r02c/pmc.log 2>&1
-python tools/traffic_from_pmc.py gpurun_out/r02c gpurun_out/r02c/traffic.json > gpurun_out/r02c/traffic_summary.txt 2>&1
-tail -3 gpurun_out/r02c/pytest_gpu.log; tail -3 gpurun_out/r02c/traffic_summary.txt
+export TMPDIR=/tmp; repo=$GRAFT_REPO_ROOT; cd /tmp
+pass() { # name, counters...
+  local name=$1; shift
+  rm -rf /tmp/pm_$name
+  timeout 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pm_$name -o kb -- python $repo/tools/kernel_bench.py --shape 3d --reps 3 --only "fwd C=" > /tmp/pm_$name.log 2>&1
+  echo "pass $name rc $?"
+  python $repo/tools/pmc_summary.py /tmp/pm_$name $repo/gpurun_out/aff_$name.csv
+}
+pass d SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_WAVES SQ_BUSY_CYCLES
+pass c TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
+pass b TCP_PENDING_STALL_CYCLES_sum TCP_TAGRAM0_REQ_sum TCP_TA_TCP_STATE_READ_sum
+cat $repo/gpurun_out/aff_d.csv $repo/gpurun_out/aff_c.csv $repo/gpurun_out/aff_b.csv | grep -E "affine_warp_fwd|k_sample_march<1|k_sample_march<4|grid_sample_fwd" | cut -c1-200

@@ -11,7 +11,7 @@ cd /tmp
 run() {  # name, command...
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
   cp "$(find /tmp/rp_$name -name "${name}_kernel_stats.csv" | head -1)" "$out/${name}_kernel_stats.csv"
 }
 run cfg2 python $repo/bench.py --steps 10 --warmup 3 --only-workload

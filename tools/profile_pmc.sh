@@ -12,7 +12,7 @@ run() {  # counter, name, command...
   local ctr=$1 name=$2; shift 2
   local lc=$(echo $ctr | tr 'A-Z' 'a-z')
   rm -rf /tmp/pmc_${lc}_$name
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${lc}_$name -o $name -- "$@" > /tmp/pmc_${lc}_$name.log 2>&1
+  timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${lc}_$name -o $name -- "$@" > /tmp/pmc_${lc}_$name.log 2>&1
   python $repo/tools/pmc_summary.py /tmp/pmc_${lc}_$name "$out/pmc_${lc}_$name.csv"
 }
 python $repo/tools/north_star_pair.py --make-fields /tmp/ns_fields.pt > /tmp/ns_make.log 2>&1     # not profiled

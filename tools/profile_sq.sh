@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 for shape in 3d 2d; do
   rm -rf /tmp/pmc_sq_$shape
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM \
+  timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM \
       --kernel-trace --output-format csv -d /tmp/pmc_sq_$shape -o kb -- python $repo/tools/kernel_bench.py --shape $shape --reps 3 > /tmp/pmc_sq_$shape.log 2>&1
   python $repo/tools/pmc_summary.py /tmp/pmc_sq_$shape "$out/pmc_sq_kb$shape.csv"
 done

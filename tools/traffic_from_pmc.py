@@ -47,6 +47,13 @@ ENTRIES["advchain_grid_sample_bwd"] = ([p for p in ENTRIES["advchain_grid_sample
 ENTRIES["advchain_compose_self_bwd"] = ([p for p in ENTRIES["advchain_compose_self_bwd"][0] if p != r"k_adjoint_march<"] +
                                         [r"k_adjoint_march<3, true"],
                                         ENTRIES["advchain_compose_self_bwd"][1].replace(r"|k_adjoint_march<", r"|k_adjoint_march<3, true"))
+# round-2 owner-computes scatters (scatter_march.hip): 3D z-march, 2D whole rows, and their row-maxima pre-pass
+for _e, _self in (("advchain_grid_sample_bwd", "false"), ("advchain_compose_self_bwd", "true")):
+    _p = [r"k_scatter_march3d<\d, \d, %s" % _self, r"k_scatter_rows2d<\d, \d, %s" % _self]
+    ENTRIES[_e] = (ENTRIES[_e][0] + _p, ENTRIES[_e][1] + "|" + "|".join(_p))
+ENTRIES["advchain_grid_sample_bwd"][0].append(r"k_march_rowmax<[14]>")
+ENTRIES["advchain_compose_self_bwd"][0].append(r"k_march_rowmax<[23]>")
+ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd"], r"k_affine_warp_fwd")
 WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_max_displacement|"
                   r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4")   # 16 B / lane
 MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
