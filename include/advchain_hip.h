@@ -91,8 +91,12 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * 0 = default scatter tiles (halo 2 in 3D) / window scatter (2D).
  * halo < 0: |halo| is EXACT -- the caller guarantees no sample moves |halo| voxels or more on any axis (measured with
  * advchain_max_displacement / disp_out): the gather form then skips the overflow list and is a single launch; samples
- * violating the guarantee would be dropped.  (Launches that do not track max|result| -- strict gather, window scatter --
- * leave a marker in the workspace, and a chained scatter call after them recomputes max|grad_out| on the device.) */
+ * violating the guarantee would be dropped.  Exact bounds beyond the gather form (3D: 2..4 voxels; 2D: 4, 8, 16 px; both
+ * entries) select the owner-computes scatters of scatter_march.hip: LDS 32-bit fixed-point accumulators scaled by the
+ * max|grad_out| over the rows a workgroup visits, plain stores, no zero fill, bit-reproducible, relative error of the
+ * accumulation <= 2^-21 of that local maximum per deposit.  (Launches that do not track max|result| -- strict gather,
+ * window scatter, owner-computes scatters -- leave a marker in the workspace, and a chained scatter call after them
+ * recomputes max|grad_out| on the device.) */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
                               int halo, int64_t N, int ndim, const int64_t* dims, void* stream);
 /* max over samples and axes of |sampling position - own voxel| of the field phi, in voxels: the displacement
