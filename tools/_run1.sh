@@ -1,5 +1,4 @@
-export TMPDIR=/tmp; cd /tmp
-for w in cfg5; do
-rm -rf /tmp/rp1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp1 -o c2 -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --only-workload > /tmp/b_$w.log 2>&1
-python $GRAFT_REPO_ROOT/tools/stats_per_call.py $(find /tmp/rp1 -name "c2_kernel_stats.csv" | head -1) 4 12
-done
+python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "affine" 2>&1 | tail -2
+for rot in 0 15; do for v in "" "ADVCHAIN_NO_AFFINE_ZG=1"; do echo "rot $rot $v"
+KB_ROT=$rot env $v python tools/kernel_bench.py --shape 3d --only "affine_warp fwd C=4" 2>/dev/null | grep affine
+done; done
