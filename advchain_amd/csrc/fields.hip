@@ -467,8 +467,20 @@ __global__ void __launch_bounds__(kBlock)
 k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, int64_t total4,
                 Dims d, int C, GaussW gw, float scale, int row_in_wave) {
   const int64_t t4 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t4 >= total4) return;
-  const int64_t t = t4 * 4;
+  int64_t t;
+  if (AXIS == 2 && row_in_wave == 2) {
+    // rows of S2/4 lanes that do not divide a wave (80 voxels = 20 lanes): floor(64 / lanes) whole rows per wave, the
+    // tail lanes idle -- the DPP form below needs every row inside one wave
+    const int q = d.s2 >> 2, rpw = 64 / q;
+    const int lane = (int)(t4 & 63);
+    const int rl = lane / q;
+    const int64_t row = (t4 >> 6) * rpw + rl;
+    if (rl >= rpw || row >= total4 / q) return;
+    t = row * d.s2 + (lane - rl * q) * 4;
+  } else {
+    if (t4 >= total4) return;
+    t = t4 * 4;
+  }
   const int V = (int)d.voxels();
   const int plane = (int)(t / V);
   const int v = (int)(t - (int64_t)plane * V);
@@ -566,6 +578,91 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
     }
   }
   *reinterpret_cast<float4*>(out + t) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// z pass, marching: a thread owns 4 consecutive x of one (plane, y) column and walks a chunk of ZC planes with the taps in
+// registers -- 1 + 8/ZC 16-byte loads per output instead of 9.  The per-output kernel above asks for every plane nine
+// times from workgroups that run on different XCDs at the same moment (no L2 reuse): at 8 x 3 x 160 x 160 x 80 the z pass
+// took 204-262 us against 91 us for the y pass, whose nine taps lie within 9 rows.  Same tap order per output (k = -4..4).
+constexpr int kGaussMarchU = 9;          // outputs per round = loads in flight per thread
+template <int PRE, int POST>
+__global__ void __launch_bounds__(kBlock)
+k_gauss_march_z(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, int64_t planes, Dims d,
+                int C, GaussW gw, float scale, int zc, int nchunk) {
+  constexpr int U = kGaussMarchU;
+  const int q = d.s2 >> 2;
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int xq = (int)(r % q);
+  r /= q;
+  const int iy = (int)(r % d.s1);
+  r /= d.s1;
+  const int chunk = (int)(r % nchunk);
+  const int64_t plane = r / nchunk;
+  if (plane >= planes) return;
+  const int V = (int)d.voxels();
+  const int stride = d.s1 * d.s2;
+  const int caxis = 2 - (int)(plane % C);
+  const int Sc = caxis == 2 ? d.s2 : (caxis == 1 ? d.s1 : d.s0);
+  const int ix = xq * 4;
+  const float* src = in + plane * V + iy * d.s2 + ix;
+  float* dst = out + plane * V + iy * d.s2 + ix;
+  const float* ax = POST == 2 ? aux + plane * V + iy * d.s2 + ix : nullptr;
+  auto fetch = [&](int j) -> float4 {     // unconditional load from the clamped plane
+    return *reinterpret_cast<const float4*>(src + (int64_t)min(max(j, 0), d.s0 - 1) * stride);
+  };
+  auto prep = [&](float4 v, int j) -> float4 {
+    if (j < 0 || j >= d.s0) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRE == 1) return make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    if (PRE == 2) {
+      float sl;
+      float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int o = 0; o < 4; ++o) e[o] = border_identity(e[o], Sc, sl) - lin_coord(caxis == 2 ? ix + o : (caxis == 1 ? iy : j), Sc);
+      return make_float4(e[0], e[1], e[2], e[3]);
+    }
+    return v;
+  };
+  const int ja = chunk * zc, jb = min(ja + zc, d.s0);
+  float4 w[8 + U];                       // inputs j0-4 .. j0+U+3 of the current round
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = prep(fetch(ja - 4 + k), ja - 4 + k);
+  for (int j0 = ja; j0 < jb; j0 += U) {
+    float4 nw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nw[u] = fetch(j0 + 4 + u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[8 + u] = prep(nw[u], j0 + 4 + u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u;
+      if (j >= jb) break;                // uniform over the workgroup's waves (same chunk)
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        acc[0] += gw.w[k] * w[u + k].x;
+        acc[1] += gw.w[k] * w[u + k].y;
+        acc[2] += gw.w[k] * w[u + k].z;
+        acc[3] += gw.w[k] * w[u + k].w;
+      }
+      if (POST == 1) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] += lin_coord(caxis == 2 ? ix + o : (caxis == 1 ? iy : j), Sc);
+      }
+      if (POST == 2) {
+        const float4 a = *reinterpret_cast<const float4*>(ax + (int64_t)j * stride);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          float slope;
+          border_identity(av[o], Sc, slope);
+          acc[o] *= slope;
+        }
+      }
+      *reinterpret_cast<float4*>(dst + (int64_t)j * stride) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = w[U + k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,7 +904,34 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
   const bool v4 = (d.s2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) |
                                        reinterpret_cast<uintptr_t>(aux)) & 15) == 0;
   dim3 grid(advchain_blocks(v4 ? total / 4 : total, kBlock));
-  const int riw = (v4 && d.s2 >= 4 && 64 % (d.s2 / 4) == 0 && (total / 4) % 64 == 0) ? 1 : 0;   // x rows aligned to waves
+  int riw = (v4 && d.s2 >= 4 && 64 % (d.s2 / 4) == 0 && (total / 4) % 64 == 0) ? 1 : 0;   // x rows aligned to waves
+  static const bool no_riw2 = getenv("ADVCHAIN_NO_GAUSS_RIW2") != nullptr, no_zmarch = getenv("ADVCHAIN_NO_GAUSS_ZMARCH") != nullptr;   // A/B knobs
+  if (!riw && v4 && axis == 2 && d.s2 >= 8 && d.s2 / 4 <= 64 && !no_riw2) {   // rows that do not divide a wave: whole rows per wave
+    riw = 2;
+    const int64_t rows = total / d.s2, rpw = 64 / (d.s2 / 4);
+    grid = dim3(advchain_blocks(((rows + rpw - 1) / rpw) * 64, kBlock));
+  }
+  if (v4 && axis == 0 && d.s0 >= 32 && !no_zmarch) {   // z pass of a volume: marching form
+    const int zc = 27;                                   // 3 rounds of 9 outputs: 1.3 loads per output
+    const int nchunk = (d.s0 + zc - 1) / zc;
+    const int64_t threads = planes * nchunk * d.s1 * (d.s2 / 4);
+    dim3 gm(advchain_blocks(threads, kBlock));
+#define GM(PRE, POST) hipLaunchKernelGGL((k_gauss_march_z<PRE, POST>), gm, blk, 0, st, in, out, aux, planes, d, (int)C, gw, scale, zc, nchunk)
+    switch (pre * 3 + post) {
+      case 0: GM(0, 0); break;
+      case 1: GM(0, 1); break;
+      case 2: GM(0, 2); break;
+      case 3: GM(1, 0); break;
+      case 4: GM(1, 1); break;
+      case 5: GM(1, 2); break;
+      case 6: GM(2, 0); break;
+      case 7: GM(2, 1); break;
+      default: GM(2, 2); break;
+    }
+#undef GM
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
 #define GA(PRE, POST)                                                                                                     \
   do {                                                                                                                    \
     if (!v4) hipLaunchKernelGGL((k_gauss_axis<PRE, POST>), grid, blk, 0, st, in, out, aux, total, d, (int)C, axis, gw, scale); \

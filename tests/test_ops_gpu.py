@@ -642,8 +642,10 @@ def test_affine_theta(nd):
     assert maxdiff(b.grad.cpu(), a.grad) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 12, 12), (2, 2, 40, 33), (2, 3, 8, 8, 32), (1, 3, 13, 11, 10)])
+@pytest.mark.parametrize("shape", [(2, 2, 12, 12), (2, 2, 40, 33), (2, 3, 8, 8, 32), (1, 3, 13, 11, 10),
+                                   (1, 3, 40, 12, 16), (1, 3, 33, 9, 80), (2, 3, 64, 6, 24), (2, 2, 20, 80), (1, 2, 7, 40)])
 def test_gauss_separable_vs_dense(shape):
+    """(the shapes with 32+ planes take the marching z pass, the rows of 80 / 40 / 24 voxels the x pass with whole rows per wave)"""
     from oracle import advchain_oracle as O
     ops = _ops()
     x = rand(shape, 41)
