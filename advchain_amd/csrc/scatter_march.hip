@@ -64,14 +64,16 @@ __device__ __forceinline__ void coord_path_diff(const float* __restrict__ in, fl
 
 // Fixed-point resolution: a cell can receive a corner of every sample within H+1 voxels of it, (2H+2)^3 at most, each of
 // weight <= 1 and |grad_out| <= the workgroup's max: 2^23 / 2^22 / 2^21 for H = 2 / 3 / 4 keeps any sum below 2^31.
-__device__ __forceinline__ float march_fix_scale(int H) { return H <= 2 ? 8388608.f : (H == 3 ? 4194304.f : 2097152.f); }
+// (H = 5..8: 18^3 deposits, 2^18.)
+__device__ __forceinline__ float march_fix_scale(int H) { return H <= 2 ? 8388608.f : (H == 3 ? 4194304.f : (H == 4 ? 2097152.f : 262144.f)); }
 
 // max |grad_out| of every x row (over its channels) -> rowmax[n][z][y].  The fixed-point scale of a workgroup comes from
 // the rows IT visits, not from the whole batch: gradients are heavy-tailed (edges), and a global scale left the small
 // ones with a median relative error of 2.5e-4 (measured, randn^5 grad_out); a local one also makes the result of a
 // sample independent of what else is in the batch (a sharded batch reproduces the whole one).
 template <int C>
-__global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict__ x, float* __restrict__ rowmax, Dims d, int rows_per_n) {
+__global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict__ x, float* __restrict__ rowmax, Dims d, int rows_per_n,
+                                                                int ctot = C) {   // ctot: channels per batch entry of x (a slice of C of them is looked at)
   // four rows per wave, their loads in flight together (a row per wave: 65536 waves of one dependent load each, 10.8 us
   // for 16.8 MB)
   constexpr int RW = 4;
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
   const int n = blockIdx.y;
   if (row0 >= rows_per_n) return;
   const int V = (int)d.voxels();
-  const float* p = x + (int64_t)n * C * V;
+  const float* p = x + (int64_t)n * ctot * V;
   float m[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) m[r] = 0.f;
@@ -114,11 +116,16 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
 // !SELF: gin <- value path; GG: ggrid <- coordinate path                            (advchain_grid_sample_bwd)
 // NWV waves per workgroup share one accumulator tile, so LDS does not cap the waves of a CU: 8 for 8 owned rows, 4 for 4
 // (with 8 waves on 4 + 2H rows half of them idle in the second round of a step: measured 380 vs 252 us, C = 4, H = 4).
-template <int PAD, int C, bool SELF, bool GG, int NWV>
+// CT > C (C == 1): channel-sliced launch for bounds of 5..8 voxels -- a ring of 2H+3 planes of ONE channel still fits 8
+// owned rows (19 x 8 x 64 cells = 38 KiB); the launcher runs one launch per channel c0, each keeps the deposits of its
+// channel; the coordinate path (all CT channels) is evaluated by every launch of a self-composition (it adds its own axis)
+// and by the first one of an image warp (GG).
+template <int PAD, int C, bool SELF, bool GG, int NWV, int CT = C, bool BIG = false>
 __global__ void __launch_bounds__(NWV * 64)
 k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int TY, int H, int NS,
-                  int clamp_grid, int32_t* __restrict__ ws, int nseg) {
+                  int clamp_grid, int32_t* __restrict__ ws, int nseg, int c0) {
+  constexpr bool SL = CT != C;
   extern __shared__ int acc[];                   // [slot 2H+3][C][TY][64]
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -135,9 +142,10 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
   const int za = tz * zc, zb = min(za + zc, d.s0);
   const int plane_cells = C * TY * 64;
   const float* gn = grid + (int64_t)n * 3 * V;
-  const float* gon = gout + (int64_t)n * C * V;
-  const float* inn = in + (int64_t)n * C * V;
-  float* ginn = gin + (int64_t)n * C * V;
+  const float* gon_all = gout + (int64_t)n * CT * V;
+  const float* gon = gon_all + (int64_t)c0 * V;
+  const float* inn = in + (int64_t)n * CT * V;
+  float* ginn = gin + (int64_t)n * CT * V + (int64_t)c0 * V;
   // fixed-point scale from the rows this workgroup visits
   __shared__ float wmax[NWV];
   {
@@ -163,7 +171,7 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
   const int xl = min(max(xs, 0), d.s2 - 1);
   const int yend = min(y0 + TY, d.s1);
 
-  constexpr int MAXR = NWV == 8 ? 2 : 3;         // sample rows per wave and step: TY + 2H <= 8 + 8 (8 waves), 4 + 8 (4)
+  constexpr int MAXR = (NWV == 8 && !BIG) ? 2 : 3;  // sample rows per wave and step: TY + 2H <= 8 + 8 (8 waves), 4 + 8 (4), 8 + 16 (BIG: H = 5..8)
   constexpr int MAXF = 1;                        // output rows per wave and step: TY <= NWV
   // requests one step ahead; not for C = 4 on 4 waves: 181 VGPRs, two workgroups a CU, 414 us where 252 is possible
   constexpr bool PF = C < 4 || NWV == 8;
@@ -269,7 +277,12 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         t.build(q[0], q[1], q[2], d);
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, fgo[k][c], t, d, ax, ay, az);
+        for (int c = 0; c < C; ++c) if (!SL) coord_path_diff<3, PAD>(inn + (int64_t)c * V, fgo[k][c], t, d, ax, ay, az);
+        if (SL) {
+          const int so = (min(max(zt, 0), d.s0 - 1) * d.s1 + min(y0 + wave + k * NWV, d.s1 - 1)) * d.s2 + xl;   // the own sample
+#pragma unroll
+          for (int c = 0; c < CT; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, gon_all[(int64_t)c * V + so], t, d, ax, ay, az);
+        }
         gg[k][0] = pass[0] ? t.x.mult * ax : 0.f;
         gg[k][1] = pass[1] ? t.y.mult * ay : 0.f;
         gg[k][2] = pass[2] ? t.z.mult * az : 0.f;
@@ -296,7 +309,7 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         const int s = (zt * d.s1 + uy) * d.s2 + xl;
         if (SELF) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) v[c] += gg[k][c < 3 ? c : 0];
+          for (int c = 0; c < C; ++c) v[c] += SL ? (c0 == 0 ? gg[k][0] : (c0 == 1 ? gg[k][1] : gg[k][2])) : gg[k][c < 3 ? c : 0];
         } else if (GG && xown) {
           float* gq = ggrid + (int64_t)n * 3 * V + s;
 #pragma unroll
@@ -519,11 +532,42 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                   hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_MARCH") != nullptr;   // A/B knob
-  static const int hmax = getenv("ADVCHAIN_SCATTER_MARCH_HMAX") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_HMAX")) : 4;   // tuning knob
-  if (off || !workspace || !gin || padding == PAD_REFLECTION || H < 2 || H > hmax || H > 4) return ADVCHAIN_ERR_UNSUPPORTED;
+  static const int hmax = getenv("ADVCHAIN_SCATTER_MARCH_HMAX") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_HMAX")) : 8;   // tuning knob
+  if (off || !workspace || !gin || padding == PAD_REFLECTION || H < 2 || H > hmax || H > 8) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 > 1024 || d.s2 < 8 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
   const int nseg = d.s2 <= 64 ? 1 : (int)((d.s2 + (64 - 2 * H) - 1) / (64 - 2 * H));
   if (self ? C != 3 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (H > 4 && C == 1 && N * d.voxels() < (6ll << 20)) return ADVCHAIN_ERR_UNSUPPORTED;   // (4 x 128 x 128 x 64, C = 1: 166 us against 139 for the window scatter; twice that batch: 231 against 282)
+  if (H > 4) {
+    // bounds of 5..8 voxels: one launch per channel (a ring of 2H+3 planes of all channels would leave 2-4 owned rows and
+    // a 5-9x y halo).  Against the window scatter's 5.8 global float atomics per sample (C = 4, 8 x 128 x 128 x 64:
+    // 1.45 ms) four passes over the samples are still the cheaper way.
+    const int NSb = 2 * H + 3, TYb = 8;
+    const size_t ldsb = (size_t)NSb * TYb * 64 * sizeof(int);
+    const int n1b = (d.s1 + TYb - 1) / TYb;
+    int zcb = d.s0;
+    while (zcb > 32 && N * n1b * nseg * ((d.s0 + zcb - 1) / zcb) < 512) zcb = (zcb + 1) / 2;
+    const int n0b = (d.s0 + zcb - 1) / zcb;
+    dim3 gb((unsigned)(n1b * n0b * nseg), (unsigned)N), bb(512);
+    const int rows = (int)(d.s0 * d.s1);
+    dim3 rg((unsigned)((rows + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N);
+    float* rowmax = reinterpret_cast<float*>(workspace + 4);
+    const bool ggb = ggrid != nullptr;
+#define GOB(PAD_, SELF_, GG_, CT_) \
+    hipLaunchKernelGGL((k_scatter_march3d<PAD_, 1, SELF_, GG_, 8, CT_, true>), gb, bb, ldsb, st, gout, in, grid, gin, ggrid, d, n1b, zcb, TYb, H, NSb, clamp_grid, workspace, nseg, c0)
+#define GOB_PAD(GG_, CT_) do { if (padding == PAD_BORDER) GOB(PAD_BORDER, false, GG_, CT_); else GOB(PAD_ZEROS, false, GG_, CT_); } while (0)
+    for (int c0 = 0; c0 < (int)C; ++c0) {
+      hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout + (int64_t)c0 * d.voxels(), rowmax, d, rows, (int)C);
+      if (self) GOB(PAD_BORDER, true, false, 3);
+      else if (C == 1) { if (ggb) GOB_PAD(true, 1); else GOB_PAD(false, 1); }
+      else if (ggb && c0 == 0) GOB_PAD(true, 4);
+      else GOB_PAD(false, 4);
+    }
+#undef GOB_PAD
+#undef GOB
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   // rows per workgroup: as many as 60 KiB of accumulator planes allow, at most 8
   static const int ty_forced = getenv("ADVCHAIN_SCATTER_MARCH_TY") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_TY")) : 0;
   int NS = 2 * H + 3;
@@ -551,8 +595,8 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
   dim3 g((unsigned)(n1 * n0 * nseg), (unsigned)N), b(nwv * 64);
   const bool gg = ggrid != nullptr;
 #define GO(PAD_, C_, SELF_, GG_) \
-  do { if (nwv == 8) hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 8>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg); \
-  else hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 4>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg); } while (0)
+  do { if (nwv == 8) hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 8>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg, 0); \
+  else hipLaunchKernelGGL((k_scatter_march3d<PAD_, C_, SELF_, GG_, 4>), g, b, lds, st, gout, in, grid, gin, ggrid, d, n1, zc, TY, H, NS, clamp_grid, workspace, nseg, 0); } while (0)
 #define GO_PAD(C_, GG_) do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, false, GG_); else GO(PAD_ZEROS, C_, false, GG_); } while (0)
   if (self) GO(PAD_BORDER, 3, true, false);
   else if (C == 1) { if (gg) GO_PAD(1, true); else GO_PAD(1, false); }

@@ -173,8 +173,19 @@ def squaring_halo(disp, d):
     if disp < 0.999:
         return -1
     if d == 3:       # exact bounds of 2..4 voxels: owner-computes march (scatter_march.hip); beyond: window scatter
-        return -2 if disp < 1.999 else (-3 if disp < 2.999 else (-4 if disp < 3.999 else 8))
+        return _halo_3d(disp)
     return _halo_2d(disp)
+
+
+def _halo_3d(disp):
+    """3D above one voxel: exact bounds of 2..4 voxels (owner-computes march scatter); beyond: a hint for the window
+    scatter.  (The C ABI also takes exact bounds of 5..8 voxels -- one march launch per channel -- but on the smooth
+    fields of the solver the window scatter is faster there: cfg-5 121.6 against 131.7 ms per call, cfg-4 61.4 against
+    63.1; on rougher fields it is the other way round, tools/kernel_bench.py: C=4 681 against 2153 us.)"""
+    for h in (2, 3, 4):
+        if disp < h - 0.001:
+            return -h
+    return 8
 
 
 def _halo_2d(disp):
@@ -316,7 +327,7 @@ def warp_halo(entry, d):
     if not est == est:
         return 0
     if d == 3:
-        return -1 if est < 0.999 else (-2 if est < 1.999 else (-3 if est < 2.999 else (-4 if est < 3.999 else 8)))
+        return -1 if est < 0.999 else _halo_3d(est)
     return _halo_2d(est)
 
 

@@ -531,11 +531,11 @@ def test_window_scatter_3d(dims, amp_vox, halo):
 
 
 @pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32), (10, 12, 80), (9, 10, 132)])
-@pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4)])
+@pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4), (5.4, 6), (7.5, 8)])
 def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
     """3D sampler backward with an EXACT displacement bound of 2..4 voxels (negative halo): the owner-computes z-march of
     scatter_march.hip (LDS integer accumulator planes, plain stores, no zero-fill; rows longer than 64 voxels in x
-    segments of 64 - 2H owned lanes).  Smooth fields whose measured
+    segments of 64 - 2H owned lanes; bounds of 5..8 voxels as one launch per channel).  Smooth fields whose measured
     displacement sits below the bound: self-composition (value + coordinate path, then chained owner-computes steps that
     must find out on the device that no max|grad| was left behind), image warps (C = 1, 4, both paddings, clamped grid,
     with and without grad_grid) against autograd through F.grid_sample; run-to-run bitwise determinism."""
@@ -545,7 +545,8 @@ def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
     phi = _smooth_field(dims, amp_vox, 61)
     measured = float(ops.raw_max_displacement(phi.to(DEV)).item())
     assert bound - 1 <= measured < bound - 0.001, measured
-    assert ops.squaring_halo(measured, 3) == -bound and ops.warp_halo([None, measured, 0, 0], 3) == -bound
+    policy = -bound if bound <= 4 else 8      # (5..8 voxels: in the C ABI, not in the product's policy -- ops._halo_3d)
+    assert ops.squaring_halo(measured, 3) == policy and ops.warp_halo([None, measured, 0, 0], 3) == policy
     w = rand((2, d) + dims, 62)
     p = phi.clone().requires_grad_(True)
     (O.compose_fields(p, p) * w).sum().backward()

@@ -99,7 +99,7 @@ def main():
     add("compose_self bwd halo=-1 (exact bound)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, -1), 12 * d * NV)
     if d == 3:   # fields of 1.5 / 3.5 voxels: exact-bound owner-computes march against the window scatter (halo 8)
         from oracle import advchain_oracle as O
-        for amp in (1.5, 3.5):
+        for amp in (1.5, 3.5, 6.5):
             low = torch.rand(N, d, *[max(2, s // 8) for s in dims], device=dev) * 2 - 1
             up = F.interpolate(low, size=dims, mode="trilinear", align_corners=True)
             up = up / up.abs().max()
