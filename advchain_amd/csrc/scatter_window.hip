@@ -176,7 +176,17 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
 // L1/L2-resident grid in the deposit pass: 4 x 3 axis taps per thread would not fit the register budget).
 // ---------------------------------------------------------------------------------------------
 constexpr int kWin3Z = 4, kWin3Y = 8, kWin3X = 32;
+#ifndef ADVCHAIN_WIN3_CP4
+#define ADVCHAIN_WIN3_CP4 2
+#endif
+#ifndef ADVCHAIN_WIN3_CPS
+#define ADVCHAIN_WIN3_CPS 3
+#endif
+constexpr int kWin3CP4 = ADVCHAIN_WIN3_CP4, kWin3CPS = ADVCHAIN_WIN3_CPS;
 constexpr int kWin3Cells = 12288;        // 48 KiB of LDS: 3 workgroups per CU
+// C = 4: the window holds TWO channels at a time (6144 cells each) and the deposit + flush passes run twice -- 3072 cells
+// per channel capped the windows of the 5-8 voxel fields, and what falls outside a window goes to global atomics
+// (8x4x128x128x64: 1449 us; with a 63-KiB window for all four channels 1057 us, but two workgroups a CU).
 
 template <int PAD, int C, bool SELF, bool GG>
 __global__ void __launch_bounds__(kBlock)
@@ -184,6 +194,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
                    float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid,
                    int32_t* __restrict__ ws) {
   __shared__ int win[kWin3Cells];
+  constexpr int CP = C == 4 ? kWin3CP4 : (SELF ? kWin3CPS : C);       // channels per deposit / flush pass
   if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
   __shared__ int red[7][kBlock / 64];
   constexpr int DIM = 3;
@@ -246,14 +257,12 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     gmax = fmaxf(gmax, __int_as_float(red[6][w]));
   }
   // window = box capped to the LDS budget (keeps the low corner; what falls outside uses global atomics)
-  constexpr int cells_per_ch = kWin3Cells / C;
+  constexpr int cells_per_ch = kWin3Cells / CP;
   int ww = min(max(hi[0] - lo[0] + 1, 0), 64), wh = max(hi[1] - lo[1] + 1, 0), wd = max(hi[2] - lo[2] + 1, 0);
   if (ww > 0 && wh > cells_per_ch / ww) wh = cells_per_ch / ww;
   if (ww * wh > 0 && wd > cells_per_ch / (ww * wh)) wd = cells_per_ch / (ww * wh);
   const int plane = ww * wh, cells = plane * wd;
-  for (int i = threadIdx.x; i < C * cells; i += kBlock) win[i] = 0;
   const float scale = gmax > 0.f ? 1048576.f / gmax : 0.f;   // 2^20
-  __syncthreads();
 
   // ---- 2. deposits.  Grid and grad_out of the four samples are requested up front (unconditionally: a dead sample
   // reads voxel 0), so the loop below starts with its operands in flight instead of one memory round trip per sample.
@@ -267,6 +276,10 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 #pragma unroll
     for (int c = 0; c < C; ++c) gopre[j][c] = gon[(int64_t)c * V + s];
   }
+#pragma unroll
+  for (int c0 = 0; c0 < C; c0 += CP) {
+  for (int i = threadIdx.x; i < CP * cells; i += kBlock) win[i] = 0;
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < kWin3Z; ++j) {
     const int sz = tz * kWin3Z + j;
@@ -304,14 +317,14 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
             const float ws = w * scale;
             int* cell = win + cell0 + (cz ? plane : 0) + (cy ? ww : 0) + cx;
 #pragma unroll
-            for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c]));
+            for (int c = 0; c < CP; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c0 + c]));
           } else {
-            float* dst = ginn + vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx;
+            float* dst = ginn + vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx + (int64_t)c0 * V;
 #pragma unroll
-            for (int c = 0; c < C; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[c]);
+            for (int c = 0; c < CP; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[c0 + c]);
           }
         }
-    if (SELF || GG) {
+    if ((SELF || GG) && c0 == 0) {
       float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c)
@@ -334,14 +347,16 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 
   // ---- 3. flush: a wave per window row (lane <-> x: runs of consecutive addresses, one division per row)
   const float inv = gmax * (1.f / 1048576.f);
-  const int lane = threadIdx.x & 63, rows = C * wd * wh;
+  const int lane = threadIdx.x & 63, rows = CP * wd * wh;
   for (int r = wave; r < rows; r += kBlock / 64) {
     if (lane >= ww) continue;
     const int a = win[r * ww + lane];
     if (a == 0) continue;
     const int c = r / (wd * wh), q = r - c * (wd * wh);
     const int wz = q / wh, wy = q - wz * wh;
-    atomic_add_f32(ginn + (int64_t)c * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + lane), (float)a * inv);
+    atomic_add_f32(ginn + (int64_t)(c0 + c) * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + lane), (float)a * inv);
+  }
+  if (c0 + CP < C) __syncthreads();          // the window is cleared for the next channel pair
   }
 }
 
