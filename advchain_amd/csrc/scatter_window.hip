@@ -21,6 +21,7 @@ namespace advchain {
 
 constexpr int kWinT = 32;               // sample tile edge
 constexpr int kWinCells = 8192;         // LDS window budget in cells (all channels together): 32 KiB
+constexpr int kWinCellsC4 = 12288;      // four channels: 48 KiB (2048 cells per channel = 45 x 45 capped stretched 32 x 32 tiles)
 
 // SELF : in == grid == phi (C == 2); the coordinate-path gradient is added to the same tensor (atomics: other tiles
 //        deposit there too).  Otherwise GG: grad_grid is written with plain stores.
@@ -29,7 +30,8 @@ __global__ void __launch_bounds__(kBlock)
 k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                    float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n2, int clamp_grid,
                    int32_t* __restrict__ ws) {
-  __shared__ int win[kWinCells];
+  constexpr int kCells2 = C == 4 ? kWinCellsC4 : kWinCells;
+  __shared__ int win[kCells2];
   if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
   __shared__ int red[8][kBlock / 64];
   constexpr int DIM = 2;
@@ -92,7 +94,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
   }
   // window = box, capped to the LDS budget (keeps the low corner; what falls outside uses global atomics)
   int ww = max(bx1 - bx0 + 1, 0), wh = max(by1 - by0 + 1, 0);
-  constexpr int cells_per_ch = kWinCells / C;
+  constexpr int cells_per_ch = kCells2 / C;
   if (ww > 128) ww = 128;
   if (ww > 0 && wh > cells_per_ch / ww) wh = cells_per_ch / ww;
   const int cells = ww * wh;
