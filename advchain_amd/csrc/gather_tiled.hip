@@ -258,12 +258,25 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
                                  hipStream_t st);
 
 // Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify (caller uses the direct-gather kernels).
+// The z-marching kernel keeps three planes of its rows in LDS and sends a lane whose taps leave them to global gathers:
+// unbeatable below one voxel (self-composition 29 against 42 us at 4 x 3 x 128 x 128 x 64), equal at 1-2 voxels, slower
+// beyond (97 against 63 us at 4 voxels, 117 against 83 at 7).  Rows longer than 64 voxels run as two or more partly
+// empty x segments: at 160 x 160 x 80 the tile kernel wins at every displacement for C = 3 / C = 1 (83 against 87 us
+// below a voxel, 116 against 465 at 4 voxels).  `hint` = the caller's displacement estimate in voxels, rounded up
+// (0 = unknown): a performance hint, results do not depend on it.
+static bool march_forward_pays(bool self, int64_t C, const Dims& d, int hint) {
+  static const bool always = getenv("ADVCHAIN_FWD_MARCH_ALWAYS") != nullptr;   // A/B knob: the round-2 policy before the hint
+  if (always) return true;
+  if (d.s2 > 64) return !self && C == 4 && hint <= 1;
+  return hint <= 1;
+}
+
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
-                                 int halo, float* disp_out, hipStream_t st) {
+                                 int halo, float* disp_out, hipStream_t st, int disp_hint) {
   static const bool off = getenv("ADVCHAIN_NO_GATHER_TILES") != nullptr;   // A/B knob
   if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (ndim == 3) {
+  if (ndim == 3 && march_forward_pays(self, C, d, disp_hint)) {
     const int rc = advchain_sample_march_launch(self, in, grid, out, phi0, N, C, d, padding, clamp_grid, final_mode, disp_out, st);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }

@@ -745,7 +745,7 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
-                                 int halo, float* disp_out, hipStream_t st);
+                                 int halo, float* disp_out, hipStream_t st, int disp_hint);
 
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
@@ -845,6 +845,8 @@ extern "C" {
 int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
                              void* stream) {
+  const int disp_hint = (clamp_grid >> 8) & 0xff;   // bits 8..15: displacement estimate in voxels (0 = unknown), a performance hint
+  clamp_grid &= 1;
   ADVCHAIN_CHECK_ARG(in && grid && out, "grid_sample_fwd: null pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "grid_sample_fwd: bad N/C");
@@ -855,7 +857,7 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
   ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_fwd: per-sample volume too large");
   if (interp == INTERP_LINEAR && id.s0 == od.s0 && id.s1 == od.s1 && id.s2 == od.s2) {   // LDS-staged tiles
     const int rc = advchain_sample_tiled_launch(false, in, grid, out, nullptr, N, C, ndim, id, padding, clamp_grid, 0, 0, nullptr,
-                                                (hipStream_t)stream);
+                                                (hipStream_t)stream, disp_hint);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   return ndim == 3 ? launch_grid_sample_fwd<3>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
@@ -904,6 +906,8 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
 
 int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
                               const int64_t* dims, int final_mode, float* disp_out, void* stream) {
+  const int disp_hint = (final_mode >> 8) & 0xff;   // bits 8..15: displacement estimate of phi in voxels (0 = unknown), a performance hint
+  final_mode &= 0xff;
   ADVCHAIN_CHECK_ARG(phi && out && phi != out, "compose_self_fwd: null/aliased pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(final_mode == 0 || (final_mode == 1 && phi0), "compose_self_fwd: final_mode 1 needs phi0");
@@ -914,7 +918,7 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
   {
     const int rc = advchain_sample_tiled_launch(true, phi, nullptr, out, phi0, N, ndim, ndim, d, PAD_BORDER, 0,
-                                                final_mode, 0, disp_out, (hipStream_t)stream);
+                                                final_mode, 0, disp_out, (hipStream_t)stream, disp_hint);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   const bool vec4 = use_unroll(V, ndim);

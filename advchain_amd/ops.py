@@ -88,14 +88,22 @@ def pad_code(padding_mode):
 # ------------------------------------------------------------------------------------------------
 # raw (non-autograd) wrappers: one C-ABI call each
 # ------------------------------------------------------------------------------------------------
-def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid):
+def _hint_bits(disp):
+    """Displacement estimate (voxels) -> the hint bits 8..15 of an int argument (0 = unknown); see include/advchain_hip.h."""
+    if disp is None or not disp == disp or disp < 0:
+        return 0
+    return min(int(disp) + 1, 255) << 8
+
+
+def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, disp_hint=None):
     N, C = inp.shape[:2]
     nd = inp.dim() - 2
     odims = grid.shape[2:]
     out = torch.empty((N, C) + tuple(odims), device=inp.device, dtype=torch.float32)
     _lib.check(_lib.load().advchain_grid_sample_fwd(_ptr(inp), _ptr(grid), _ptr(out), N, C, nd,
                                                     _lib.dims_array(inp.shape[2:]), _lib.dims_array(odims),
-                                                    interp, padding, int(clamp_grid), _stream()), "grid_sample_fwd")
+                                                    interp, padding, int(clamp_grid) | _hint_bits(disp_hint), _stream()),
+               "grid_sample_fwd")
     return out
 
 
@@ -124,13 +132,14 @@ def raw_grid_sample_bwd(gout, inp, grid, interp, padding, clamp_grid, need_gin, 
     return gin, ggrid
 
 
-def raw_compose_self_fwd(phi, phi0=None, final_mode=0, disp_out=None):
-    """phi o phi; `disp_out` (DISP_SLOTS zero-initialised floats) max-accumulates the displacement of the result."""
+def raw_compose_self_fwd(phi, phi0=None, final_mode=0, disp_out=None, disp_hint=None):
+    """phi o phi; `disp_out` (DISP_SLOTS zero-initialised floats) max-accumulates the displacement of the result.
+    `disp_hint`: the caller's estimate of phi's displacement in voxels (picks the forward kernel; results do not depend on it)."""
     N = phi.shape[0]
     nd = phi.dim() - 2
     out = torch.empty_like(phi)
     _lib.check(_lib.load().advchain_compose_self_fwd(_ptr(phi), _ptr(out), _ptr(phi0), N, nd,
-                                                     _lib.dims_array(phi.shape[2:]), final_mode, _ptr(disp_out),
+                                                     _lib.dims_array(phi.shape[2:]), final_mode | _hint_bits(disp_hint), _ptr(disp_out),
                                                      _stream()), "compose_self_fwd")
     return out
 
@@ -313,9 +322,24 @@ def grid_displacement(grid):
     and then the prediction)."""
     hit = getattr(grid, "_advchain_disp", None)
     if hit is None or hit[2] != grid._version:
-        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0]
+        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, tuple(grid.shape[2:])]
         grid._advchain_disp = hit
     return hit
+
+
+def forward_hint(grid):
+    """Displacement estimate (voxels) for the FORWARD warp by `grid`, without waiting for anything: the bound riding on
+    the grid if its read-back has already arrived, else the last bound read for a grid of this shape (the deformation of
+    the previous ascent step), else None.  Picks the forward kernel only."""
+    hit = getattr(grid, "_advchain_disp", None)
+    if hit is not None and hit[2] == grid._version:
+        if hit[1] is None and hit[0].event.query():
+            hit[1] = float(hit[0].values()[hit[3]])
+            if len(hit) > 4:
+                _WARP_HINTS[hit[4]] = hit[1]
+        if hit[1] is not None:
+            return hit[1]
+    return _WARP_HINTS.get(tuple(grid.shape[2:]))
 
 
 def warp_halo(entry, d):
@@ -324,6 +348,8 @@ def warp_halo(entry, d):
     if entry[1] is None:
         entry[1] = float(entry[0].values()[entry[3]])
     est = entry[1]
+    if len(entry) > 4:
+        _WARP_HINTS[entry[4]] = est
     if not est == est:
         return 0
     if d == 3:
@@ -333,12 +359,12 @@ def warp_halo(entry, d):
 
 class _GridSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, grid, interp, padding, clamp_grid, disp):
+    def forward(ctx, inp, grid, interp, padding, clamp_grid, disp, hint=None):
         inp, grid = _dev(inp, "input"), _dev(grid, "grid")
         ctx.save_for_backward(inp, grid)
         ctx.cfg = (interp, padding, clamp_grid)
         ctx.disp = disp
-        return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid)
+        return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, hint)
 
     @staticmethod
     def backward(ctx, gout):
@@ -346,11 +372,11 @@ class _GridSample(torch.autograd.Function):
         interp, padding, clamp_grid = ctx.cfg
         need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_in or need_grid):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         halo = warp_halo(ctx.disp, inp.dim() - 2) if (ctx.disp is not None and need_in) else 0
         gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid,
                                          halo)
-        return gin, ggrid, None, None, None, None
+        return gin, ggrid, None, None, None, None, None
 
 
 @_on_tensor_device
@@ -369,7 +395,8 @@ def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=F
     if (ADAPTIVE_HALO and code == 0 and torch.is_grad_enabled() and inp.requires_grad and grid.is_cuda
             and inp.shape[2:] == grid.shape[2:] and grid.dtype == torch.float32 and grid.is_contiguous()):
         disp = grid_displacement(grid)       # the backward sizes its halo / picks the gather form from it
-    return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp)
+    hint = forward_hint(grid) if (code == 0 and nd == 3 and grid.is_cuda) else None
+    return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp, hint)
 
 
 class _AffineWarp(torch.autograd.Function):
@@ -566,10 +593,15 @@ class _DemonsField(torch.autograd.Function):
         # shrink a displacement).  Read back once (asynchronously): the backward sizes every step exactly from it.
         disp = torch.zeros(n + 1, DISP_SLOTS, device=vel.device, dtype=torch.float32) if ADAPTIVE_HALO else None
         row = (lambda m: None) if disp is None else (lambda m: disp[m])
+        # what the squarings of the PREVIOUS field of this shape measured (a field changes little between two ascent
+        # steps): picks the forward kernel per squaring, nothing else
+        key = (tuple(vel.shape), n)
+        hints = _CHAIN_HINTS.get(key)
+        hint = (lambda m: None) if hints is None else (lambda m: hints[m])
         phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))]
         for i in range(n - 1):
-            phis.append(raw_compose_self_fwd(phis[-1], disp_out=row(i + 1)))
-        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1, disp_out=row(n))
+            phis.append(raw_compose_self_fwd(phis[-1], disp_out=row(i + 1), disp_hint=hint(i)))
+        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1, disp_out=row(n), disp_hint=hint(n - 1))
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, *phis)
         ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp))
@@ -577,6 +609,7 @@ class _DemonsField(torch.autograd.Function):
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
+        ctx.hint_key = key
         return q
 
     @staticmethod
@@ -594,6 +627,7 @@ class _DemonsField(torch.autograd.Function):
         n = len(phis)
         if ctx.disp is not None:
             dm = ctx.disp.values()
+            _CHAIN_HINTS[ctx.hint_key] = list(dm)
             halos = [squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
         else:
             big = 2 if d == 3 else 16
@@ -607,6 +641,8 @@ class _DemonsField(torch.autograd.Function):
 
 
 _LAST_FIELD_BOUND = None
+_CHAIN_HINTS = {}     # (velocity shape, n) -> displacement of phi_0..phi_n measured by the last backward of such a chain
+_WARP_HINTS = {}      # spatial dims -> displacement of the last grid of that shape whose bound was read
 
 
 @_on_tensor_device
@@ -616,7 +652,7 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, False)
     if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
         rb, idx = _LAST_FIELD_BOUND
-        q._advchain_disp = [rb, None, q._version, idx]
+        q._advchain_disp = [rb, None, q._version, idx, tuple(q.shape[2:])]
         _LAST_FIELD_BOUND = None
     return q
 
@@ -634,8 +670,8 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     qp, qm = q2[:N], q2[N:]
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
-        qp._advchain_disp = [rb, None, qp._version, idx]
-        qm._advchain_disp = [rb, None, qm._version, idx]
+        qp._advchain_disp = [rb, None, qp._version, idx, tuple(qp.shape[2:])]
+        qm._advchain_disp = [rb, None, qm._version, idx, tuple(qm.shape[2:])]
         _LAST_FIELD_BOUND = None
     return qp, qm
 
