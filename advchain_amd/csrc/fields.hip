@@ -751,6 +751,22 @@ k_norm_axpy(const float* __restrict__ base, const float* __restrict__ x, const f
   for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
 }
 
+// rows of at most one chunk (the low-resolution parameters of AdvBias / AdvMorph / AdvAffine): both steps in one launch,
+// one workgroup per row, same summation order as the two-launch form
+__global__ void __launch_bounds__(kBlock)
+k_norm_axpy_row(const float* __restrict__ base, const float* __restrict__ x, float step, float* __restrict__ out, int64_t M) {
+  __shared__ float smem[4];
+  __shared__ float inv_s;
+  const int64_t off = (int64_t)blockIdx.x * M;
+  float s[1] = {0.f};
+  for (int64_t i = threadIdx.x; i < M; i += kBlock) { const float q = x[off + i]; s[0] += q * q; }
+  block_sum<1>(s, smem);
+  if (threadIdx.x == 0) inv_s = step / (sqrtf(s[0]) + 1e-20f);
+  __syncthreads();
+  const float inv = inv_s;
+  for (int64_t i = threadIdx.x; i < M; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -999,6 +1015,11 @@ int advchain_norm_axpy(const float* base, const float* x, float* out, float* wor
   const int chunk = 16384;
   const int nb = (int)((M + chunk - 1) / chunk);
   dim3 grid(nb, (unsigned)N), blk(kBlock);
+  if (nb == 1) {
+    hipLaunchKernelGGL(k_norm_axpy_row, dim3((unsigned)N), blk, 0, (hipStream_t)stream, base, x, step, out, M);
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   hipLaunchKernelGGL(k_sumsq_partial, grid, blk, 0, (hipStream_t)stream, x, workspace, M, chunk);
   hipLaunchKernelGGL(k_norm_axpy, grid, blk, 0, (hipStream_t)stream, base, x, workspace, nb, step, out, M, chunk);
   ADVCHAIN_LAUNCH_CHECK();
