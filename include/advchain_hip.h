@@ -46,6 +46,10 @@ const char* advchain_last_error(void);
  *           torch.clamp(dxy,-1,1) of adv_morph.py:304-305,490 when clamp_grid != 0 (the
  *           clamp and its sub-gradient mask are applied to the grid on load).
  * in (N,C,in_dims), grid (N,ndim,out_dims) planar, out (N,C,out_dims).                      */
+/* clamp_grid: bit 0 = clamp the grid to [-1, 1] on load; bits 8..15 (optional) = the caller's estimate of the grid's
+ * displacement |position - own voxel| in voxels, rounded up, 0 = unknown -- a performance hint that selects the forward
+ * kernel (z-marching below one voxel, LDS tiles above); results do not depend on it.  advchain_compose_self_fwd takes the
+ * same hint in bits 8..15 of final_mode. */
 int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding,
                              int clamp_grid, void* stream);

@@ -1,4 +1,5 @@
-python -m pytest tests/test_ops_gpu.py tests/test_solver_gpu.py -m gpu -q -x -k "axpy or solver or golden" 2>&1 | tail -2
-for w in cfg1 cfg2; do
-echo "== $w"; python bench.py --workload $w --only-workload --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('value'), d.get('ms_per_step'))"
+export TMPDIR=/tmp; cd /tmp
+for w in cfg5; do
+rm -rf /tmp/rp1; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp1 -o c2 -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --only-workload > /tmp/b_$w.log 2>&1
+python $GRAFT_REPO_ROOT/tools/stats_per_call.py $(find /tmp/rp1 -name "c2_kernel_stats.csv" | head -1) 4 30
 done
