@@ -1,5 +1,3 @@
-export TMPDIR=/tmp; cd /tmp
-for w in cfg5; do
-rm -rf /tmp/rp1; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp1 -o c2 -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 3 --warmup 1 --only-workload > /tmp/b_$w.log 2>&1
-python $GRAFT_REPO_ROOT/tools/stats_per_call.py $(find /tmp/rp1 -name "c2_kernel_stats.csv" | head -1) 4 30
+for v in "" "ADVCHAIN_GTILE_T0=4" "ADVCHAIN_GTILE_T1=16" "ADVCHAIN_GTILE_H3=2" "ADVCHAIN_GTILE_T0=4 ADVCHAIN_GTILE_H3=2" "ADVCHAIN_GTILE_T0=1 ADVCHAIN_GTILE_T1=16"; do
+echo "== cfg5 $v"; env $v python bench.py --workload cfg5 --only-workload --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d.get('value'), d.get('ms_per_step'))"
 done
