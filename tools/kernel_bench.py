@@ -27,6 +27,13 @@ def timeit(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def _identity_grid(N, dims):
+    """(N, d, *dims) identity sampling grid, channel 0 = x (fastest axis), align_corners=True convention."""
+    lin = [torch.linspace(-1, 1, s) for s in dims]
+    mesh = torch.meshgrid(*lin, indexing="ij")
+    return torch.stack(list(reversed(mesh)), 0).unsqueeze(0).repeat(N, *([1] * (len(dims) + 1))).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="3d")
@@ -98,13 +105,12 @@ def main():
     add("compose_self bwd halo=1 (gather form)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 1), 12 * d * NV)
     add("compose_self bwd halo=-1 (exact bound)", lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, -1), 12 * d * NV)
     if d == 3:   # fields of 1.5 / 3.5 voxels: exact-bound owner-computes march against the window scatter (halo 8)
-        from oracle import advchain_oracle as O
         for amp in (1.5, 3.5, 6.5):
             low = torch.rand(N, d, *[max(2, s // 8) for s in dims], device=dev) * 2 - 1
             up = F.interpolate(low, size=dims, mode="trilinear", align_corners=True)
             up = up / up.abs().max()
             sc = torch.tensor([2.0 * amp / (dims[d - 1 - a] - 1) for a in range(d)], device=dev).view(1, d, 1, 1, 1)
-            big = (O.identity_grid(N, dims).to(dev) + up * sc).contiguous()
+            big = (_identity_grid(N, dims).to(dev) + up * sc).contiguous()
             hb = -int(amp + 1)
             add("compose_self bwd %.1f vox halo=%d (march)" % (amp, hb), lambda big=big, hb=hb: ops.raw_compose_self_bwd(gq, big, ws, False, hb), 12 * d * NV)
             add("compose_self bwd %.1f vox halo=8 (window)" % amp, lambda big=big: ops.raw_compose_self_bwd(gq, big, ws, False, 8), 12 * d * NV)
@@ -113,13 +119,12 @@ def main():
             add("grid_sample bwd C=4 %.1f vox halo=%d (march)" % (amp, hb), lambda big=big, hb=hb: ops.raw_grid_sample_bwd(g4, x4, big, 0, 0, True, True, True, hb), 4 * NV * (12 + 2 * d))
             add("grid_sample bwd C=4 %.1f vox halo=8 (window)" % amp, lambda big=big: ops.raw_grid_sample_bwd(g4, x4, big, 0, 0, True, True, True, 8), 4 * NV * (12 + 2 * d))
     if d == 2:   # fields of 1.5 / 3.5 / 6 px: exact-bound gather form (H = 2, 4) against the window scatter
-        from oracle import advchain_oracle as O
         for amp in (1.5, 3.5, 6.0, 12.0):
             low = torch.rand(N, d, *[max(2, s // 8) for s in dims], device=dev) * 2 - 1
             up = F.interpolate(low, size=dims, mode="bilinear", align_corners=True)
             up = up / up.abs().max()
             sc = torch.tensor([2.0 * amp / (dims[d - 1 - a] - 1) for a in range(d)], device=dev).view(1, d, 1, 1)
-            big = (O.identity_grid(N, dims).to(dev) + up * sc).contiguous()
+            big = (_identity_grid(N, dims).to(dev) + up * sc).contiguous()
             cand = [16] + [-h for h in (2, 4, 8, 16) if amp < h and h < 4 * amp]
             for hb in cand:
                 add("compose_self bwd %.1f px halo=%d" % (amp, hb), lambda big=big, hb=hb: ops.raw_compose_self_bwd(gq, big, ws, False, hb), 12 * d * NV)
