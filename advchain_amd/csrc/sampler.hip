@@ -1029,6 +1029,45 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   return ADVCHAIN_OK;
 }
 
+// ---- the whole scaling-and-squaring chain in one call (the same launches as n calls of the two entries above; the host
+// side of a solver step is as long as its GPU side, and a chain is 2 x n of its ~700 launches)
+int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_t N, int ndim, const int64_t* dims, int n,
+                            float* disp_rows, const int32_t* hints, void* stream) {
+  ADVCHAIN_CHECK_ARG(phi0 && pos && n >= 1 && n <= 64 && (n == 1 || fields), "expo_chain_fwd: null pointer / bad n");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_fwd: bad dims");
+  const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
+  const float* src = phi0;
+  for (int m = 0; m + 1 < n; ++m) {
+    float* dst = fields + (int64_t)m * F;
+    const int rc = advchain_compose_self_fwd(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
+                                             disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, stream);
+    if (rc != ADVCHAIN_OK) return rc;
+    src = dst;
+  }
+  return advchain_compose_self_fwd(src, pos, phi0, N, ndim, dims, 1 | (hints ? (hints[n - 1] & 0xff) << 8 : 0),
+                                   disp_rows ? disp_rows + (int64_t)n * kDispSlots : nullptr, stream);
+}
+
+int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const float* fields, float* grad_phi0, float* scratch,
+                            int32_t* workspace, const int32_t* halos, int64_t N, int ndim, const int64_t* dims, int n,
+                            void* stream) {
+  ADVCHAIN_CHECK_ARG(grad_pos && phi0 && grad_phi0 && n >= 1 && n <= 64 && (n == 1 || (fields && scratch)) && halos,
+                     "expo_chain_bwd: null pointer / bad n");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(grad_phi0 != scratch && grad_pos != grad_phi0 && grad_pos != scratch, "expo_chain_bwd: aliased buffers");
+  const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
+  const float* g = grad_pos;
+  for (int i = 0; i < n; ++i) {                      // squaring m = n-1 .. 0; the last one writes grad_phi0
+    const int m = n - 1 - i;
+    const float* phi = m == 0 ? phi0 : fields + (int64_t)(m - 1) * F;
+    float* out = (m % 2 == 0) ? grad_phi0 : scratch;
+    const int rc = advchain_compose_self_bwd(g, phi, out, workspace, i > 0 ? 1 : 0, halos[i], N, ndim, dims, stream);
+    if (rc != ADVCHAIN_OK) return rc;
+    g = out;
+  }
+  return ADVCHAIN_OK;
+}
+
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims) {
   if (!dims_ok(ndim, dims)) return -1;
   const Dims d = make_dims(ndim, dims);

@@ -598,12 +598,16 @@ class _DemonsField(torch.autograd.Function):
         key = (tuple(vel.shape), n)
         hints = _CHAIN_HINTS.get(key)
         hint = (lambda m: None) if hints is None else (lambda m: hints[m])
-        phis = [raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))]
-        for i in range(n - 1):
-            phis.append(raw_compose_self_fwd(phis[-1], disp_out=row(i + 1), disp_hint=hint(i)))
-        pos = raw_compose_self_fwd(phis[-1], phi0=phis[0], final_mode=1, disp_out=row(n), disp_hint=hint(n - 1))
+        phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
+        # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
+        fields = torch.empty((n - 1,) + tuple(phi0.shape), device=phi0.device, dtype=torch.float32)
+        pos = torch.empty_like(phi0)
+        harr = None if hints is None else (ctypes.c_int32 * n)(*[_hint_bits(hints[m]) >> 8 for m in range(n)])
+        _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
+                                                       _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr, _stream()),
+                   "expo_chain_fwd")
         q = raw_gauss(pos, d, pre=2, post=1)
-        ctx.save_for_backward(pos, *phis)
+        ctx.save_for_backward(pos, phi0, fields)
         ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp))
         global _LAST_FIELD_BOUND
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
@@ -614,8 +618,7 @@ class _DemonsField(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gq):
-        pos = ctx.saved_tensors[0]
-        phis = ctx.saved_tensors[1:]
+        pos, phi0, fields = ctx.saved_tensors
         scale, tables, inv, d = ctx.cfg
         gq = _dev(gq, "grad")
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
@@ -624,7 +627,7 @@ class _DemonsField(torch.autograd.Function):
         # squaring m composes a field whose displacement is ~2^(m-n) of the total: the early steps are sub-voxel and
         # take the gather-form adjoint.  The bound is a performance hint only (larger displacements stay correct
         # through the overflow list); it comes from the displacement measured in forward (one 4-byte read-back).
-        n = len(phis)
+        n = ctx.nsteps
         if ctx.disp is not None:
             dm = ctx.disp.values()
             _CHAIN_HINTS[ctx.hint_key] = list(dm)
@@ -632,8 +635,16 @@ class _DemonsField(torch.autograd.Function):
         else:
             big = 2 if d == 3 else 16
             halos = [big, big, max(1, big // 2)] + [1 if d == 3 else 2] * n
-        for i, phi in enumerate(reversed(phis)):
-            g = raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halos[i])
+        halos = halos[:n]
+        if ws is None:     # (global-atomic A/B path: per-step calls with zero-filled outputs)
+            phis = [phi0] + list(fields.unbind(0))
+            for i, phi in enumerate(reversed(phis)):
+                g = raw_compose_self_bwd(g, phi, None, chain=False, halo=halos[i])
+        else:
+            g, scratch = torch.empty_like(gpos), torch.empty_like(gpos)
+            _lib.check(_lib.load().advchain_expo_chain_bwd(_ptr(gpos), _ptr(phi0), _ptr(fields), _ptr(g), _ptr(scratch), _ptr(ws),
+                                                           (ctypes.c_int32 * n)(*[int(h) for h in halos]), gpos.shape[0], d,
+                                                           _lib.dims_array(gpos.shape[2:]), n, _stream()), "expo_chain_bwd")
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)

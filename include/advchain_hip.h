@@ -103,6 +103,19 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * recomputes max|grad_out| on the device.) */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
                               int halo, int64_t N, int ndim, const int64_t* dims, void* stream);
+/* replaces: the loops of vectorFieldExponentiation{2,3}D (adv_morph.py:132-135,165-168) and their autograd, n squarings
+ * in one call -- exactly the launches of n calls of advchain_compose_self_fwd / _bwd (same kernels, same results).
+ * fwd: phi_1..phi_{n-1} -> fields[(n-1)][N][ndim][dims], the sampling positions (final_mode 1 of the last squaring)
+ *      -> pos; disp_rows (may be NULL): (n+1) x ADVCHAIN_DISP_SLOTS zero-initialised floats, row m receives the
+ *      displacement of phi_m (m >= 1; row 0 belongs to whoever made phi0), row n that of pos; hints (may be NULL): n
+ *      displacement estimates in voxels (0 = unknown) for phi_0..phi_{n-1} (see advchain_grid_sample_fwd).
+ * bwd: grad_pos -> grad_phi0 through the n adjoint steps; halos[i] is the bound for the i-th step in BACKWARD order
+ *      (squaring n-1 first); scratch: one field-sized buffer; workspace as for advchain_compose_self_bwd.             */
+int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_t N, int ndim, const int64_t* dims, int n,
+                            float* disp_rows, const int32_t* hints, void* stream);
+int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const float* fields, float* grad_phi0, float* scratch,
+                            int32_t* workspace, const int32_t* halos, int64_t N, int ndim, const int64_t* dims, int n,
+                            void* stream);
 /* max over samples and axes of |sampling position - own voxel| of the field phi, in voxels: the displacement
  * bound `halo` above wants.  out: one float, zero-initialised by the caller (atomic max).            */
 int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim, const int64_t* dims, void* stream);

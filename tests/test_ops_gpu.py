@@ -406,6 +406,49 @@ def test_scatter_rows_2d_exact_bounds(dims, amp_px, bound):
             assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dims", [(24, 40), (10, 12, 16), (6, 9, 80)])
+@pytest.mark.parametrize("amp", [0.05, 2.5])
+def test_expo_chain_entries_equal_the_per_step_calls(dims, amp):
+    """advchain_expo_chain_fwd / _bwd (all n squarings in one call) run exactly the launches of n calls of
+    advchain_compose_self_fwd / _bwd: same fields, positions, displacement rows and gradient, bit for bit (the window
+    scatter of the large-displacement case is compared to rounding)."""
+    import ctypes
+    from oracle import advchain_oracle as O
+    from advchain_amd import _lib
+    ops = _ops()
+    d, n, N = len(dims), 5, 2
+    phi0 = (O.identity_grid(N, dims) + amp / 16 * 2.0 / min(dims) * rand((N, d) + dims, 95)).contiguous().to(DEV)
+    lib = _lib.load()
+    rows_a = torch.zeros(n + 1, ops.DISP_SLOTS, device=DEV)
+    phis = [phi0]
+    for m in range(n - 1):
+        phis.append(ops.raw_compose_self_fwd(phis[-1], disp_out=rows_a[m + 1]))
+    pos_a = ops.raw_compose_self_fwd(phis[-1], phi0=phi0, final_mode=1, disp_out=rows_a[n])
+    rows_b = torch.zeros(n + 1, ops.DISP_SLOTS, device=DEV)
+    fields = torch.empty((n - 1,) + tuple(phi0.shape), device=DEV)
+    pos_b = torch.empty_like(phi0)
+    _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(phi0), ops._ptr(fields), ops._ptr(pos_b), N, d, _lib.dims_array(dims), n,
+                                           ops._ptr(rows_b), None, ops._stream()), "expo_chain_fwd")
+    assert torch.equal(pos_a, pos_b) and torch.equal(rows_a.max(1).values, rows_b.max(1).values)
+    for m in range(1, n):
+        assert torch.equal(phis[m], fields[m - 1])
+    dm = ops.raw_slot_rows_max(rows_b).tolist()
+    halos = [ops.squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
+    gpos = rand((N, d) + dims, 96).to(DEV)
+    ws = ops._scatter_workspace(N, dims, DEV)
+    g = gpos
+    for i, phi in enumerate(reversed(phis)):
+        g = ops.raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halos[i])
+    out, scratch = torch.empty_like(gpos), torch.empty_like(gpos)
+    _lib.check(lib.advchain_expo_chain_bwd(ops._ptr(gpos), ops._ptr(phi0), ops._ptr(fields), ops._ptr(out), ops._ptr(scratch),
+                                           ops._ptr(ws), (ctypes.c_int32 * n)(*halos), N, d, _lib.dims_array(dims), n,
+                                           ops._stream()), "expo_chain_bwd")
+    if all(h < 0 for h in halos):
+        assert torch.equal(out, g)
+    else:
+        assert maxdiff(out, g) <= 1e-5 * max(1.0, float(g.abs().max()))
+
+
 @pytest.mark.parametrize("dims,vs,scale", [((32, 48), [4, 6], 1.5), ((32, 48), [4, 6], 12.0), ((16, 20, 24), [4, 5, 6], 1.0),
                                            ((16, 20, 24), [4, 5, 6], 9.0)])
 def test_demons_field_pair_is_the_two_single_fields(dims, vs, scale):
