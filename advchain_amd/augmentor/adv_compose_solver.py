@@ -124,7 +124,7 @@ class ComposeAdversarialTransformSolver(object):
                 step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
                 anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
         dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
-            data.detach().clone(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
+            data.detach(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
         self.init_output = init_output
         self.warped_back_adv_output = warped_back_adv_output
         self.origin_data = data
@@ -141,9 +141,12 @@ class ComposeAdversarialTransformSolver(object):
     def forward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
         """Apply the chain in order (adv_compose_solver.py:148-176)."""
         data.requires_grad = False
-        t_data = data.detach().clone()
         if chain_of_transforms is None:
             chain_of_transforms = self.chain_of_transforms
+        # the reference clones here (adv_compose_solver.py:160); the native transforms never write to their input, so the
+        # copy is only made for a third-party transform that might
+        native = len(chain_of_transforms) > 0 and all(isinstance(t, _NATIVE) for t in chain_of_transforms)
+        t_data = data.detach() if native else data.detach().clone()
         self._last_chain = list(chain_of_transforms)
         for transform in chain_of_transforms:
             t_data = transform.forward(t_data, interp=interp, padding_mode=padding_mode)
@@ -272,7 +275,7 @@ class ComposeAdversarialTransformSolver(object):
                                                chain_of_transforms=self.chain_of_transforms)
             self._shared_fields(self.chain_of_transforms, True)
             try:
-                augmented_data = self.forward(data.detach().clone())
+                augmented_data = self.forward(data.detach())     # (a new tensor object: forward() clears ITS requires_grad flag)
                 with _disable_tracking_bn_stats(model):
                     perturbed_output = self.get_net_output(model, augmented_data)
                 if self.if_contains_geo_transform(self.chain_of_transforms):
