@@ -503,7 +503,8 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
   const int nseg = (d.s2 + 63) / 64;
   int TY = H >= 8 ? 32 : 16;
   if (ty_forced > 0) TY = ty_forced;
-  while (TY > 4 && ((size_t)C * TY * d.s2 * 4 > 49152 || TY * nseg > 64)) TY >>= 1;   // 48 KiB of cells, 8 own items a wave
+  static const size_t lds_cap = getenv("ADVCHAIN_SCATTER_ROWS2D_LDS") ? (size_t)atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_LDS")) : 49152;   // tuning knob
+  while (TY > 4 && ((size_t)C * TY * d.s2 * 4 > lds_cap || TY * nseg > 64)) TY >>= 1;   // 48 KiB of cells, 8 own items a wave
   const size_t lds = (size_t)C * TY * d.s2 * sizeof(int);
   if (lds > 65536 - 64 || TY * nseg > 64) return ADVCHAIN_ERR_UNSUPPORTED;
   {

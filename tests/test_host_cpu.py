@@ -212,3 +212,18 @@ def test_anatomy_retry_logic(cpu_ops):
                                     volume_preserve_tolerance=1e-9)
     assert steps["n"] == 3                         # N=1: tries at i=1 (+new init, +N), i=2 (+1), i=3 (>=3N: give up)
     assert len(solver.chain_of_transforms) == 2    # reference quirk: last transform appended again on give-up
+
+
+def test_displacement_hint_bits_and_halo_policies():
+    """Host-side policy helpers of advchain_amd.ops (no kernel call): the forward displacement hint travels in bits 8..15
+    of an int argument; exact bounds are only promised below the measured displacement; the 3D policy stops at 4 voxels
+    (window scatter beyond), the 2D one at 16 px."""
+    from advchain_amd import ops
+    assert ops._hint_bits(None) == 0 and ops._hint_bits(float("nan")) == 0 and ops._hint_bits(-1.0) == 0
+    assert ops._hint_bits(0.3) == 1 << 8 and ops._hint_bits(1.0) == 2 << 8 and ops._hint_bits(6.2) == 7 << 8
+    assert ops._hint_bits(1e9) == 255 << 8
+    assert [ops.squaring_halo(x, 3) for x in (0.5, 0.9995, 1.5, 2.5, 3.5, 3.9995, 7.0)] == [-1, -2, -2, -3, -4, 8, 8]
+    assert [ops.squaring_halo(x, 2) for x in (0.5, 1.5, 3.0, 7.9, 15.0, 15.9995, 40.0)] == [-1, -2, -4, -8, -16, 16, 16]
+    assert ops.squaring_halo(float("nan"), 3) == 0
+    assert ops.warp_halo([None, 0.4, 0, 0], 3) == -1 and ops.warp_halo([None, 5.0, 0, 0], 3) == 8
+    assert ops.warp_halo([None, 0.4, 0, 0], 2) == -2 and ops.warp_halo([None, 20.0, 0, 0], 2) == 16
