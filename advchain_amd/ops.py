@@ -574,6 +574,9 @@ class _DemonsField(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False):
         vel = _dev(vel, "velocity")
+        ctx.pair = bool(pair)
+        if pair:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))
+            vel = torch.cat([vel, -vel], 0)
         N, d = vel.shape[:2]
         s1 = raw_gauss(vel, d, pre=1, scale=scale)
         n = 8
@@ -614,13 +617,17 @@ class _DemonsField(torch.autograd.Function):
         ctx.cfg = (scale, tables, inv, d)
         ctx.nsteps = n
         ctx.hint_key = key
+        if pair:
+            return q[:N // 2], q[N // 2:]
         return q
 
     @staticmethod
-    def backward(ctx, gq):
+    def backward(ctx, *grads):
         pos, phi0, fields = ctx.saved_tensors
         scale, tables, inv, d = ctx.cfg
-        gq = _dev(gq, "grad")
+        # pair: one contiguous gradient for the batch [v; -v] (autograd's own route -- two slice_backward zero-fills of
+        # the whole batch, two copies and an add per chain -- cost more than the concatenation)
+        gq = torch.cat([_dev(g, "grad") for g in grads], 0) if ctx.pair else _dev(grads[0], "grad")
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
         ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
@@ -648,6 +655,9 @@ class _DemonsField(torch.autograd.Function):
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
         gvel = raw_gauss(gs1, d, pre=1, scale=scale)
+        if ctx.pair:
+            h = gvel.shape[0] // 2
+            gvel = gvel[:h] - gvel[h:]
         return gvel, None, None, None, None, None
 
 
@@ -677,8 +687,7 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
     N = vel.shape[0]
-    q2 = _DemonsField.apply(torch.cat([vel, -vel], 0), float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
-    qp, qm = q2[:N], q2[N:]
+    qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
         qp._advchain_disp = [rb, None, qp._version, idx, tuple(qp.shape[2:])]
