@@ -72,12 +72,13 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
                 c_a = c_b = 0.0
             coef = [(2 ** scale) * c for c in (c_mse, c_a, c_b)]
             val, _ = ops.consistency_sums(out_s, ref_s, m, coef, ref_is_prob=is_gt, want_edges=has_cnt)
-            dist = dist + val
+            dist = val if isinstance(dist, float) and dist == 0. else dist + val     # (0. + x is x: no launch for it)
         if 'kl' in divergence_types:
             w_kl = sum(w for t, w in zip(divergence_types, divergence_weights) if t == 'kl')
             kl = kl_divergence(pred=out_s, reference=ref_s, mask=mask, is_gt=is_gt, global_batch=global_batch)
             dist = dist + (2 ** scale) * (w_kl * kl)
-    return dist / (1.0 * len(scales))
+    # (x / 1.0 is x: the reference's division by the number of scales is skipped for its only call, scales = [0])
+    return dist if len(scales) == 1 else dist / (1.0 * len(scales))
 
 
 def kl_divergence(reference, pred, mask=None, is_gt=False, global_batch=None):
