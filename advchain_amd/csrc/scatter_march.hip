@@ -1,4 +1,5 @@
-// z-marching owner-computes scatter for the 3D sampler backward with an EXACT displacement bound of 2..4 voxels (gfx950).
+// Owner-computes scatters for the sampler backward with an EXACT displacement bound (gfx950): z-marching in 3D (bounds of
+// 2..4 voxels; 5..8 as one launch per channel, see the launcher), whole-row tiles in 2D (4, 8, 16 px; k_scatter_rows2d below).
 //
 // Above one voxel the gather form is too expensive ((2H+1)^3 tent products per output) and the source-tiled window
 // scatter (scatter_window.hip) pays for its freedom from any bound with global float atomics: every window cell is
@@ -9,8 +10,8 @@
 //     samples of plane zp in rows y0-H .. y0+TY+H-1 straight from global memory (coalesced 4-byte loads: a sample row
 //     is read once per workgroup, nothing to stage), builds their taps with the sampler's own arithmetic and deposits
 //     the corners that fall in ITS rows and ITS chunk into a ring of 2H+3 accumulator planes in LDS -- 32-bit fixed
-//     point, value * 2^20 / max|grad_out| over the rows the workgroup visits (LDS integer atomics run at LDS rate,
-//     LDS float atomics do not);
+//     point, value * 2^(21..23) / max|grad_out| over the rows the workgroup visits (march_fix_scale; LDS integer atomics
+//     run at LDS rate, LDS float atomics do not);
 //   * after plane zp the output plane zp-H has seen every sample that can reach it: it is converted, the coordinate
 //     path of its own samples is added (self-composition) or stored (grad_grid), and it leaves with PLAIN stores.
 // No global atomic, no zero-fill, fixed summation order up to the commutativity of integer adds: deterministic.
