@@ -580,6 +580,90 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
   *reinterpret_cast<float4*>(out + t) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// x and y passes in one launch: a workgroup owns TY whole rows of one (plane, z) slice, stages rows y0-4 .. y0+TY+3 with
+// the prologue applied, runs the x pass LDS -> LDS on all staged rows and the y pass LDS -> registers on its own.  One read
+// and one write of the tensor instead of two each; the x pass is done (TY+8)/TY times.  Same tap order per output as the
+// per-axis kernels (k = -4..4, x first).  POST belongs to the LAST pass: this kernel in 2D, the z pass in 3D.
+template <int PRE, int POST>
+__global__ void __launch_bounds__(kBlock)
+k_gauss_xy(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, Dims d, int C, GaussW gw,
+           float scale, int TY) {
+  extern __shared__ float gx_lds[];
+  const int W = d.s2, Q = W >> 2, PA = W + 8;
+  const int R = TY + 8;
+  float* A = gx_lds;                       // [R][PA]: 4 zeros | row | 4 zeros
+  float* B = gx_lds + R * PA;              // [R][W]
+  const int plane = blockIdx.z, iz = blockIdx.y;
+  const int y0 = blockIdx.x * TY;
+  const int caxis = 2 - plane % C;
+  const int Sc = caxis == 2 ? d.s2 : (caxis == 1 ? d.s1 : d.s0);
+  const int64_t base = ((int64_t)plane * d.s0 + iz) * d.s1 * (int64_t)W;
+  for (int e = threadIdx.x; e < R * 2; e += kBlock)
+    *reinterpret_cast<float4*>(A + (e >> 1) * PA + ((e & 1) ? W + 4 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- stage (unconditional loads from the clamped row, rows outside the volume zeroed by a select)
+  for (int e = threadIdx.x; e < R * Q; e += kBlock) {
+    const int r = e / Q, q = e - r * Q;
+    const int gy = y0 - 4 + r;
+    const bool inr = gy >= 0 && gy < d.s1;
+    const float4 v = *reinterpret_cast<const float4*>(in + base + (int64_t)min(max(gy, 0), d.s1 - 1) * W + 4 * q);
+    float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (PRE == 1) t[o] *= scale;
+      if (PRE == 2) {
+        float sl;
+        t[o] = border_identity(t[o], Sc, sl) - lin_coord(caxis == 2 ? 4 * q + o : (caxis == 1 ? gy : iz), Sc);
+      }
+      if (!inr) t[o] = 0.f;
+    }
+    *reinterpret_cast<float4*>(A + r * PA + 4 + 4 * q) = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  __syncthreads();
+  // ---- x pass on every staged row
+  for (int e = threadIdx.x; e < R * Q; e += kBlock) {
+    const int r = e / Q, q = e - r * Q;
+    const float* a = A + r * PA + 4 * q;                 // inputs x-4 .. x+7 of outputs x .. x+3
+    const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4),
+                 a2 = *reinterpret_cast<const float4*>(a + 8);
+    const float win[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[o] += gw.w[k] * win[o + k];
+    *reinterpret_cast<float4*>(B + r * W + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+  // ---- y pass on the owned rows
+  for (int e = threadIdx.x; e < TY * Q; e += kBlock) {
+    const int ry = e / Q, q = e - ry * Q;
+    const int gy = y0 + ry;
+    if (gy >= d.s1) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 b = *reinterpret_cast<const float4*>(B + (ry + k) * W + 4 * q);
+      acc[0] += gw.w[k] * b.x; acc[1] += gw.w[k] * b.y; acc[2] += gw.w[k] * b.z; acc[3] += gw.w[k] * b.w;
+    }
+    const int64_t off = base + (int64_t)gy * W + 4 * q;
+    if (POST == 1) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] += lin_coord(caxis == 2 ? 4 * q + o : (caxis == 1 ? gy : iz), Sc);
+    }
+    if (POST == 2) {
+      const float4 a4 = *reinterpret_cast<const float4*>(aux + off);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float slope;
+        border_identity(av[o], Sc, slope);
+        acc[o] *= slope;
+      }
+    }
+    *reinterpret_cast<float4*>(out + off) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
 // z pass, marching: a thread owns 4 consecutive x of one (plane, y) column and walks a chunk of ZC planes with the taps in
 // registers -- 1 + 8/ZC 16-byte loads per output instead of 9.  The per-output kernel above asks for every plane nine
 // times from workgroups that run on different XCDs at the same moment (no L2 reuse): at 8 x 3 x 160 x 160 x 80 the z pass
@@ -967,6 +1051,47 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
     default: GA(2, 2); break;
   }
 #undef GA
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// x and y passes of the separable Gaussian in one launch (rows of 4k <= 512 voxels, 16-byte aligned tensors).  `post` is
+// only legal when y is the last axis (ndim == 2).  Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify: the
+// caller then runs the per-axis passes.
+int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim, const int64_t* dims,
+                      const float* weights9, int pre, int post, float scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && in != out && weights9, "gauss_xy: null/aliased pointer");
+  ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_xy: bad dims");
+  ADVCHAIN_CHECK_ARG(C >= 1 && C <= 3 && pre >= 0 && pre <= 2 && post >= 0 && post <= 2 && (post != 2 || aux), "gauss_xy: bad C/pre/post");
+  ADVCHAIN_CHECK_ARG(post == 0 || ndim == 2, "gauss_xy: post belongs to the last axis");
+  const Dims d = fmake_dims(ndim, dims);
+  static const bool off = getenv("ADVCHAIN_NO_GAUSS_XY") != nullptr;   // A/B knob
+  if (off || (d.s2 & 3) != 0 || d.s2 < 8 || d.s2 > 512 || d.s1 < 8 || planes > 65535 || d.s0 > 65535 ||
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(aux)) & 15) != 0)
+    return ADVCHAIN_ERR_UNSUPPORTED;
+  if (planes == 0 || d.voxels() == 0) return ADVCHAIN_OK;
+  int TY = 32;
+  while (TY > 8 && (size_t)(TY + 8) * (2 * d.s2 + 8) * 4 > 53248) TY >>= 1;     // 52 KiB: three workgroups a CU
+  if (TY > d.s1) TY = (d.s1 + 7) / 8 * 8;
+  const size_t lds = (size_t)(TY + 8) * (2 * d.s2 + 8) * sizeof(float);
+  if (lds > 65536) return ADVCHAIN_ERR_UNSUPPORTED;
+  GaussW gw;
+  for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
+  dim3 grid((unsigned)((d.s1 + TY - 1) / TY), (unsigned)d.s0, (unsigned)planes);
+  hipStream_t st = (hipStream_t)stream;
+#define GXY(PRE, POST) hipLaunchKernelGGL((k_gauss_xy<PRE, POST>), grid, dim3(kBlock), lds, st, in, out, aux, d, (int)C, gw, scale, TY)
+  switch (pre * 3 + post) {
+    case 0: GXY(0, 0); break;
+    case 1: GXY(0, 1); break;
+    case 2: GXY(0, 2); break;
+    case 3: GXY(1, 0); break;
+    case 4: GXY(1, 1); break;
+    case 5: GXY(1, 2); break;
+    case 6: GXY(2, 0); break;
+    case 7: GXY(2, 1); break;
+    default: GXY(2, 2); break;
+  }
+#undef GXY
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

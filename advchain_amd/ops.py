@@ -219,6 +219,19 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
                    "gauss_small")
         return out
     cur = x
+    # x and y in one launch where the shape allows (advchain_gauss_xy); post belongs to the last axis
+    out = torch.empty_like(x)
+    rc = lib.advchain_gauss_xy(_ptr(x), _ptr(out), _ptr(aux) if (post == 2 and nd == 2) else None, planes, C, nd, dims, _GAUSS9,
+                               pre, post if nd == 2 else 0, float(scale) if pre == 1 else 1.0, _stream())
+    if rc == 0:
+        if nd == 2:
+            return out
+        out2 = torch.empty_like(x)
+        _lib.check(lib.advchain_gauss_axis(_ptr(out), _ptr(out2), _ptr(aux) if post == 2 else None, planes, C, nd, dims, 0,
+                                           _GAUSS9, 0, post, 1.0, _stream()), "gauss_axis")
+        return out2
+    if rc != -2:
+        _lib.check(rc, "gauss_xy")
     for i, ax in enumerate(axes):
         out = torch.empty_like(x)
         p = pre if i == 0 else 0

@@ -198,6 +198,12 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
                         const int64_t* dims, int axis, const float* weights9_host, int pre, int post, float scale,
                         void* stream);
 
+/* x and y passes of the Gaussian above in ONE launch (LDS tile of whole rows): one read and one write of the tensor
+ * instead of two each, bit-identical to the two per-axis calls.  post != 0 only when y is the last axis (ndim == 2).
+ * Returns -2 (unsupported, no error text) for shapes it does not take (rows not a multiple of 4 or longer than 512, unaligned
+ * tensors): run advchain_gauss_axis for axes 2 and 1 then.                                                             */
+int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim, const int64_t* dims,
+                      const float* weights9, int pre, int post, float scale, void* stream);
 /* all axes of the same Gaussian in ONE launch for small planes (<= 4096 voxels: the low-resolution velocity grids,
  * adv_morph.py:462-463); pre = 0 | 1 (x * scale), no epilogue; same arithmetic as the per-axis calls.              */
 int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
