@@ -583,7 +583,7 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
 // x and y passes in one launch: a workgroup owns TY whole rows of one (plane, z) slice, stages rows y0-4 .. y0+TY+3 with
 // the prologue applied, runs the x pass LDS -> LDS on all staged rows and the y pass LDS -> registers on its own.  One read
 // and one write of the tensor instead of two each; the x pass is done (TY+8)/TY times.  Same tap order per output as the
-// per-axis kernels (k = -4..4, x first).  POST belongs to the LAST pass: this kernel in 2D, the z pass in 3D.
+// per-axis kernels (k = -4..4, x first; multiply-adds are fused here, so results agree to a few ulp, not bit for bit).  POST belongs to the LAST pass: this kernel in 2D, the z pass in 3D.
 template <int PRE, int POST>
 __global__ void __launch_bounds__(kBlock)
 k_gauss_xy(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, Dims d, int C, GaussW gw,

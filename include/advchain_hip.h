@@ -199,7 +199,7 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
                         void* stream);
 
 /* x and y passes of the Gaussian above in ONE launch (LDS tile of whole rows): one read and one write of the tensor
- * instead of two each, bit-identical to the two per-axis calls.  post != 0 only when y is the last axis (ndim == 2).
+ * instead of two each; the same sums in the same tap order as the two per-axis calls (results agree to a few ulp).  post != 0 only when y is the last axis (ndim == 2).
  * Returns -2 (unsupported, no error text) for shapes it does not take (rows not a multiple of 4 or longer than 512, unaligned
  * tensors): run advchain_gauss_axis for axes 2 and 1 then.                                                             */
 int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim, const int64_t* dims,

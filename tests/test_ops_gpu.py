@@ -171,6 +171,33 @@ def test_gauss_small_planes_match_the_per_axis_passes(dims):
     assert maxdiff(fused.cpu(), O.gaussian_smooth(1.5 * x)) < 2e-6
 
 
+@pytest.mark.parametrize("dims", [(72, 96), (64, 256), (33, 80), (9, 40, 16), (35, 20, 80), (6, 70, 64)])
+@pytest.mark.parametrize("pre,post", [(0, 0), (1, 0), (2, 1), (0, 2)])
+def test_gauss_xy_launch_equals_the_per_axis_passes(dims, pre, post):
+    """advchain_gauss_xy (x and y passes in one launch, the route ops.raw_gauss takes) against the per-axis entry called
+    axis by axis: the same sums in the same order up to the contraction of multiply-adds (a few ulp), with the prologues / epilogues of the DemonsCompose forward (pre 2, post 1) and its
+    adjoint (post 2 with the positions as aux)."""
+    from oracle import advchain_oracle as O
+    from advchain_amd import _lib
+    ops = _ops()
+    d = len(dims)
+    x = (rand((2, d) + dims, 64) * 0.5 + (O.identity_grid(2, dims) if pre == 2 else 0)).contiguous().to(DEV)
+    aux = (O.identity_grid(2, dims) * 1.05 + 0.1 * rand((2, d) + dims, 65)).contiguous().to(DEV) if post == 2 else None
+    got = ops.raw_gauss(x, d, pre=pre, post=post, scale=1.5, aux=aux)
+    lib = _lib.load()
+    cur = x
+    axes = [2, 1, 0][:d]
+    for i, ax in enumerate(axes):
+        out = torch.empty_like(cur)
+        p = pre if i == 0 else 0
+        q = post if i == len(axes) - 1 else 0
+        _lib.check(lib.advchain_gauss_axis(ops._ptr(cur), ops._ptr(out), ops._ptr(aux) if q == 2 else None, 2 * d, d, d,
+                                           _lib.dims_array(dims), ax, ops._GAUSS9, p, q, 1.5 if p == 1 else 1.0, ops._stream()),
+                   "gauss_axis")
+        cur = out
+    assert maxdiff(got, cur) <= 5e-7 * max(1.0, float(cur.abs().max()))
+
+
 @pytest.mark.parametrize("dims", [(20, 28), (64, 256), (8, 12, 16), (16, 24, 64)])
 def test_displacement_measurements(dims):
     """advchain_max_displacement and the disp_out slots of advchain_compose_self_fwd report max |position - voxel|."""
