@@ -27,7 +27,7 @@ ENTRIES = {   # entry -> (regexes of the kernels an entry launch runs, regex of 
     "advchain_affine_warp_fwd": ([r"k_affine_warp_fwd<"], r"k_affine_warp_fwd<"),
     "advchain_affine_warp_bwd": ([r"k_affine_warp_bwd<", r"k_affine_gather_bwd<", r"k_affine_geometry<", r"k_reduce_partials"],
                                  r"k_affine_warp_bwd<"),
-    "advchain_gauss_axis": ([r"k_gauss_axis"], r"k_gauss_axis"),
+    "advchain_gauss_axis": ([r"k_gauss_axis", r"k_gauss_march_z", r"k_gauss_xy"], r"k_gauss_axis|k_gauss_march_z|k_gauss_xy"),   # per launch of any pass
     "advchain_tp_interp_fwd": ([r"k_tp_interp_fwd<"], r"k_tp_interp_fwd<"),
     "advchain_band_reduce_axis": ([r"k_band_reduce"], r"k_band_reduce"),
     "advchain_bias_field_fwd": ([r"k_bias_field_fwd|k_bias_fwd"], r"k_bias_field_fwd|k_bias_fwd"),
@@ -54,7 +54,7 @@ for _e, _self in (("advchain_grid_sample_bwd", "false"), ("advchain_compose_self
 ENTRIES["advchain_grid_sample_bwd"][0].append(r"k_march_rowmax<[14]>")
 ENTRIES["advchain_compose_self_bwd"][0].append(r"k_march_rowmax<[23]>")
 ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd"], r"k_affine_warp_fwd")
-WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_max_displacement|"
+WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
                   r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4")   # 16 B / lane
 MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
 
