@@ -613,7 +613,6 @@ class _DemonsField(torch.autograd.Function):
         # steps): picks the forward kernel per squaring, nothing else
         key = (tuple(vel.shape), n)
         hints = _CHAIN_HINTS.get(key)
-        hint = (lambda m: None) if hints is None else (lambda m: hints[m])
         phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
         fields = torch.empty((n - 1,) + tuple(phi0.shape), device=phi0.device, dtype=torch.float32)
@@ -695,11 +694,10 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
 def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     """(field(+scale * vel), field(-scale * vel)): the deformation and its approximate inverse, which one solver step
     always needs together (adv_morph.py:285-331), integrated as ONE batch [v; -v] -- half the launches, each twice the
-    size (the 2D kernels of a 40-image batch are too small to fill 256 CUs).  Per sample the arithmetic is that of two
+    size (the 2D kernels of a 32-image batch are too small to fill 256 CUs).  Per sample the arithmetic is that of two
     separate calls: -(s*v) == (-s)*v exactly, so the results are bit-identical to demons_field(vel, +-scale)."""
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
-    N = vel.shape[0]
     qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
