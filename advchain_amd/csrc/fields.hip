@@ -587,7 +587,7 @@ k_gauss_axis_v4(const float* __restrict__ in, float* __restrict__ out, const flo
 template <int PRE, int POST>
 __global__ void __launch_bounds__(kBlock)
 k_gauss_xy(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ aux, Dims d, int C, GaussW gw,
-           float scale, int TY) {
+           float scale, int TY, const float* __restrict__ in_hi, int planes_lo) {
   extern __shared__ float gx_lds[];
   const int W = d.s2, Q = W >> 2, PA = W + 8;
   const int R = TY + 8;
@@ -598,6 +598,8 @@ k_gauss_xy(const float* __restrict__ in, float* __restrict__ out, const float* _
   const int caxis = 2 - plane % C;
   const int Sc = caxis == 2 ? d.s2 : (caxis == 1 ? d.s1 : d.s0);
   const int64_t base = ((int64_t)plane * d.s0 + iz) * d.s1 * (int64_t)W;
+  // the input may come as two tensors (planes [0, planes_lo) and the rest): the two halves of a paired field's gradient
+  const float* src = (in_hi && plane >= planes_lo) ? in_hi + (((int64_t)(plane - planes_lo) * d.s0 + iz) * d.s1 * (int64_t)W) : in + base;
   for (int e = threadIdx.x; e < R * 2; e += kBlock)
     *reinterpret_cast<float4*>(A + (e >> 1) * PA + ((e & 1) ? W + 4 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
   // ---- stage (unconditional loads from the clamped row, rows outside the volume zeroed by a select)
@@ -605,7 +607,7 @@ k_gauss_xy(const float* __restrict__ in, float* __restrict__ out, const float* _
     const int r = e / Q, q = e - r * Q;
     const int gy = y0 - 4 + r;
     const bool inr = gy >= 0 && gy < d.s1;
-    const float4 v = *reinterpret_cast<const float4*>(in + base + (int64_t)min(max(gy, 0), d.s1 - 1) * W + 4 * q);
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)min(max(gy, 0), d.s1 - 1) * W + 4 * q);
     float t[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -1059,7 +1061,7 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
 // only legal when y is the last axis (ndim == 2).  Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify: the
 // caller then runs the per-axis passes.
 int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim, const int64_t* dims,
-                      const float* weights9, int pre, int post, float scale, void* stream) {
+                      const float* weights9, int pre, int post, float scale, void* stream, const float* in_hi, int64_t planes_lo) {
   ADVCHAIN_CHECK_ARG(in && out && in != out && weights9, "gauss_xy: null/aliased pointer");
   ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_xy: bad dims");
   ADVCHAIN_CHECK_ARG(C >= 1 && C <= 3 && pre >= 0 && pre <= 2 && post >= 0 && post <= 2 && (post != 2 || aux), "gauss_xy: bad C/pre/post");
@@ -1067,8 +1069,10 @@ int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t pla
   const Dims d = fmake_dims(ndim, dims);
   static const bool off = getenv("ADVCHAIN_NO_GAUSS_XY") != nullptr;   // A/B knob
   if (off || (d.s2 & 3) != 0 || d.s2 < 8 || d.s2 > 512 || d.s1 < 8 || planes > 65535 || d.s0 > 65535 ||
-      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(aux)) & 15) != 0)
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(aux) |
+        reinterpret_cast<uintptr_t>(in_hi)) & 15) != 0)
     return ADVCHAIN_ERR_UNSUPPORTED;
+  ADVCHAIN_CHECK_ARG(!in_hi || (planes_lo > 0 && planes_lo < planes), "gauss_xy: bad split of the input planes");
   if (planes == 0 || d.voxels() == 0) return ADVCHAIN_OK;
   int TY = 32;
   while (TY > 8 && (size_t)(TY + 8) * (2 * d.s2 + 8) * 4 > 53248) TY >>= 1;     // 52 KiB: three workgroups a CU
@@ -1079,7 +1083,7 @@ int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t pla
   for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
   dim3 grid((unsigned)((d.s1 + TY - 1) / TY), (unsigned)d.s0, (unsigned)planes);
   hipStream_t st = (hipStream_t)stream;
-#define GXY(PRE, POST) hipLaunchKernelGGL((k_gauss_xy<PRE, POST>), grid, dim3(kBlock), lds, st, in, out, aux, d, (int)C, gw, scale, TY)
+#define GXY(PRE, POST) hipLaunchKernelGGL((k_gauss_xy<PRE, POST>), grid, dim3(kBlock), lds, st, in, out, aux, d, (int)C, gw, scale, TY, in_hi, (int)planes_lo)
   switch (pre * 3 + post) {
     case 0: GXY(0, 0); break;
     case 1: GXY(0, 1); break;

@@ -207,12 +207,22 @@ def _halo_2d(disp):
 
 
 def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
-    """Separable 9-tap Gaussian over all spatial axes of x (planes = x.shape[0]*x.shape[1])."""
+    """Separable 9-tap Gaussian over all spatial axes of x (planes = x.shape[0]*x.shape[1]).  `x` may be a pair of
+    tensors (the two halves of a batch, e.g. the gradients of a paired field): the fused x+y launch reads both in place,
+    any other route concatenates them first."""
+    x_hi = None
+    if isinstance(x, (tuple, list)):
+        x, x_hi = x
+        shape = (x.shape[0] + x_hi.shape[0],) + tuple(x.shape[1:])
+    else:
+        shape = tuple(x.shape)
     nd = x.dim() - 2
-    planes = x.shape[0] * x.shape[1]
+    planes = shape[0] * shape[1]
     dims = _lib.dims_array(x.shape[2:])
     axes = [2, 1, 0][:nd]  # innermost first (padded 3-axis numbering)
     lib = _lib.load()
+    if x_hi is not None and (x[0, 0].numel() <= 4096 or not (x.is_contiguous() and x_hi.is_contiguous())):
+        x, x_hi = torch.cat([x, x_hi], 0), None
     if post == 0 and pre in (0, 1) and x[0, 0].numel() <= 4096:     # low-resolution grids: all axes in one launch
         out = torch.empty_like(x)
         _lib.check(lib.advchain_gauss_small(_ptr(x), _ptr(out), planes, nd, dims, _GAUSS9, pre, float(scale), _stream()),
@@ -220,18 +230,21 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
         return out
     cur = x
     # x and y in one launch where the shape allows (advchain_gauss_xy); post belongs to the last axis
-    out = torch.empty_like(x)
+    out = torch.empty(shape, device=x.device, dtype=torch.float32)
     rc = lib.advchain_gauss_xy(_ptr(x), _ptr(out), _ptr(aux) if (post == 2 and nd == 2) else None, planes, C, nd, dims, _GAUSS9,
-                               pre, post if nd == 2 else 0, float(scale) if pre == 1 else 1.0, _stream())
+                               pre, post if nd == 2 else 0, float(scale) if pre == 1 else 1.0, _stream(), _ptr(x_hi),
+                               x.shape[0] * x.shape[1])
     if rc == 0:
         if nd == 2:
             return out
-        out2 = torch.empty_like(x)
+        out2 = torch.empty_like(out)
         _lib.check(lib.advchain_gauss_axis(_ptr(out), _ptr(out2), _ptr(aux) if post == 2 else None, planes, C, nd, dims, 0,
                                            _GAUSS9, 0, post, 1.0, _stream()), "gauss_axis")
         return out2
     if rc != -2:
         _lib.check(rc, "gauss_xy")
+    if x_hi is not None:
+        x = cur = torch.cat([x, x_hi], 0)
     for i, ax in enumerate(axes):
         out = torch.empty_like(x)
         p = pre if i == 0 else 0
@@ -639,10 +652,10 @@ class _DemonsField(torch.autograd.Function):
         scale, tables, inv, d = ctx.cfg
         # pair: one contiguous gradient for the batch [v; -v] (autograd's own route -- two slice_backward zero-fills of
         # the whole batch, two copies and an add per chain -- cost more than the concatenation)
-        gq = torch.cat([_dev(g, "grad") for g in grads], 0) if ctx.pair else _dev(grads[0], "grad")
+        gq = tuple(_dev(g, "grad") for g in grads) if ctx.pair else _dev(grads[0], "grad")
         gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
-        ws = _scatter_workspace(gq.shape[0], gq.shape[2:], gq.device) if TILED_SCATTER else None
+        ws = _scatter_workspace(gpos.shape[0], gpos.shape[2:], gpos.device) if TILED_SCATTER else None
         # squaring m composes a field whose displacement is ~2^(m-n) of the total: the early steps are sub-voxel and
         # take the gather-form adjoint.  The bound is a performance hint only (larger displacements stay correct
         # through the overflow list); it comes from the displacement measured in forward (one 4-byte read-back).

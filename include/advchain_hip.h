@@ -201,9 +201,12 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
 /* x and y passes of the Gaussian above in ONE launch (LDS tile of whole rows): one read and one write of the tensor
  * instead of two each; the same sums in the same tap order as the two per-axis calls (results agree to a few ulp).  post != 0 only when y is the last axis (ndim == 2).
  * Returns -2 (unsupported, no error text) for shapes it does not take (rows not a multiple of 4 or longer than 512, unaligned
- * tensors): run advchain_gauss_axis for axes 2 and 1 then.                                                             */
+ * tensors): run advchain_gauss_axis for axes 2 and 1 then.
+ * in_hi (may be NULL): the input planes [planes_lo, planes) come from this second tensor (the gradient of a paired field
+ * arrives as two halves), in: planes [0, planes_lo).                                                                    */
 int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim, const int64_t* dims,
-                      const float* weights9, int pre, int post, float scale, void* stream);
+                      const float* weights9, int pre, int post, float scale, void* stream, const float* in_hi,
+                      int64_t planes_lo);
 /* all axes of the same Gaussian in ONE launch for small planes (<= 4096 voxels: the low-resolution velocity grids,
  * adv_morph.py:462-463); pre = 0 | 1 (x * scale), no epilogue; same arithmetic as the per-axis calls.              */
 int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
