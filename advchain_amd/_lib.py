@@ -40,8 +40,8 @@ PROTOTYPES = {
     "advchain_axpy": (_I, [_P, _P, _P, _F, _L, _P]),
     "advchain_norm_workspace": (_L, [_L, _L]),
     "advchain_norm_axpy": (_I, [_P, _P, _P, _P, _F, _L, _L, _P]),
-    "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _P]),
-    "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _I, _P, _I, _P]),
+    "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
+    "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
 }
 
 _lib = None

@@ -142,10 +142,23 @@ class AdvMorph(AdvTransformBase):
         self._field_cache = {}
 
     def DemonsCompose(self, duv, init_deformation_dxy=None, smooth=True):
-        """Clamped sampling grid (N,d,...) for an explicit low-res velocity (adv_morph.py:454-491)."""
-        if init_deformation_dxy is not None or not smooth:
-            raise NotImplementedError('DemonsCompose: only the call the reference itself makes is implemented '
-                                      '(init_deformation_dxy=None, smooth=True; adv_morph.py:299-303,322-324)')
+        """Clamped sampling grid (N,d,...) for an explicit low-res velocity (adv_morph.py:454-491).
+
+        The reference's own (and only) call is ``DemonsCompose(duv=duv, init_deformation_dxy=self.base_grid,
+        smooth=True)`` (adv_morph.py:299-303,322-324,342-343): composition with the IDENTITY grid, which is what the HIP
+        chain implements.  ``init_deformation_dxy`` may therefore be None or the identity grid (``self.base_grid`` itself
+        or a tensor equal to it); a genuinely different initial deformation raises."""
+        if init_deformation_dxy is not None and init_deformation_dxy is not self._base_grid:
+            base = self.base_grid
+            if (tuple(init_deformation_dxy.shape) != tuple(base.shape)
+                    or not torch.equal(init_deformation_dxy.to(base.device), base)):
+                raise NotImplementedError('DemonsCompose: init_deformation_dxy must be the identity grid '
+                                          '(self.base_grid, as in every call of the reference: adv_morph.py:299-303,'
+                                          '322-324,342-343) or None; composing with another initial deformation is not '
+                                          'implemented by the HIP chain')
+        if not smooth:
+            raise NotImplementedError('DemonsCompose: smooth=False is not implemented (every call of the reference passes '
+                                      'smooth=True; adv_morph.py:299-303,322-324,342-343)')
         if (self.sigma, self.num_steps, self.smooth_iter, self.integration_type) != (1, 8, 1, 'ss'):
             raise NotImplementedError('DemonsCompose: the HIP chain implements the reference defaults only '
                                       '(sigma=1, num_steps=8, smooth_iter=1, integration_type="ss"; adv_morph.py:236-242)')

@@ -1,14 +1,12 @@
 """Segmentation-consistency loss (reference: advchain/common/loss.py:8-249).
 
-'mse' and 'contour' -- the solver's defaults -- run in the fused HIP kernels
-(:func:`advchain_amd.ops.consistency_sums`: softmax + mask + squared error + 3^d edge stencils in two
-launches forward, one backward).  'kl' (optional, non-default) is composed from tensor ops.
+'mse', 'contour' and 'kl' all run in the fused HIP kernels (:func:`advchain_amd.ops.consistency_sums`:
+softmax + mask + squared error + KL sum + 3^d edge stencils in two launches forward, one backward).
 
 Batch sharding: ``global_batch`` overrides N in every normaliser -- mse ~ 1/(N^2 K V^2),
 contour ~ 1/(N V) -- so that the per-shard values SUM to the whole-batch loss and the mse:contour mix
 (hence the ascent direction) does not depend on the shard size."""
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 
@@ -55,8 +53,9 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
                 raise NotImplementedError
         has_mse = 'mse' in divergence_types
         has_cnt = 'contour' in divergence_types and K > 1
+        has_kl = 'kl' in divergence_types
         m = _single_channel_mask(mask if scale == 0 else (None if mask is None else mask), K)
-        if has_mse or has_cnt:
+        if has_mse or has_cnt or has_kl:
             # 'mse': MSELoss(mean) over N*K*V elements, divided again by numel(mask)/K (loss.py:62-64, Q13): N*V for the
             # default all-ones / K-channel mask, N*V/K for a caller's 1-channel mask (an expanded view counts as K)
             mask_ch = K if mask is None else mask.shape[1]
@@ -70,34 +69,26 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
                     c_b = w_cnt * (1.0 / 3.0) / (float(Ng) * V * (K - 1))
             else:
                 c_a = c_b = 0.0
-            coef = [(2 ** scale) * c for c in (c_mse, c_a, c_b)]
+            # 'kl': mean over the N*V voxels of sum_k m_k p_k (log p_k - log q_k)  (loss.py:244-248)
+            w_kl = sum(w for t, w in zip(divergence_types, divergence_weights) if t == 'kl')
+            c_kl = (w_kl / (float(Ng) * V)) if has_kl else 0.0
+            coef = [(2 ** scale) * c for c in (c_mse, c_a, c_b, c_kl)]
             val, _ = ops.consistency_sums(out_s, ref_s, m, coef, ref_is_prob=is_gt, want_edges=has_cnt)
             dist = val if isinstance(dist, float) and dist == 0. else dist + val     # (0. + x is x: no launch for it)
-        if 'kl' in divergence_types:
-            w_kl = sum(w for t, w in zip(divergence_types, divergence_weights) if t == 'kl')
-            kl = kl_divergence(pred=out_s, reference=ref_s, mask=mask, is_gt=is_gt, global_batch=global_batch)
-            dist = dist + (2 ** scale) * (w_kl * kl)
     # (x / 1.0 is x: the reference's division by the number of scales is skipped for its only call, scales = [0])
     return dist if len(scales) == 1 else dist / (1.0 * len(scales))
 
 
 def kl_divergence(reference, pred, mask=None, is_gt=False, global_batch=None):
-    """KL(P||Q) of two logit maps (loss.py:223-249).  Optional term, tensor ops."""
-    q = pred
-    if mask is None:
-        mask = torch.ones_like(q)
-    if not is_gt:
-        p = F.softmax(reference, dim=1)
-        log_p = F.log_softmax(reference, dim=1)
-    else:
-        p = torch.where(reference == 0, 1e-8, 1 - 1e-8)
-        log_p = torch.log(p)
-    plogp = torch.sum(mask * (p * log_p), dim=1)
-    plogq = torch.sum(mask * (p * F.log_softmax(q, dim=1)), dim=1)
-    if global_batch is None:
-        return torch.mean(plogp - plogq)
-    per_sample = (plogp - plogq).numel() // q.shape[0]
-    return torch.sum(plogp - plogq) / (float(global_batch) * per_sample)
+    """KL(P||Q) of two logit maps (loss.py:223-249): the 'kl' term of the fused kernels on its own."""
+    K = pred.size(1)
+    V = 1
+    for s in pred.shape[2:]:
+        V *= s
+    Ng = pred.shape[0] if global_batch is None else int(global_batch)
+    val, _ = ops.consistency_sums(pred, reference, _single_channel_mask(mask, K), [0.0, 0.0, 0.0, 1.0 / (float(Ng) * V)],
+                                  ref_is_prob=is_gt, want_edges=False)
+    return val
 
 
 def calc_segmentation_mse_consistency(input, target):

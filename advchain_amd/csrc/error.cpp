@@ -10,4 +10,4 @@ extern "C" void advchain_set_error_(const char* msg) {
 
 extern "C" const char* advchain_last_error(void) { return g_last_error; }
 
-extern "C" int advchain_version(void) { return 100; }  // 0.1.0
+extern "C" int advchain_version(void) { return 110; }  // 0.1.1: consistency_fwd/bwd carry the kl term

@@ -10,6 +10,10 @@
 //             conv_y in the reference), B = h (x) h (x) hp;  sums[1] = sum (A*D m)^2, sums[2] = sum (B*D m)^2
 //           R = 2 m^2 (A*D), 2 m^2 (B*D)   (kept for the backward)
 // backward: grad_pred = softmax'(P) [ gs * ( c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B ) ]
+// 'kl' term (loss.py:223-249), folded into the same kernels: with T' = softmax(ref) (is_gt: where(ref == 0, 1e-8, 1 - 1e-8)),
+//           sums[3] = sum_k m_k T'_k (log T'_k - log P_k)   (log-softmax from the max / log-sum-exp already in registers);
+//           its gradient w.r.t. the logits is added behind the softmax Jacobian:  gs c_kl (P_j sum_k m_k T'_k - m_j T'_j),
+//           T' recovered from the saved P and D (T = P - D).
 // The caller owns the normalisers (global N under batch sharding).
 // Streaming + 3^d stencil: HBM-bound, no MFMA.
 #include <stdlib.h>
@@ -35,14 +39,22 @@ __device__ __forceinline__ void stencil_w(int a0, int a1, int a2, float& wa, flo
   }
 }
 
+// 'kl' (loss.py:239-248): m * p * (log p - log q).  is_gt: p = where(ref == 0, 1e-8, 1 - 1e-8) (= 1.0f in fp32), log p = log(p)
+__device__ __forceinline__ float kl_prob(float t, int is_gt) { return is_gt ? (t == 0.f ? 1e-8f : 1.f) : t; }
+__device__ __forceinline__ float kl_term(float t, float log_t, float log_q, float m, int is_gt) {
+  const float p = kl_prob(t, is_gt);
+  const float lp = is_gt ? logf(p) : log_t;
+  return m * (p * lp) - m * (p * log_q);
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
                float* __restrict__ P, float* __restrict__ D, float* __restrict__ sums, int K, int V, int mask_ch,
-               int ref_is_prob) {
-  __shared__ float smem[4];
+               int ref_is_prob, int want_kl) {
+  __shared__ float smem[8];
   const int n = blockIdx.y;
   const int v = blockIdx.x * kBlock + threadIdx.x;
-  float acc[1] = {0.f};
+  float acc[2] = {0.f, 0.f};
   if (v < V) {
     const float* pn = pred + (int64_t)n * K * V + v;
     const float* rn = ref + (int64_t)n * K * V + v;
@@ -56,19 +68,25 @@ k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, co
       sp += expf(pn[(int64_t)k * V] - mp);
       sr += expf(rn[(int64_t)k * V] - mr);
     }
+    const float lsp = logf(sp), lsr = logf(sr);
     for (int k = 0; k < K; ++k) {
-      const float p = expf(pn[(int64_t)k * V] - mp) / sp;
-      const float t = ref_is_prob ? rn[(int64_t)k * V] : expf(rn[(int64_t)k * V] - mr) / sr;
+      const float zp = pn[(int64_t)k * V] - mp, zr = rn[(int64_t)k * V] - mr;
+      const float p = expf(zp) / sp;
+      const float t = ref_is_prob ? rn[(int64_t)k * V] : expf(zr) / sr;
       const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
       const int64_t o = ((int64_t)n * K + k) * V + v;
       P[o] = p;
       D[o] = p - t;
       const float e = p * m - t * m;
       acc[0] += e * e;
+      if (want_kl) acc[1] += kl_term(t, zr - lsr, zp - lsp, m, ref_is_prob);
     }
   }
-  block_sum<1>(acc, smem);
-  if (threadIdx.x == 0) atomic_add_f32(sums + sum_slot(), acc[0]);
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + sum_slot(), acc[0]);
+    if (want_kl) atomic_add_f32(sums + 3 * kSumSlots + sum_slot(), acc[1]);
+  }
 }
 
 // K known at compile time, V % 4 == 0: 4 voxels per thread with 16-byte loads and stores, every input read once
@@ -78,11 +96,11 @@ template <int K>
 __global__ void __launch_bounds__(kBlock)
 k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
                   float* __restrict__ P, float* __restrict__ D, float* __restrict__ sums, int V, int mask_ch,
-                  int ref_is_prob) {
-  __shared__ float smem[4];
+                  int ref_is_prob, int want_kl) {
+  __shared__ float smem[8];
   const int n = blockIdx.y;
   const int v = (blockIdx.x * kBlock + threadIdx.x) * 4;
-  float acc[1] = {0.f};
+  float acc[2] = {0.f, 0.f};
   if (v < V) {
     float p[K][4], r[K][4];
 #pragma unroll
@@ -105,10 +123,12 @@ k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref,
       float sp = 0.f, sr = 0.f;
 #pragma unroll
       for (int k = 0; k < K; ++k) { sp += expf(p[k][q] - mp); sr += expf(r[k][q] - mr); }
+      const float lsp = want_kl ? logf(sp) : 0.f, lsr = want_kl ? logf(sr) : 0.f;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float pp = expf(p[k][q] - mp) / sp;
-        const float tt = ref_is_prob ? r[k][q] : expf(r[k][q] - mr) / sr;
+        const float zp = p[k][q] - mp, zr = r[k][q] - mr;
+        const float pp = expf(zp) / sp;
+        const float tt = ref_is_prob ? r[k][q] : expf(zr) / sr;
         p[k][q] = pp;
         r[k][q] = pp - tt;          // D
         const float tq = tt;
@@ -116,6 +136,7 @@ k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref,
         if (mask && mask_ch > 1) m = mask[((int64_t)n * mask_ch + k) * V + v + q];
         const float e = pp * m - tq * m;
         acc[0] += e * e;
+        if (want_kl) acc[1] += kl_term(tt, zr - lsr, zp - lsp, m, ref_is_prob);
       }
     }
 #pragma unroll
@@ -125,8 +146,11 @@ k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref,
       *reinterpret_cast<float4*>(D + o) = make_float4(r[k][0], r[k][1], r[k][2], r[k][3]);
     }
   }
-  block_sum<1>(acc, smem);
-  if (threadIdx.x == 0) atomic_add_f32(sums + sum_slot(), acc[0]);
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + sum_slot(), acc[0]);
+    if (want_kl) atomic_add_f32(sums + 3 * kSumSlots + sum_slot(), acc[1]);
+  }
 }
 
 template <int DIM>
@@ -185,7 +209,7 @@ template <int DIM>
 __global__ void __launch_bounds__(kBlock)
 k_consistency_bwd(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
                   const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
-                  float c_mse, float c_a, float c_b, int K, Dims d, int mask_ch) {
+                  float c_mse, float c_a, float c_b, int K, Dims d, int mask_ch, float c_kl, int kl_gt) {
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
   const int v = blockIdx.x * kBlock + threadIdx.x;
@@ -196,7 +220,7 @@ k_consistency_bwd(const float* __restrict__ P, const float* __restrict__ D, cons
   const int i0 = r / d.s1;
   const float gs = gscale ? gscale[0] : 1.f;
   float gp[kMaxK];
-  float dot = 0.f;
+  float dot = 0.f, klS = 0.f;
   for (int k = 0; k < K; ++k) {
     const int64_t o = ((int64_t)n * K + k) * V + v;
     const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
@@ -226,10 +250,16 @@ k_consistency_bwd(const float* __restrict__ P, const float* __restrict__ D, cons
     g *= gs;
     gp[k] = g;
     dot += g * P[o];
+    if (c_kl != 0.f) klS += m * kl_prob(P[o] - D[o], kl_gt);
   }
   for (int k = 0; k < K; ++k) {
     const int64_t o = ((int64_t)n * K + k) * V + v;
-    gpred[o] = P[o] * (gp[k] - dot);
+    float g = P[o] * (gp[k] - dot);
+    if (c_kl != 0.f) {   // 'kl': gs c_kl (P_j sum_k m_k T'_k - m_j T'_j)
+      const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
+      g += gs * c_kl * (P[o] * klS - m * kl_prob(P[o] - D[o], kl_gt));
+    }
+    gpred[o] = g;
   }
 }
 
@@ -314,7 +344,7 @@ template <int DIM>
 __global__ void __launch_bounds__(kBlock)
 k_consistency_bwd_rows(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
                        const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
-                       float c_mse, float c_a, float c_b, int K, Dims d, int mask_ch) {
+                       float c_mse, float c_a, float c_b, int K, Dims d, int mask_ch, float c_kl, int kl_gt) {
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
   const int v = blockIdx.x * kBlock + threadIdx.x;
@@ -325,7 +355,7 @@ k_consistency_bwd_rows(const float* __restrict__ P, const float* __restrict__ D,
   const int i0 = r / d.s1;
   const float gs = gscale ? gscale[0] : 1.f;
   float gp[kMaxK];
-  float dot = 0.f;
+  float dot = 0.f, klS = 0.f;
   for (int k = 0; k < K; ++k) {
     const int64_t o = ((int64_t)n * K + k) * V + v;
     const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
@@ -355,10 +385,16 @@ k_consistency_bwd_rows(const float* __restrict__ P, const float* __restrict__ D,
     g *= gs;
     gp[k] = g;
     dot += g * P[o];
+    if (c_kl != 0.f) klS += m * kl_prob(P[o] - D[o], kl_gt);
   }
   for (int k = 0; k < K; ++k) {
     const int64_t o = ((int64_t)n * K + k) * V + v;
-    gpred[o] = P[o] * (gp[k] - dot);
+    float g = P[o] * (gp[k] - dot);
+    if (c_kl != 0.f) {   // 'kl': gs c_kl (P_j sum_k m_k T'_k - m_j T'_j)
+      const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
+      g += gs * c_kl * (P[o] * klS - m * kl_prob(P[o] - D[o], kl_gt));
+    }
+    gpred[o] = g;
   }
 }
 
@@ -449,11 +485,11 @@ k_edge_fwd_march(const float* __restrict__ D, const float* __restrict__ mask, fl
   }
 }
 
-template <int DIM, int K>
+template <int DIM, int K, bool KL>
 __global__ void __launch_bounds__(kBlock)
 k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
                         const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
-                        float c_mse, float c_a, float c_b, Dims d, int mask_ch) {
+                        float c_mse, float c_a, float c_b, Dims d, int mask_ch, float c_kl, int kl_gt) {
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
   int i0, y0, x;
@@ -479,13 +515,14 @@ k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D
   const int y1 = min(y0 + kMarch, d.s1);
   for (int i1 = y0; i1 < y1; ++i1) {
     const int v = (i0 * d.s1 + i1) * d.s2 + x;
-    float gp[K], pk[K];
-    float dot = 0.f;
+    float gp[K], pk[K], mt[KL ? K : 1];
+    float dot = 0.f, klS = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int64_t o = ((int64_t)n * K + k) * V + v;
       const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
-      float g = c_mse * 2.f * m * m * D[o];
+      const float dk = D[o];
+      float g = c_mse * 2.f * m * m * dk;
       if (k >= 1 && R) {
         fold(k, i1 + 1, za[k - 1][2], zb[k - 1][2]);
         // adjoint: tap a1 reads row i1 - (a1 - 1)
@@ -505,9 +542,14 @@ k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D
       gp[k] = g;
       pk[k] = P[o];
       dot += g * pk[k];
+      if (KL) { mt[k] = m * kl_prob(pk[k] - dk, kl_gt); klS += mt[k]; }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) gpred[((int64_t)n * K + k) * V + v] = pk[k] * (gp[k] - dot);
+    for (int k = 0; k < K; ++k) {
+      float g = pk[k] * (gp[k] - dot);
+      if (KL) g += gs * c_kl * (pk[k] * klS - mt[k]);
+      gpred[((int64_t)n * K + k) * V + v] = g;
+    }
   }
 }
 
@@ -629,11 +671,11 @@ k_edge_fwd_march4(const float* __restrict__ D, const float* __restrict__ mask, f
   }
 }
 
-template <int DIM, int K>
+template <int DIM, int K, bool KL>
 __global__ void __launch_bounds__(kBlock)
 k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ D, const float* __restrict__ R,
                          const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
-                         float c_mse, float c_a, float c_b, Dims d, int mask_ch, int mlen) {
+                         float c_mse, float c_a, float c_b, Dims d, int mask_ch, int mlen, float c_kl, int kl_gt) {
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
   int i0, y0, x;
@@ -662,8 +704,8 @@ k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ 
   const int y1 = min(y0 + mlen, d.s1);
   for (int i1 = y0; i1 < y1; ++i1) {
     const int v = (i0 * d.s1 + i1) * d.s2 + x;
-    float gp[K][4], pk[K][4];
-    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    float gp[K][4], pk[K][4], mt[KL ? K : 1][4];
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, klS[4] = {0.f, 0.f, 0.f, 0.f};
     float m1[4] = {1.f, 1.f, 1.f, 1.f};
     if (mask && mask_ch == 1) {
       const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
@@ -699,6 +741,7 @@ k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ 
         g *= gs;
         gp[k][q] = g;
         dot[q] += g * pk[k][q];
+        if (KL) { mt[k][q] = m[q] * kl_prob(pk[k][q] - dv[q], kl_gt); klS[q] += mt[k][q]; }
       }
       if (k >= 1 && R) {
         za[k - 1][0] = za[k - 1][1]; za[k - 1][1] = za[k - 1][2];
@@ -707,10 +750,15 @@ k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ 
     }
     if (ok) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) =
-            make_float4(pk[k][0] * (gp[k][0] - dot[0]), pk[k][1] * (gp[k][1] - dot[1]), pk[k][2] * (gp[k][2] - dot[2]),
-                        pk[k][3] * (gp[k][3] - dot[3]));
+      for (int k = 0; k < K; ++k) {
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o4[q] = pk[k][q] * (gp[k][q] - dot[q]);
+          if (KL) o4[q] += gs * c_kl * (pk[k][q] * klS[q] - mt[k][q]);
+        }
+        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
     }
   }
 }
@@ -775,25 +823,47 @@ static bool launch_edge_march(int64_t K, int64_t N, const Dims& d, hipStream_t s
 template <int DIM>
 static bool launch_bwd_march(int64_t K, int64_t N, const Dims& d, hipStream_t st, const float* P, const float* D,
                              const float* R, const float* mask, const float* gscale, float* gpred, float c_mse,
-                             float c_a, float c_b, int mask_ch, bool rows) {
+                             float c_a, float c_b, int mask_ch, bool rows, float c_kl, int kl_gt) {
+  const bool kl = c_kl != 0.f;
   if (g_no_march) return false;
   if (march4_ok(d, P, D, R, mask) && (reinterpret_cast<uintptr_t>(gpred) & 15) == 0) {
     const int mlen = march4_len(d, N);
     const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
     switch (K) {
-      case 2: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 2>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
-      case 3: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 3>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
-      case 4: hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 4>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen); return true;
+      case 2:
+        if (kl) hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 2, true>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        else hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 2, false>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        return true;
+      case 3:
+        if (kl) hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 3, true>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        else hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 3, false>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        return true;
+      case 4:
+        if (kl) hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 4, true>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        else hipLaunchKernelGGL((k_consistency_bwd_march4<DIM, 4, false>), g4, b4, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, mlen, c_kl, kl_gt);
+        return true;
       default: break;   // K = 5: the scalar march (register budget)
     }
   }
   if (!rows) return false;   // the scalar march needs whole waves per row (S2 % 64 == 0)
   const dim3 g = march_grid(d, N), b(kBlock);
   switch (K) {
-    case 2: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 2>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
-    case 3: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 3>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
-    case 4: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 4>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
-    case 5: hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 5>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch); return true;
+    case 2:
+      if (kl) hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 2, true>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      else hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 2, false>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      return true;
+    case 3:
+      if (kl) hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 3, true>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      else hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 3, false>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      return true;
+    case 4:
+      if (kl) hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 4, true>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      else hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 4, false>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      return true;
+    case 5:
+      if (kl) hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 5, true>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      else hipLaunchKernelGGL((k_consistency_bwd_march<DIM, 5, false>), g, b, 0, st, P, D, R, mask, gscale, gpred, c_mse, c_a, c_b, d, mask_ch, c_kl, kl_gt);
+      return true;
     default: return false;
   }
 }
@@ -815,7 +885,7 @@ extern "C" {
 
 int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
                              float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
-                             int ref_is_prob, int want_edges, void* stream) {
+                             int ref_is_prob, int want_edges, int want_kl, void* stream) {
   ADVCHAIN_CHECK_ARG(pred && ref && P && D && sums, "consistency_fwd: null pointer");
   ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_fwd: bad N/K (K <= 16)");
@@ -831,13 +901,13 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
   if (V % 4 == 0 && al16 && K >= 2 && K <= 5) {
     dim3 g4(advchain_blocks(V / 4, kBlock), (unsigned)N);
     switch (K) {
-      case 2: hipLaunchKernelGGL(k_softmax_diff_v4<2>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
-      case 3: hipLaunchKernelGGL(k_softmax_diff_v4<3>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
-      case 4: hipLaunchKernelGGL(k_softmax_diff_v4<4>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
-      default: hipLaunchKernelGGL(k_softmax_diff_v4<5>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob); break;
+      case 2: hipLaunchKernelGGL(k_softmax_diff_v4<2>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob, want_kl); break;
+      case 3: hipLaunchKernelGGL(k_softmax_diff_v4<3>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob, want_kl); break;
+      case 4: hipLaunchKernelGGL(k_softmax_diff_v4<4>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob, want_kl); break;
+      default: hipLaunchKernelGGL(k_softmax_diff_v4<5>, g4, b, 0, st, pred, ref, mask, P, D, sums, V, mask_channels, ref_is_prob, want_kl); break;
     }
   } else {
-    hipLaunchKernelGGL(k_softmax_diff, g, b, 0, st, pred, ref, mask, P, D, sums, (int)K, V, mask_channels, ref_is_prob);
+    hipLaunchKernelGGL(k_softmax_diff, g, b, 0, st, pred, ref, mask, P, D, sums, (int)K, V, mask_channels, ref_is_prob, want_kl);
   }
   if (want_edges && K > 1) {
     const bool rows = (d.s2 % 64) == 0;   // lane <-> x with whole waves per row: DPP neighbour exchange
@@ -856,8 +926,9 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
 }
 
 int advchain_consistency_bwd(const float* P, const float* D, const float* R, const float* mask,
-                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
-                             int64_t K, int ndim, const int64_t* dims, int mask_channels, void* stream) {
+                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, float c_kl,
+                             int kl_is_gt, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                             void* stream) {
   ADVCHAIN_CHECK_ARG(P && D && grad_pred, "consistency_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_bwd: bad N/K (K <= 16)");
@@ -869,13 +940,13 @@ int advchain_consistency_bwd(const float* P, const float* D, const float* R, con
   hipStream_t st = (hipStream_t)stream;
   const bool rows = (d.s2 % 64) == 0;
   if (ndim == 3) {
-    if (launch_bwd_march<3>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows)) {}
-    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
-    else hipLaunchKernelGGL(k_consistency_bwd<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+    if (launch_bwd_march<3>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows, c_kl, kl_is_gt)) {}
+    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
+    else hipLaunchKernelGGL(k_consistency_bwd<3>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
   } else {
-    if (launch_bwd_march<2>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows)) {}
-    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
-    else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels);
+    if (launch_bwd_march<2>(K, N, d, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, mask_channels, rows, c_kl, kl_is_gt)) {}
+    else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
+    else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;

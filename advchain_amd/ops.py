@@ -736,8 +736,9 @@ def _coef_vector(coef, device):
 
 
 class _Consistency(torch.autograd.Function):
-    """c_mse * S0 + c_a * SA + c_b * SB  with  S0 = sum((P m - T m)^2), SA/SB = masked edge energies
-    (advchain/common/loss.py:55-79,102-220).  Differentiable w.r.t. the prediction logits only."""
+    """c_mse * S0 + c_a * SA + c_b * SB + c_kl * SKL  with  S0 = sum((P m - T m)^2), SA/SB = masked edge energies,
+    SKL = sum m T' (log T' - log P)  (advchain/common/loss.py:55-79,102-220,223-249).  Differentiable w.r.t. the
+    prediction logits only."""
 
     @staticmethod
     def forward(ctx, pred, ref, mask, coef, ref_is_prob, want_edges):
@@ -750,16 +751,17 @@ class _Consistency(torch.autograd.Function):
         P = torch.empty_like(pred)
         D = torch.empty_like(pred)
         need_grad = ctx.needs_input_grad[0]
+        want_kl = coef[3] != 0.0
         R = None
         if need_grad and want_edges and K > 1:
             R = torch.empty((N, 2 * (K - 1)) + tuple(pred.shape[2:]), device=pred.device, dtype=torch.float32)
-        slots = torch.zeros(3, 64, device=pred.device, dtype=torch.float32)   # per-workgroup partials, 64 slots per sum
+        slots = torch.zeros(4, 64, device=pred.device, dtype=torch.float32)   # per-workgroup partials, 64 slots per sum
         _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
                                                         _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
-                                                        int(want_edges), _stream()), "consistency_fwd")
+                                                        int(want_edges), int(want_kl), _stream()), "consistency_fwd")
         if need_grad:
             ctx.save_for_backward(P, D, R, mask)
-        ctx.cfg = (coef, mch)
+        ctx.cfg = (coef, mch, int(ref_is_prob))
         sums = slots.sum(dim=1)
         ctx.mark_non_differentiable(sums)
         return torch.dot(sums, _coef_vector(coef, pred.device)), sums
@@ -767,18 +769,23 @@ class _Consistency(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gsums):
         P, D, R, mask = ctx.saved_tensors
-        coef, mch = ctx.cfg
+        coef, mch, is_gt = ctx.cfg
         N, K = P.shape[:2]
         nd = P.dim() - 2
         gs = _dev(gloss.reshape(1), "grad")
         gpred = torch.empty_like(P)
         _lib.check(_lib.load().advchain_consistency_bwd(_ptr(P), _ptr(D), _ptr(R), _ptr(mask), _ptr(gs), _ptr(gpred),
-                                                        float(coef[0]), float(coef[1]), float(coef[2]), N, K, nd,
-                                                        _lib.dims_array(P.shape[2:]), mch, _stream()), "consistency_bwd")
+                                                        float(coef[0]), float(coef[1]), float(coef[2]), float(coef[3]),
+                                                        is_gt, N, K, nd, _lib.dims_array(P.shape[2:]), mch, _stream()),
+                   "consistency_bwd")
         return gpred, None, None, None, None, None
 
 
 @_on_tensor_device
 def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
-    """Returns (coef . sums, sums) with sums = [S_mse, S_edgeA, S_edgeB] (device tensor, raw sums)."""
-    return _Consistency.apply(pred, ref, mask, tuple(float(c) for c in coef), bool(ref_is_prob), bool(want_edges))
+    """Returns (coef . sums, sums) with sums = [S_mse, S_edgeA, S_edgeB, S_kl] (device tensor, raw sums); `coef` has 3
+    (no 'kl' term) or 4 entries."""
+    coef = tuple(float(c) for c in coef)
+    if len(coef) == 3:
+        coef = coef + (0.0,)
+    return _Consistency.apply(pred, ref, mask, coef, bool(ref_is_prob), bool(want_edges))

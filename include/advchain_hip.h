@@ -223,24 +223,27 @@ int advchain_norm_axpy(const float* base, const float* x, float* out, float* wor
                        int64_t M, void* stream);
 
 /* ---- consistency loss ------------------------------------------------------------------
- * replaces: calc_segmentation_consistency / contour_loss, advchain/common/loss.py:8-87,102-220
- *           ('mse' and 'contour' terms: softmax over K, mask, 3^d edge stencils, Q13/Q14).
+ * replaces: calc_segmentation_consistency / contour_loss / kl_divergence, advchain/common/loss.py:8-87,102-220,223-249
+ *           ('mse', 'contour' and 'kl' terms: softmax over K, mask, 3^d edge stencils, Q13/Q14).
  * pred/ref (N,K,dims) logits (ref already a probability map when ref_is_prob), mask
  * (N, mask_channels in {1,K}, dims) or NULL.  Outputs: P = softmax(pred), D = P - T (N,K,dims);
  * R (N, 2(K-1), dims) = 2 m^2 (A*D), 2 m^2 (B*D) per class 1..K-1 (NULL when no backward is
- * needed); sums is 3 x 64 partial accumulators (row r, slot s at sums[64 r + s]; per-workgroup partials are
+ * needed); sums is 4 x 64 partial accumulators (row r, slot s at sums[64 r + s]; per-workgroup partials are
  * spread over the slots because same-address atomics serialise): row 0 += sum ((P m)-(T m))^2, row 1 +=
- * sum (A*D m)^2, row 2 += sum (B*D m)^2 (caller zeroes `sums`, adds the slots up and applies the GLOBAL
- * normalisers -- required for batch sharding).  2D: A = Sobel-x, B = Sobel-y.  3D: A = h(x)hp(x)h (the
- * reference uses it for conv_x AND conv_y), B = h(x)h(x)hp.                                      */
+ * sum (A*D m)^2, row 2 += sum (B*D m)^2, row 3 (want_kl != 0 only) += sum_k m_k T'_k (log T'_k - log P_k) with
+ * T' = T, or where(ref == 0, 1e-8, 1 - 1e-8) when ref_is_prob (loss.py:239-243) (caller zeroes `sums`, adds the slots up
+ * and applies the GLOBAL normalisers -- required for batch sharding).  2D: A = Sobel-x, B = Sobel-y.
+ * 3D: A = h(x)hp(x)h (the reference uses it for conv_x AND conv_y), B = h(x)h(x)hp.                */
 int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
                              float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
-                             int ref_is_prob, int want_edges, void* stream);
-/* grad_pred (N,K,dims) = softmax'(P)[ gs (c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B) ], gs = *grad_scale
- * (device scalar, NULL = 1).                                                                    */
+                             int ref_is_prob, int want_edges, int want_kl, void* stream);
+/* grad_pred (N,K,dims) = softmax'(P)[ gs (c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B) ]
+ *                        + gs c_kl (P_j sum_k m_k T'_k - m_j T'_j),   gs = *grad_scale (device scalar, NULL = 1);
+ * the 'kl' term (c_kl != 0) rebuilds T' from P - D (kl_is_gt: the where() of the forward).        */
 int advchain_consistency_bwd(const float* P, const float* D, const float* R, const float* mask,
-                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
-                             int64_t K, int ndim, const int64_t* dims, int mask_channels, void* stream);
+                             const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, float c_kl,
+                             int kl_is_gt, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,7 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
 
 
 def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
-    """[S_mse, S_edgeA, S_edgeB] raw sums as the HIP kernels define them (advchain_amd/csrc/loss.hip)."""
+    """[S_mse, S_edgeA, S_edgeB, S_kl] raw sums as the HIP kernels define them (advchain_amd/csrc/loss.hip)."""
     K = pred.shape[1]
     d = pred.dim() - 2
     P = torch.softmax(pred, dim=1)
@@ -118,7 +118,13 @@ def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
         mr = m0.unsqueeze(1).expand(-1, K - 1, *m0.shape[1:]).reshape(-1, 1, *m0.shape[2:])
         sa = ((conv(Dr, ka, padding=1) * mr) ** 2).sum()
         sb = ((conv(Dr, kb, padding=1) * mr) ** 2).sum()
-    sums = torch.stack([s0, sa, sb])
+    coef = list(coef) + [0.0] * (4 - len(coef))
+    skl = torch.zeros(())
+    if coef[3] != 0.0:      # 'kl' row (loss.py:223-249)
+        p = torch.where(ref == 0, 1e-8, 1 - 1e-8) if ref_is_prob else T
+        log_p = torch.log(p) if ref_is_prob else F.log_softmax(ref, dim=1)
+        skl = (m * (p * log_p)).sum() - (m * (p * F.log_softmax(pred, dim=1))).sum()
+    sums = torch.stack([s0, sa, sb, skl])
     return torch.dot(sums, torch.tensor(coef, dtype=sums.dtype)), sums.detach()
 
 

@@ -81,6 +81,13 @@ def test_morph_and_affine_host_classes(cpu_ops):
         data, w = fx.t(key + "data"), fx.t(key + "w")
         dxy, disp = t.get_deformation_displacement_field(duv=t.epsilon * p)
         assert maxdiff(dxy, fx.t(key + "dxy_fwd")) < 2e-6
+        # the reference's own call form (adv_morph.py:342-343): the identity grid as initial deformation, positional
+        assert maxdiff(t.DemonsCompose(t.epsilon * p, t.base_grid, smooth=True), dxy) == 0
+        assert maxdiff(t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=t.base_grid.clone()), dxy) == 0
+        with pytest.raises(NotImplementedError):
+            t.DemonsCompose(t.epsilon * p, 0.5 * t.base_grid, smooth=True)
+        with pytest.raises(NotImplementedError):
+            t.DemonsCompose(t.epsilon * p, t.base_grid, smooth=False)
         o = t.forward(data)
         (o * w).sum().backward()
         assert maxdiff(o, fx.t(key + "forward")) < 2e-6

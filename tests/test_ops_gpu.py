@@ -1075,6 +1075,35 @@ def test_consistency_loss_row_kernels(dims):
         assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10
 
 
+@pytest.mark.parametrize("dims", [(12, 64), (7, 9, 80), (11, 20), (5, 6, 64), (9, 11), (3, 5, 7)])
+@pytest.mark.parametrize("K", [2, 4, 5, 6])
+def test_kl_term_in_every_kernel_variant(dims, K):
+    """'kl' (loss.py:223-249) through advchain_consistency_fwd/bwd: the 16-byte / scalar marching kernels, the row
+    kernels and the generic per-voxel ones (shape and K select them), alone and mixed with 'mse' / 'contour', with no
+    mask, a K-channel mask with distinct channels and is_gt one-hot references -- vs the CPU oracle."""
+    from advchain_amd.common.loss import calc_segmentation_consistency, kl_divergence
+    from oracle import advchain_oracle as O
+    pred = rand((2, K) + dims, 311) * 3
+    ref = rand((2, K) + dims, 312) * 3
+    mk = (rand((2, K) + dims, 313) > -0.6).float()
+    onehot = F.one_hot(ref.argmax(1), K).movedim(-1, 1).float().contiguous()
+    for types, weights in ((["kl"], [1.0]), (["kl", "contour"], [1.0, 0.5]), (["mse", "kl", "contour"], [0.7, 1.3, 0.5])):
+        for mask, is_gt in ((None, False), (mk, False), (mk, True)):
+            r = onehot if is_gt else ref
+            a = pred.clone().requires_grad_(True)
+            v_ref = O.consistency_loss(a, r, types, weights, mask=mask, is_gt=is_gt)
+            v_ref.backward()
+            b = pred.to(DEV).requires_grad_(True)
+            v = calc_segmentation_consistency(b, r.to(DEV), types, weights, scales=[0],
+                                              mask=None if mask is None else mask.to(DEV), is_gt=is_gt)
+            v.backward()
+            tag = (types, mask is not None, is_gt)
+            assert abs(float(v) - float(v_ref)) < 1e-7 + 2e-5 * abs(float(v_ref)), tag
+            assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10, tag
+    v = kl_divergence(ref.to(DEV), pred.to(DEV))
+    assert abs(float(v) - float(O.consistency_loss(pred, ref, ["kl"], [1.0]))) < 1e-7 + 2e-5 * abs(float(v))
+
+
 @pytest.mark.parametrize("dims", [(9, 11), (5, 6, 7)])
 def test_out_of_range_corners_do_not_read_the_image(dims):
     """Corner loads are unconditional (indices clamped into the volume) and an out-of-range corner's VALUE is
