@@ -1,0 +1,448 @@
+// Affine warp through an LDS-staged source box (gfx950).
+//
+//   advchain_affine_warp_fwd / _bwd  <-  F.affine_grid + F.grid_sample, reference adv_affine.py:297-313
+//   (linear interpolation, zeros padding -- the only mode AdvAffine uses, Q9 -- S2 % 4 == 0, 16-byte aligned tensors;
+//   everything else stays on the direct-gather kernels of sampler.hip)
+//
+// Why: the direct-gather kernels issue 2^d dword gathers per voxel and channel, and a CU retires one vector-memory
+// wave-instruction per ~26 clk whatever it carries (DESIGN lesson 4): C = 4 forward = 36 instructions per 64 voxels
+// = 100 us at 4x4x128x128x64, 75 % of the wave-cycles stalled on issue (profiles/r02/sq_issue_summary.txt) at 13 % of
+// the HBM roofline.  An affine map sends an output tile to a parallelepiped of the source: a workgroup takes a
+// TX x TY x TZ output tile, computes the taps of its voxels ONCE (positions with the forward's exact arithmetic),
+// reduces the integer bounding box of their corners over the workgroup (exact: no assumption about rounding), and per
+// channel stages that box with 16-byte loads (1 KiB per wave-instruction instead of 256 B, every line asked for once
+// per workgroup) into LDS, zero-filled outside the volume -- zeros padding becomes DATA: a two-cell zero border means
+// corner validity needs no select and the +1 corners sit at fixed LDS offsets (ds_read2_b32 pairs).  The 2^d corners
+// of every voxel then come from LDS.  A tile whose box does not fit (strong minification, NaN theta) takes the
+// direct gathers, block-uniformly.  The theta-gradient kernel is the same walk with the derivative weights.
+#include <stdlib.h>
+#include "sampler_common.h"
+
+namespace advchain {
+
+// Tile geometry.  TZ (3D) is a template parameter: 8 planes = 8 voxels a thread, least box inflation, 52 KiB and ~150
+// VGPRs (3 workgroups a CU); 4 planes = 38 KiB, ~100 VGPRs (4 workgroups a CU), 1.4x the staged bytes.
+template <int DIM, int TZ_> struct BoxGeom;
+template <> struct BoxGeom<3, 8> { static constexpr int TX = 16, TY = 16, TZ = 8, CAP = 13312, LPR = 8, WGS = 3; };
+template <> struct BoxGeom<3, 4> { static constexpr int TX = 16, TY = 16, TZ = 4, CAP = 9728, LPR = 8, WGS = 4; };
+template <> struct BoxGeom<2, 1> { static constexpr int TX = 32, TY = 32, TZ = 1, CAP = 4096, LPR = 16, WGS = 4; };   // 16 KiB
+
+template <int DIM, int TZ>
+__host__ __device__ inline int box_tiles(const Dims& d) {
+  using G = BoxGeom<DIM, TZ>;
+  return ((d.s2 + G::TX - 1) / G::TX) * ((d.s1 + G::TY - 1) / G::TY) * ((d.s0 + G::TZ - 1) / G::TZ);
+}
+
+// block b -> tile: blocks are dealt to the XCDs round-robin (b % 8); give every XCD a CONTIGUOUS run of tiles so that
+// the boxes of neighbouring tiles, which overlap, are served by one L2
+__device__ __forceinline__ int xcd_contiguous(int b, int nb) {
+  if (nb & 7) return b;
+  return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+struct BoxDesc {
+  int x0, y0, z0;   // volume coordinates of box cell (0,0,0); x0 % 4 == 0
+  int ex, ey, ez;   // extents in cells; ex % 4 == 0
+  bool fits;
+};
+
+// The taps of one voxel, kept for all channels: lower corner and the upper-corner weights w1 = x - i0.  The lower
+// weights are 1 - w1 EXACTLY: make_tap's w0 = (i0 + 1) - x is exact (x - i0 is, and 1 - w1 is a multiple of ulp(x) below
+// one), so nothing is lost by not storing them.
+struct VoxTap {
+  int ix, iy, iz;        // lower corner, clamped into [-2, S]
+  float fx, fy, fz;
+};
+
+template <int DIM>
+__device__ __forceinline__ VoxTap make_vox_tap(const Theta<DIM>& th, int ox, int oy, int oz, const Dims& d) {
+  float bx, by, bz, gx, gy, gz;
+  affine_position_xyz<DIM>(th, ox, oy, oz, d, bx, by, bz, gx, gy, gz);
+  const AxisTap tx = make_tap<PAD_ZEROS>(gx, d.s2), ty = make_tap<PAD_ZEROS>(gy, d.s1);
+  VoxTap v;
+  v.ix = min(max(tx.i0, -2), d.s2);     // corners beyond the volume read the zero border: [-2,-1] and [S, S+1]
+  v.iy = min(max(ty.i0, -2), d.s1);
+  v.fx = tx.w1; v.fy = ty.w1;
+  if (DIM == 3) {
+    const AxisTap tz = make_tap<PAD_ZEROS>(gz, d.s0);
+    v.iz = min(max(tz.i0, -2), d.s0);
+    v.fz = tz.w1;
+  } else {
+    v.iz = 0; v.fz = 0.f;
+  }
+  return v;
+}
+
+// Exact bounding box of the corners of all voxels of the workgroup (every thread passes the min / max over its own).
+template <int DIM, int TZ>
+__device__ __forceinline__ BoxDesc reduce_box(int lox, int hix, int loy, int hiy, int loz, int hiz, int (*red)[6]) {
+  using G = BoxGeom<DIM, TZ>;
+  lox = wave_min_i(lox); hix = wave_max_i(hix);
+  loy = wave_min_i(loy); hiy = wave_max_i(hiy);
+  if (DIM == 3) { loz = wave_min_i(loz); hiz = wave_max_i(hiz); }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave][0] = lox; red[wave][1] = hix; red[wave][2] = loy; red[wave][3] = hiy; red[wave][4] = loz; red[wave][5] = hiz;
+  }
+  __syncthreads();
+  lox = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+  hix = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+  loy = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+  hiy = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+  loz = min(min(red[0][4], red[1][4]), min(red[2][4], red[3][4]));
+  hiz = max(max(red[0][5], red[1][5]), max(red[2][5], red[3][5]));
+  BoxDesc b;
+  b.x0 = lox & ~3;                                  // 16-byte staging loads (two's complement: -2 -> -4)
+  b.ex = ((hix + 1 - b.x0 + 1) + 3) & ~3;           // corners ix .. ix + 1
+  b.y0 = loy; b.ey = hiy + 1 - loy + 1;
+  b.z0 = DIM == 3 ? loz : 0; b.ez = DIM == 3 ? hiz + 1 - loz + 1 : 1;
+  b.fits = b.ex <= 4 * G::LPR && b.ex * b.ey * b.ez <= G::CAP;
+  return b;
+}
+
+// Stage the box of one channel: rows of ex / 4 float4s, LPR lanes a row, loads unconditional from clamped addresses and
+// zeroed by selects on the way to LDS (a conditional load is a serial load: DESIGN lessons 15, 20).
+template <int DIM, int TZ>
+__device__ __forceinline__ void stage_box(const float* __restrict__ src, const BoxDesc& b, const Dims& d, float* box) {
+  using G = BoxGeom<DIM, TZ>;
+  constexpr int RPP = kBlock / G::LPR;               // rows per pass
+  const int qx = threadIdx.x % G::LPR;
+  const int r0 = threadIdx.x / G::LPR;
+  const int rows = b.ey * b.ez;
+  const int gx = b.x0 + 4 * qx;
+  const bool xin = gx >= 0 && gx + 4 <= d.s2;
+  const int cx = min(max(gx, 0), d.s2 - 4);
+  const bool lane_on = 4 * qx < b.ex;
+  const float inv_ey = 1.f / (float)b.ey;
+  constexpr int U = 4;     // 8 x 16 bytes in flight per lane: a box is 9-15 row passes, i.e. two memory round trips per channel
+  for (int rb = r0; rb < rows; rb += RPP * U) {
+    float4 v[U];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(rb + u * RPP, rows - 1);
+      const int rz = DIM == 3 ? (int)(((float)r + 0.5f) * inv_ey) : 0;
+      const int ry = r - rz * b.ey;
+      const int gy = b.y0 + ry, gz = b.z0 + rz;
+      in[u] = xin && gy >= 0 && gy < d.s1 && gz >= 0 && gz < d.s0;
+      const int cy = min(max(gy, 0), d.s1 - 1), cz = min(max(gz, 0), d.s0 - 1);
+      v[u] = *reinterpret_cast<const float4*>(src + ((int64_t)cz * d.s1 + cy) * d.s2 + cx);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + u * RPP;
+      if (lane_on && r < rows)     // component selects (a select between two float4 OBJECTS goes through scratch memory)
+        *reinterpret_cast<float4*>(box + r * b.ex + 4 * qx) =
+            make_float4(in[u] ? v[u].x : 0.f, in[u] ? v[u].y : 0.f, in[u] ? v[u].z : 0.f, in[u] ? v[u].w : 0.f);
+    }
+  }
+}
+
+template <int DIM, int TZ>
+__device__ __forceinline__ void tile_origin(const Dims& d, int& x0, int& y0, int& z0) {
+  using G = BoxGeom<DIM, TZ>;
+  const int ntx = (d.s2 + G::TX - 1) / G::TX, nty = (d.s1 + G::TY - 1) / G::TY;
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int r = t / ntx;
+  x0 = (t - r * ntx) * G::TX;
+  z0 = (r / nty) * G::TZ;
+  y0 = (r - (r / nty) * nty) * G::TY;
+}
+
+// voxel k of thread t inside the tile
+template <int DIM>
+__device__ __forceinline__ void local_voxel(int k, int& lx, int& ly, int& lz) {
+  if (DIM == 3) { lx = threadIdx.x & 15; ly = (threadIdx.x >> 4) & 15; lz = k; }
+  else { lx = threadIdx.x & 31; ly = (threadIdx.x >> 5) + 8 * k; lz = 0; }
+}
+
+template <int DIM>
+__device__ __forceinline__ Theta<DIM> load_theta(const float* __restrict__ theta, int n) {
+  Theta<DIM> th;
+#pragma unroll
+  for (int r = 0; r < DIM; ++r)
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) th.m[r][c] = theta[(int64_t)n * DIM * (DIM + 1) + r * (DIM + 1) + c];
+  return th;
+}
+
+template <int DIM>
+__device__ __forceinline__ Taps<DIM, PAD_ZEROS> rebuild_taps(const Theta<DIM>& th, int ox, int oy, int oz, const Dims& d) {
+  float bx, by, bz, gx, gy, gz;
+  affine_position_xyz<DIM>(th, ox, oy, oz, d, bx, by, bz, gx, gy, gz);
+  Taps<DIM, PAD_ZEROS> t;
+  t.build(gx, gy, gz, d);
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int TZ>
+__global__ void __launch_bounds__(kBlock, (BoxGeom<DIM, TZ>::WGS))     // as many workgroups a CU as the LDS allows
+k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, int C, Dims d) {
+  using G = BoxGeom<DIM, TZ>;
+  constexpr int VPT = G::TX * G::TY * G::TZ / kBlock;
+  __shared__ __attribute__((aligned(16))) float box[G::CAP];
+  __shared__ int red[4][6];
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const Theta<DIM> th = load_theta<DIM>(theta, n);
+  int tx0, ty0, tz0;
+  tile_origin<DIM, TZ>(d, tx0, ty0, tz0);
+  // per voxel and for all channels: the LDS cell of the lower corner (box-relative) and three fractions
+  int cell[VPT];
+  float fx[VPT], fy[VPT], fz[VPT];
+  int lox = 1 << 30, hix = -(1 << 30), loy = lox, hiy = hix, loz = lox, hiz = hix;
+  {
+    int ixs[VPT], iys[VPT], izs[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      // overhanging threads take a voxel of the volume: their taps exist, do not widen the box much, are not stored
+      const VoxTap t = make_vox_tap<DIM>(th, min(tx0 + lx, d.s2 - 1), min(ty0 + ly, d.s1 - 1), min(tz0 + lz, d.s0 - 1), d);
+      ixs[k] = t.ix; iys[k] = t.iy; izs[k] = t.iz; fx[k] = t.fx; fy[k] = t.fy; fz[k] = t.fz;
+      lox = min(lox, t.ix); hix = max(hix, t.ix);
+      loy = min(loy, t.iy); hiy = max(hiy, t.iy);
+      loz = min(loz, t.iz); hiz = max(hiz, t.iz);
+      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    const BoxDesc bb = reduce_box<DIM, TZ>(lox, hix, loy, hiy, loz, hiz, red);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) cell[k] = ((izs[k] - bb.z0) * bb.ey + (iys[k] - bb.y0)) * bb.ex + (ixs[k] - bb.x0);
+    lox = bb.x0; hix = bb.ex; loy = bb.y0; hiy = bb.ey; loz = bb.z0; hiz = bb.ez;
+    if (!bb.fits) hix = 0;
+  }
+  BoxDesc b;
+  b.x0 = lox; b.ex = hix; b.y0 = loy; b.ey = hiy; b.z0 = loz; b.ez = hiz; b.fits = hix != 0;
+  const float* inn = in + (int64_t)n * C * V;
+  float* on = out + (int64_t)n * C * V;
+  if (!b.fits) {      // block-uniform: direct gathers (the arithmetic of k_affine_warp_fwd); no register array is
+#pragma unroll 1      // indexed by the run-time k here (that would move the arrays to scratch for the fast path too)
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+      if (!(ox < d.s2 && oy < d.s1 && oz < d.s0)) continue;
+      const Taps<DIM, PAD_ZEROS> t = rebuild_taps<DIM>(th, ox, oy, oz, d);
+      const int o = (oz * d.s1 + oy) * d.s2 + ox;
+      for (int c = 0; c < C; ++c) on[(int64_t)c * V + o] = sample_linear<DIM, PAD_ZEROS>(inn + (int64_t)c * V, t, d);
+    }
+    return;
+  }
+  const int sy = b.ex, sz = b.ex * b.ey;
+  for (int c = 0; c < C; ++c) {
+    if (c > 0) __syncthreads();            // everyone is done reading the previous channel's box
+    stage_box<DIM, TZ>(inn + (int64_t)c * V, b, d, box);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const float* p = box + cell[k];
+      // nested lerps x -> y -> z with the taps' own weights (w1 = x - i0, w0 = 1 - w1 exactly): 17 VALU operations
+      // per voxel and channel instead of 8 x (2 products + fma); agrees with the corner-sum form to rounding
+      const float gx = 1.f - fx[k], gy = 1.f - fy[k];
+      float a[4];
+#pragma unroll
+      for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+          a[cz * 2 + cy] = fmaf(p[cz * sz + cy * sy + 1], fx[k], p[cz * sz + cy * sy] * gx);
+      float acc = fmaf(a[1], fy[k], a[0] * gy);
+      if (DIM == 3) acc = fmaf(fmaf(a[3], fy[k], a[2] * gy), fz[k], acc * (1.f - fz[k]));
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+      if (ox < d.s2 && oy < d.s1 && oz < d.s0) on[(int64_t)c * V + (oz * d.s1 + oy) * d.s2 + ox] = acc;
+      // two voxels' LDS reads in flight at a time: left alone the scheduler hoists all 8 x 2^d reads (64 live
+      // registers on top of the taps) and the kernel no longer fits three workgroups a CU
+      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// theta gradient: gtheta_partial (N, gridDim.x, DIM*(DIM+1)) block partial sums (k_reduce_partials of sampler.hip)
+// ---------------------------------------------------------------------------------------------
+template <int DIM, int TZ>
+__global__ void __launch_bounds__(kBlock, (BoxGeom<DIM, TZ>::WGS - (DIM == 3 ? 1 : 0)))
+k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
+                    float* __restrict__ gtheta_partial, int C, Dims d) {
+  using G = BoxGeom<DIM, TZ>;
+  constexpr int VPT = G::TX * G::TY * G::TZ / kBlock;
+  constexpr int NT = DIM * (DIM + 1);
+  __shared__ __attribute__((aligned(16))) float box[G::CAP];
+  __shared__ int red[4][6];
+  __shared__ float smem[4 * NT];
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  const Theta<DIM> th = load_theta<DIM>(theta, n);
+  int tx0, ty0, tz0;
+  tile_origin<DIM, TZ>(d, tx0, ty0, tz0);
+  int cell[VPT];
+  float fx[VPT], fy[VPT], fz[VPT];
+  int lox = 1 << 30, hix = -(1 << 30), loy = lox, hiy = hix, loz = lox, hiz = hix;
+  {
+    int ixs[VPT], iys[VPT], izs[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const VoxTap t = make_vox_tap<DIM>(th, min(tx0 + lx, d.s2 - 1), min(ty0 + ly, d.s1 - 1), min(tz0 + lz, d.s0 - 1), d);
+      ixs[k] = t.ix; iys[k] = t.iy; izs[k] = t.iz; fx[k] = t.fx; fy[k] = t.fy; fz[k] = t.fz;
+      lox = min(lox, t.ix); hix = max(hix, t.ix);
+      loy = min(loy, t.iy); hiy = max(hiy, t.iy);
+      loz = min(loz, t.iz); hiz = max(hiz, t.iz);
+      if (k & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    const BoxDesc bb = reduce_box<DIM, TZ>(lox, hix, loy, hiy, loz, hiz, red);
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) cell[k] = ((izs[k] - bb.z0) * bb.ey + (iys[k] - bb.y0)) * bb.ex + (ixs[k] - bb.x0);
+    lox = bb.x0; hix = bb.ex; loy = bb.y0; hiy = bb.ey; loz = bb.z0; hiz = bb.ez;
+    if (!bb.fits) hix = 0;
+  }
+  BoxDesc b;
+  b.x0 = lox; b.ex = hix; b.y0 = loy; b.ey = hiy; b.z0 = loz; b.ez = hiz; b.fits = hix != 0;
+  const float* inn = in + (int64_t)n * C * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  float acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) acc[q] = 0.f;
+  // d loss / d theta[r][c] += (d loss / d grid_r of this voxel) * base_c ; zeros padding: d(unnormalised coordinate) /
+  // d(grid value) = (S - 1) / 2 everywhere
+  auto add_theta = [&](int ox, int oy, int oz, float sx, float sy_, float sz_) {
+    const float bx = affine_base_coord(ox, d.s2), by = affine_base_coord(oy, d.s1);
+    const float bz = DIM == 3 ? affine_base_coord(oz, d.s0) : 1.f;
+    const float ggx = (0.5f * (float)(d.s2 - 1)) * sx, ggy = (0.5f * (float)(d.s1 - 1)) * sy_;
+    const float ggz = DIM == 3 ? (0.5f * (float)(d.s0 - 1)) * sz_ : 0.f;
+    const float base[4] = {bx, by, bz, 1.f};
+#pragma unroll
+    for (int c = 0; c < DIM + 1; ++c) {
+      acc[0 * (DIM + 1) + c] += ggx * base[c];
+      acc[1 * (DIM + 1) + c] += ggy * base[c];
+      if constexpr (DIM == 3) acc[2 * (DIM + 1) + c] += ggz * base[c];
+    }
+  };
+  if (!b.fits) {      // block-uniform: direct gathers; no register array indexed by the run-time k
+#pragma unroll 1
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+      if (!(ox < d.s2 && oy < d.s1 && oz < d.s0)) continue;
+      const Taps<DIM, PAD_ZEROS> t = rebuild_taps<DIM>(th, ox, oy, oz, d);
+      const int o = (oz * d.s1 + oy) * d.s2 + ox;
+      float sx = 0.f, sy_ = 0.f, sz_ = 0.f;
+      for (int c = 0; c < C; ++c)
+        sample_linear_bwd<DIM, PAD_ZEROS, false, true>(inn + (int64_t)c * V, nullptr, gon[(int64_t)c * V + o], t, d, sx, sy_, sz_);
+      add_theta(ox, oy, oz, sx, sy_, sz_);
+    }
+  } else {
+    float ax[VPT], ay[VPT], az[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) { ax[k] = 0.f; ay[k] = 0.f; az[k] = 0.f; }
+    const int sy = b.ex, sz = b.ex * b.ey;
+    for (int c = 0; c < C; ++c) {
+      if (c > 0) __syncthreads();
+      stage_box<DIM, TZ>(inn + (int64_t)c * V, b, d, box);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        int lx, ly, lz;
+        local_voxel<DIM>(k, lx, ly, lz);
+        const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+        const bool ok = ox < d.s2 && oy < d.s1 && oz < d.s0;
+        const float gl = gon[(int64_t)c * V + (min(oz, d.s0 - 1) * d.s1 + min(oy, d.s1 - 1)) * d.s2 + min(ox, d.s2 - 1)];
+        const float g = ok ? gl : 0.f;
+        const float* p = box + cell[k];
+        // d(sample)/d(x, y, z) in difference form: x-lerps a and x-differences dx of the 2^(d-1) corner pairs, then
+        // lerps / differences along y and z (~35 VALU operations per voxel and channel; the corner-sum form of
+        // sample_linear_bwd is ~100).  Invalid corners read the zero border.
+        const float gx = 1.f - fx[k], gy = 1.f - fy[k], gz = 1.f - fz[k];
+        float a[4], dx[4];
+#pragma unroll
+        for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const float v0 = p[cz * sz + cy * sy], v1 = p[cz * sz + cy * sy + 1];
+            a[cz * 2 + cy] = fmaf(v1, fx[k], v0 * gx);
+            dx[cz * 2 + cy] = v1 - v0;
+          }
+        if (DIM == 3) {
+          const float ddx = fmaf(fmaf(dx[3], fy[k], dx[2] * gy), fz[k], fmaf(dx[1], fy[k], dx[0] * gy) * gz);
+          const float ddy = fmaf(a[3] - a[2], fz[k], (a[1] - a[0]) * gz);
+          const float ddz = fmaf(a[3], fy[k], a[2] * gy) - fmaf(a[1], fy[k], a[0] * gy);
+          ax[k] = fmaf(ddx, g, ax[k]); ay[k] = fmaf(ddy, g, ay[k]); az[k] = fmaf(ddz, g, az[k]);
+        } else {
+          ax[k] = fmaf(fmaf(dx[1], fy[k], dx[0] * gy), g, ax[k]);
+          ay[k] = fmaf(a[1] - a[0], g, ay[k]);
+        }
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);     // see k_affine_box_fwd
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+      if (ox < d.s2 && oy < d.s1 && oz < d.s0) add_theta(ox, oy, oz, ax[k], ay[k], az[k]);
+    }
+  }
+  block_sum<NT>(acc, smem);
+  if (threadIdx.x == 0) {
+    float* dst = gtheta_partial + ((int64_t)n * gridDim.x + blockIdx.x) * NT;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) dst[q] = acc[q];
+  }
+}
+
+}  // namespace advchain
+
+using namespace advchain;
+
+static const bool g_no_affine_box = getenv("ADVCHAIN_NO_AFFINE_BOX") != nullptr;   // A/B knob: direct-gather kernels
+
+static inline bool box_shape_ok(const Dims& d, const void* a, const void* b, const void* c) {
+  if (g_no_affine_box) return false;
+  if (d.s2 % 4 != 0 || d.s2 < 4) return false;
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+static const int g_box_tz = getenv("ADVCHAIN_AFFINE_BOX_TZ") ? atoi(getenv("ADVCHAIN_AFFINE_BOX_TZ")) : 8;   // tuning knob: 8 | 4
+
+// Returns true when the box kernel took the launch (linear, zeros padding).
+bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
+                                    hipStream_t st) {
+  if (!box_shape_ok(d, in, out, nullptr)) return false;
+  dim3 b(kBlock);
+  if (ndim == 3 && g_box_tz == 4) hipLaunchKernelGGL((k_affine_box_fwd<3, 4>), dim3(box_tiles<3, 4>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
+  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_fwd<3, 8>), dim3(box_tiles<3, 8>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
+  else hipLaunchKernelGGL((k_affine_box_fwd<2, 1>), dim3(box_tiles<2, 1>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
+  return true;
+}
+
+// Block partial sums of grad_theta -> gpart[(n * nblocks + block) * ndim * (ndim + 1)]; returns the number of blocks per
+// sample, 0 when the shape is not taken.
+int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st) {
+  if (!box_shape_ok(d, in, gout, nullptr)) return 0;
+  const bool tz4 = ndim == 3 && g_box_tz == 4;
+  const int nb = ndim == 3 ? (tz4 ? box_tiles<3, 4>(d) : box_tiles<3, 8>(d)) : box_tiles<2, 1>(d);
+  if (nb > max_blocks) return 0;
+  dim3 b(kBlock), g(nb, (unsigned)N);
+  if (tz4) hipLaunchKernelGGL((k_affine_box_gtheta<3, 4>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
+  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_gtheta<3, 8>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
+  else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
+  return nb;
+}

@@ -302,26 +302,6 @@ k_compose_self_bwd(const float* __restrict__ gout, const float* __restrict__ phi
 // affine warp: grid = theta_n * (x, y[, z], 1) evaluated in registers
 // =============================================================================================
 template <int DIM>
-struct Theta { float m[DIM][DIM + 1]; };
-
-template <int DIM>
-__device__ __forceinline__ void affine_position_xyz(const Theta<DIM>& th, int ix, int iy, int iz, const Dims& d,
-                                                    float& bx, float& by, float& bz, float& gx, float& gy, float& gz) {
-  bx = affine_base_coord(ix, d.s2);
-  by = affine_base_coord(iy, d.s1);
-  if constexpr (DIM == 3) {
-    bz = affine_base_coord(iz, d.s0);
-    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2] * bz + th.m[0][3];
-    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2] * bz + th.m[1][3];
-    gz = th.m[DIM - 1][0] * bx + th.m[DIM - 1][1] * by + th.m[DIM - 1][2] * bz + th.m[DIM - 1][DIM];
-  } else {
-    bz = 0.f; gz = 0.f;
-    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2];
-    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2];
-  }
-}
-
-template <int DIM>
 __device__ __forceinline__ void affine_position(const Theta<DIM>& th, int64_t v, const Dims& d, float& bx, float& by,
                                                 float& bz, float& gx, float& gy, float& gz) {
   const int ix = (int)(v % d.s2);
@@ -742,6 +722,12 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                    hipStream_t st);
 
+// affine_box.hip: LDS-staged source box (linear, zeros padding, rows of 4k voxels)
+bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
+                                    hipStream_t st);
+int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st);
+
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
@@ -1002,6 +988,10 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   hipStream_t st = (hipStream_t)stream;
   static const float thr = getenv("ADVCHAIN_PATCH_THR") ? (float)atof(getenv("ADVCHAIN_PATCH_THR")) : 7.f;   // tuning knob (break-even measured at ~6 degrees)
   static const bool no_v = getenv("ADVCHAIN_NO_AFFINE_V") != nullptr;   // A/B knob
+  if (interp == INTERP_LINEAR && padding == PAD_ZEROS && advchain_affine_box_fwd_launch(in, theta, out, N, C, ndim, d, st)) {
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   if (interp == INTERP_LINEAR && C <= 4 && !no_v) {
     const unsigned nw = (unsigned)affine_waves(d);
 #define GO_V(DIM_, CT_, VEC_) do { \
@@ -1117,6 +1107,14 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
   } else if (grad_in) {
     (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * d.voxels(), st);
   }
+  int nb_theta = nb;      // block partials per sample of grad_theta
+  if (gpart && interp == INTERP_LINEAR && padding == PAD_ZEROS && (!grad_in || mode)) {
+    // theta gradient through the LDS-staged source box; grad_in (when asked for) comes from the lattice gather above,
+    // and only the samples it flagged still need the scatter kernel -- without its theta part
+    const int nbx = advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st);
+    if (nbx > 0) { nb_theta = nbx; gpart = nullptr; }
+  }
+  if (gpart || grad_in)
   DISPATCH_PAD(padding, {
     if (ndim == 3) {
       if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode);
@@ -1132,7 +1130,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
       (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
     } else {
       const int K = ndim * (ndim + 1);
-      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)N, K), dim3(kBlock), 0, st, gpart, grad_theta, nb, K);
+      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)N, K), dim3(kBlock), 0, st, workspace, grad_theta, nb_theta, K);
       ADVCHAIN_LAUNCH_CHECK();
     }
   }

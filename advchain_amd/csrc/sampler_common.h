@@ -112,6 +112,27 @@ __device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, 
       }
 }
 
+// affine warp: grid = theta_n * (x, y[, z], 1) evaluated in registers (F.affine_grid, align_corners=True)
+template <int DIM>
+struct Theta { float m[DIM][DIM + 1]; };
+
+template <int DIM>
+__device__ __forceinline__ void affine_position_xyz(const Theta<DIM>& th, int ix, int iy, int iz, const Dims& d,
+                                                    float& bx, float& by, float& bz, float& gx, float& gy, float& gz) {
+  bx = affine_base_coord(ix, d.s2);
+  by = affine_base_coord(iy, d.s1);
+  if constexpr (DIM == 3) {
+    bz = affine_base_coord(iz, d.s0);
+    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2] * bz + th.m[0][3];
+    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2] * bz + th.m[1][3];
+    gz = th.m[DIM - 1][0] * bx + th.m[DIM - 1][1] * by + th.m[DIM - 1][2] * bz + th.m[DIM - 1][DIM];
+  } else {
+    bz = 0.f; gz = 0.f;
+    gx = th.m[0][0] * bx + th.m[0][1] * by + th.m[0][2];
+    gy = th.m[1][0] * bx + th.m[1][1] * by + th.m[1][2];
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&r)[VEC]) {
   if constexpr (VEC == 4) {
