@@ -446,3 +446,4 @@ int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const 
   else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
   return nb;
 }
+

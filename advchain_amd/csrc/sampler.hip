@@ -576,8 +576,11 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
   const int n = blockIdx.y;
   const float* gn0 = geo + (int64_t)n * kGeoFloats;
   // the candidates of consecutive u along x walk along Minv[:, 0] in the gradient tensor: patch mapping when that is steep
-  const int u = (int)mapped_thread_voxel(fabsf(gn0[12 + 3]) + (DIM == 3 ? fabsf(gn0[12 + 6]) : 0.f), d);
-  if (u < 0) return;
+  // (32-bit coordinates: the 64-bit divisions of mapped_thread_voxel() were ~350 of this kernel's ~1600 instructions)
+  int ux, uy, uz;
+  if (!mapped_wave_coords(fabsf(gn0[12 + 3]) + (DIM == 3 ? fabsf(gn0[12 + 6]) : 0.f), d,
+                          (unsigned)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), threadIdx.x & 63, 7.f, ux, uy, uz)) return;
+  const int u = (uz * d.s1 + uy) * d.s2 + ux;
   float* ginn = gin + (int64_t)n * C * V + u;
   if (mode[n] != 0) {  // this sample goes through the atomic kernel: start from zero
     for (int c = 0; c < C; ++c) ginn[(int64_t)c * V] = 0.f;
@@ -597,10 +600,6 @@ k_affine_gather_bwd(const float* __restrict__ gout, const float* __restrict__ th
     t[r] = gn[9 + r];
     ext[r] = gn[21 + r];
   }
-  const int ux = u % d.s2;
-  const int rq = u / d.s2;
-  const int uy = rq % d.s1;
-  const int uz = rq / d.s1;
   const float uu[3] = {(float)ux - t[0], (float)uy - t[1], DIM == 3 ? (float)uz - t[2] : 0.f};
   float cen[3];
 #pragma unroll

@@ -21,7 +21,8 @@ import torch.nn.functional as F
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle._import_reference import import_reference  # noqa: E402
-from tests.helpers import bn_dropout_model, counted_torch_seed, device_independent, make_model_multi  # noqa: E402
+from tests.helpers import (bn_dropout_model, counted_torch_seed, device_independent, make_model_multi, notebook_configs,  # noqa: E402
+                           sampled_record, seeded_init_param)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 CPU = torch.device("cpu")
@@ -461,6 +462,73 @@ def g6_solver(aug):
         save("g6_" + tag, out)
 
 
+# ----------------------------------------------------------------------------- G6L: realistic sizes
+G6L_CASES = {
+    # the bench geometries at batch sizes the CPU reference finishes in seconds: the large-shape kernels of the product
+    # (row / window scatters, marching samplers and adjoints, LDS-box affine warps, 16-byte loss stencils) are selected
+    # at these sizes and not at the 32 x 32 / 16 x 16 x 8 of the g6 fixtures
+    "2d_full_256": dict(sd=2, N=2, dims=(256, 256), names=["noise", "bias", "morph", "affine"], seed=4100),
+    "3d_full_64": dict(sd=3, N=1, dims=(64, 64, 32), names=["noise", "bias", "morph", "affine"], seed=4200),
+    "3d_morph_40x40x80": dict(sd=3, N=1, dims=(40, 40, 80), names=["morph"], morph_div8=True, seed=4300),
+}
+
+
+def g6l_large(aug):
+    """ONE ascent step + the final consistency pass of the reference at realistic size, from seeded inputs (data and
+    initial parameters are regenerated from the seeds by the tests: tests/helpers.py).  Large tensors are stored as a
+    strided sample plus float64 moments (tests/helpers.sampled_record) so that a fixture stays below 1 MB."""
+    import contextlib
+    import io
+    cls = {"noise": aug.AdvNoise, "bias": aug.AdvBias, "morph": aug.AdvMorph, "affine": aug.AdvAffine}
+    for tag, c in G6L_CASES.items():
+        if ONLY and not any(o in ("g6l", "g6l_" + tag) for o in ONLY):
+            continue
+        sd, N, dims = c["sd"], c["N"], c["dims"]
+        specs = notebook_configs(dims, N, c["names"], morph_div8=c.get("morph_div8", False))
+        chain = [cls[nm](spatial_dims=sd, config_dict=dict(cfg), use_gpu=False, device=CPU) for nm, cfg in specs]
+        for i, (t, (nm, cfg)) in enumerate(zip(chain, specs)):
+            t.init_parameters()
+            t.param = seeded_init_param(nm, t.param.shape, c["seed"] + 10 + i)
+        solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
+                                                       divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
+        data = smooth_data(N, 1, dims, c["seed"])
+        model = make_model(sd)
+        steps, losses = [], []
+        for ti, t in enumerate(chain):
+            def wrap(t=t, ti=ti, orig=t.optimize_parameters):
+                def f(step_size=None):
+                    rec = dict(ti=ti, grad=t.param.grad.detach().clone())
+                    r = orig(step_size=step_size)
+                    rec["param_out"] = t.param.detach().clone()
+                    steps.append(rec)
+                    return r
+                return f
+            t.optimize_parameters = wrap()
+        orig_loss = solver.loss_fn
+
+        def loss_rec(pred, reference, mask=None):
+            v = orig_loss(pred=pred, reference=reference, mask=mask)
+            losses.append(float(v.detach()))
+            return v
+        solver.loss_fn = loss_rec
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = solver.adversarial_training(data=data, model=model, n_iter=1, lazy_load=True, step_sizes=1)
+        assert len(steps) == len(chain)
+        out = dict(meta=dict(spatial_dims=sd, batch=N, dims=list(dims), names=c["names"], morph_div8=c.get("morph_div8", False),
+                             seed=c["seed"], chain=[dict(name=nm, config=cfg) for nm, cfg in specs]),
+                   loss_trace=np.array(losses, dtype=np.float64), final_loss=loss.detach().double())
+        recs = dict(adv_data=solver.adv_data, init_output=solver.init_output, warped_back=solver.warped_back_adv_output)
+        for rec in steps:
+            recs["grad_%d" % rec["ti"]] = rec["grad"]
+            recs["param_out_%d" % rec["ti"]] = rec["param_out"]
+        for i, t in enumerate(chain):
+            recs["final_param_%d" % i] = t.param
+        for k, v in recs.items():
+            for kk, vv in sampled_record(v).items():
+                out[k + "__" + kk] = vv
+        save("g6l_" + tag, out)
+
+
 # ----------------------------------------------------------------------------- KATs (SURVEY Appendix B)
 def kat(aug):
     """Re-derive the Appendix B scalars from the live reference so the fixture, not the prose, is the pin."""
@@ -848,6 +916,8 @@ def main():
         g5_loss()
     if want("g6"):
         g6_solver(aug)
+    if want("g6l"):
+        g6l_large(aug)
     if want("g6s"):
         global JIT
         merged = {}

@@ -148,3 +148,75 @@ def fixture_model(meta, dropout_classes, device="cpu"):
     if meta.get("in_ch", 1) > 1:
         return make_model_multi(sd, meta["in_ch"], device=device)
     return make_model(sd, device=device)
+
+
+# ------------------------------------------------------------------ realistic-size one-step fixtures (g6l_*)
+def notebook_configs(dims, batch, names, morph_div8=False):
+    """Transform configurations of the reference's notebooks at a given size (the same table as
+    bench.transform_configs) -- shared by oracle/make_golden.py (g6l fixtures) and the tests that replay them."""
+    sd = len(dims)
+    ds = [batch, 1] + list(dims)
+    out = []
+    for nm in names:
+        if nm == "noise":
+            out.append((nm, dict(epsilon=1.0, xi=1e-6, data_size=ds)))
+        elif nm == "bias":
+            out.append((nm, dict(epsilon=0.3, control_point_spacing=[s // 2 for s in dims],
+                                 downscale=2 if sd == 2 else 4, data_size=ds, interpolation_order=3,
+                                 init_mode="random", space="log")))
+        elif nm == "morph":
+            if morph_div8:
+                vs = [s // 8 for s in dims]
+            elif sd == 2:
+                vs = [s // 16 for s in dims]
+            else:
+                vs = [dims[0] // 16, dims[1] // 16, dims[2] // 2]
+            out.append((nm, dict(epsilon=1.5, data_size=ds, vector_size=vs)))
+        else:
+            if sd == 2:
+                out.append((nm, dict(rot=30.0 / 180, scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=ds)))
+            else:
+                out.append((nm, dict(rot_x=10.0 / 180, rot_y=10.0 / 180, rot_z=10.0 / 180, scale_x=0.1, scale_y=0.1,
+                                     scale_z=0.1, shift_x=0.1, shift_y=0.1, shift_z=0.1, data_size=ds)))
+    return out
+
+
+def seeded_init_param(name, shape, seed):
+    """Initial parameters of a g6l case, from a seed (the fixtures do not store them): bias well inside its clip range,
+    affine at 60 % of its bounds, noise / morph on the unit L2 sphere per sample (what init_parameters() produces)."""
+    r = rand(tuple(shape), seed)
+    if name == "bias":
+        return 0.1 * r
+    if name == "affine":
+        return 0.6 * r
+    flat = r.reshape(r.shape[0], -1)
+    return (flat / (flat.norm(dim=1, keepdim=True) + 1e-20)).reshape(r.shape).contiguous()
+
+
+SAMPLE_STRIDE = 61      # tensors above SAMPLE_FULL elements are stored as every 61st element + float64 moments
+SAMPLE_FULL = 8192
+
+
+def sampled_record(t):
+    """What a g6l fixture keeps of a tensor: everything (small) or a strided sample plus float64 sum / |sum| / sum of
+    squares / max of the whole tensor (large)."""
+    flat = t.detach().reshape(-1).double().cpu()
+    if flat.numel() <= SAMPLE_FULL:
+        return dict(full=t.detach().float().cpu())
+    return dict(samples=flat[::SAMPLE_STRIDE].float(), moments=torch.stack([flat.sum(), flat.abs().sum(), (flat ** 2).sum(),
+                                                                           flat.abs().max()]))
+
+
+def compare_sampled(fx, key, t, tol_abs):
+    """Max |difference| of tensor `t` against the record `key` of fixture `fx` (full tensor, or the strided sample and
+    the moments: sums normalised by the element count so that they are on the scale of one element)."""
+    flat = t.detach().reshape(-1).double().cpu()
+    if key + "__full" in fx:
+        return maxdiff(t.detach().cpu(), fx.t(key + "__full"))
+    err = float((flat[::SAMPLE_STRIDE] - fx.t(key + "__samples").double()).abs().max())
+    m = fx.t(key + "__moments").double()
+    n = flat.numel()
+    mine = torch.stack([flat.sum(), flat.abs().sum(), (flat ** 2).sum(), flat.abs().max()])
+    err = max(err, float((mine[0] - m[0]).abs()) / n ** 0.5, float((mine[1] - m[1]).abs()) / n ** 0.5,
+              float((mine[3] - m[3]).abs()))
+    return err

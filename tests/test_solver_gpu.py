@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import Fixture, counted_torch_seed, fixture_model, make_model, maxdiff, rand, smooth_data
+from tests.helpers import (Fixture, compare_sampled, counted_torch_seed, fixture_model, make_model, maxdiff, rand,
+                           seeded_init_param, smooth_data)
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -169,6 +170,91 @@ def _teacher_forced(case, fx, solver, chain, meta, model, data, kw, n_steps, n_t
                 assert maxdiff(t.param.cpu()[sel], p_ref[sel]) < TOL, (case, k, ti, "param")
             else:
                 assert maxdiff(t.param.cpu(), p_ref) < TOL * max(1.0, float(p_ref.abs().max())), (case, k, ti, "param")
+
+
+G6L_CASES = ["2d_full_256", "3d_full_64", "3d_morph_40x40x80"]
+
+
+@pytest.mark.parametrize("case", G6L_CASES)
+def test_teacher_forced_step_at_realistic_size(case):
+    """tests/golden/g6l_*.npz: ONE ascent step of the REFERENCE ITSELF at the bench geometries (2 x 1 x 256 x 256 full
+    chain, 1 x 1 x 64 x 64 x 32 full chain, 1 x 1 x 40 x 40 x 80 morph-only with cfg-5's rows of 80) from seeded inputs:
+    dist_0, the raw gradient of every transform, theta_1, the final loss, adv_data and the rescaled parameters at
+    1e-4 * scale -- no jitter widening.  At these sizes the product selects its large-shape kernels (asserted below), which
+    the 32 x 32 / 16 x 16 x 8 fixtures do not reach."""
+    from advchain_amd import ops
+    from advchain_amd.augmentor import ComposeAdversarialTransformSolver
+    fx = Fixture("g6l_" + case)
+    meta = fx.json()
+    sd, N, dims, seed = meta["spatial_dims"], meta["batch"], tuple(meta["dims"]), meta["seed"]
+    chain = build_chain(meta["chain"])
+    init = []
+    for i, (t, sp) in enumerate(zip(chain, meta["chain"])):
+        t.init_parameters()
+        init.append(seeded_init_param(sp["name"], t.param.shape, seed + 10 + i).to(DEV))
+        t.set_parameters(init[-1])
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
+                                               divergence_weights=[1.0, 0.5])
+    data = smooth_data(N, 1, dims, seed).to(DEV)
+    model = make_model(sd, device=DEV)
+    # ---- the ascent step through the product's own loop, gradients captured before the update
+    init_output = solver.get_init_output(model, data)
+    assert compare_sampled(fx, "init_output", init_output, 0) < 2e-5
+    captured = {}
+    for ti, t in enumerate(chain):
+        t.eval()
+        t.param = init[ti].clone()
+
+        def wrap(t=t, ti=ti, orig=t.optimize_parameters):
+            def f(step_size=None):
+                captured[ti] = t.param.grad.detach().clone()
+                return orig(step_size=step_size)
+            return f
+        t._orig_opt = t.optimize_parameters
+        t.optimize_parameters = wrap()
+    ops._CHAIN_HINTS.clear()
+    with contextlib.redirect_stdout(io.StringIO()):
+        _run_one_step(solver, model, data, init_output, [1] * len(chain), None, {})
+    for t in chain:
+        t.optimize_parameters = t._orig_opt
+    d0 = float(fx.arr("loss_trace")[0])
+    assert abs(float(solver.last_inner_dist) - d0) < 1e-7 + TOL * abs(d0), (float(solver.last_inner_dist), d0)
+    for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
+        gkey = "grad_%d" % ti
+        scale = float(fx.t(gkey + "__full").abs().max()) if gkey + "__full" in fx else float(fx.t(gkey + "__moments")[3])
+        err = compare_sampled(fx, gkey, captured[ti], 0)
+        assert err < TOL * max(scale, 1e-12), (case, sp["name"], "grad err %.3e scale %.3e" % (err, scale))
+        pkey = "param_out_%d" % ti
+        if sp["name"] == "affine":      # sign(grad) is discontinuous at 0: compare where the reference gradient is clearly non-zero
+            g_ref, p_ref = fx.t(gkey + "__full"), fx.t(pkey + "__full")
+            sel = g_ref.abs() > 1e-3 * scale
+            assert maxdiff(t.param.cpu()[sel], p_ref[sel]) < TOL, (case, "affine param")
+        else:
+            pscale = float(fx.t(pkey + "__full").abs().max()) if pkey + "__full" in fx else float(fx.t(pkey + "__moments")[3])
+            err = compare_sampled(fx, pkey, t.param, 0)
+            assert err < TOL * max(1.0, pscale), (case, sp["name"], "param err %.3e" % err)
+    # ---- the large-shape kernels really ran: the squarings of the chain reached displacements beyond the sub-voxel gather
+    # form (march / row / window scatters), or the geometry is one the 64-voxel-row kernels do not take (rows of 80)
+    if any(sp["name"] == "morph" for sp in meta["chain"]):
+        hints = list(ops._CHAIN_HINTS.values())
+        assert hints, "the chain backward did not record its displacement read-back"
+        top = max(max(h) for h in hints)
+        halos = [ops.squaring_halo(v, sd) for h in hints for v in h]
+        assert min(halos) < -1 or max(halos) > 1, (top, halos)      # some step beyond the sub-voxel gather form
+    # ---- the whole call from the same start: final loss, adv_data, rescaled parameters
+    for t, p in zip(chain, init):
+        t.set_parameters(p)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = solver.adversarial_training(data=data, model=model, n_iter=1, lazy_load=True, step_sizes=1)
+    ref = fx.f("final_loss")
+    assert abs(float(loss) - ref) < 1e-7 + TOL * abs(ref), (float(loss), ref)
+    assert compare_sampled(fx, "adv_data", solver.adv_data, 0) < TOL
+    for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
+        if sp["name"] == "affine":
+            continue        # (covered above where the sign is well defined)
+        key = "final_param_%d" % ti
+        pscale = float(fx.t(key + "__full").abs().max()) if key + "__full" in fx else float(fx.t(key + "__moments")[3])
+        assert compare_sampled(fx, key, t.param, 0) < TOL * max(1.0, pscale), (case, sp["name"], "final param")
 
 
 def _run_one_step(solver, model, data, init_output, step_sizes, anatomy, kw):
