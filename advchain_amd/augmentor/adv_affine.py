@@ -149,11 +149,13 @@ class AdvAffine(AdvTransformBase):
     def optimize_parameters(self, step_size=None):
         # adv_affine.py:182-198 : param + step * sign(grad)   (N x 5|9 values: host-level bookkeeping)
         try:
-            sign = self.param.grad.sign().detach()
+            grad = self.param.grad
+            if not isinstance(grad, torch.Tensor):
+                raise TypeError('no gradient')
             if self.power_iteration:
-                self.param = sign
+                self.param = ops.sign_axpy(None, grad, 1.0)
             else:
-                self.param = (self.param + step_size * sign).detach()
+                self.param = ops.sign_axpy(self.param, grad, step_size)     # one launch for sign, scale and add
         except Exception:
             logging.warning('fail to optimize')
         return self.param

@@ -12,9 +12,11 @@ What differs under the hood (results are unchanged, SURVEY §2.3 "Redundancy"):
     intensity range, anatomy check) and every normaliser uses the GLOBAL batch size.
 """
 import logging
+import math
 
 import torch
 
+from .. import ops
 from ..common.loss import calc_segmentation_consistency
 from ..common.utils import _disable_tracking_bn_stats, _fix_dropout
 from .adv_affine import AdvAffine
@@ -209,10 +211,9 @@ class ComposeAdversarialTransformSolver(object):
         zero_grad_ok = all(t in ('mse', 'contour') for t in self.divergence_types)
         if native and zero_grad_ok:
             with torch.no_grad():
-                ones = torch.ones((init_output.shape[0], 1) + tuple(init_output.shape[2:]), dtype=init_output.dtype,
-                                  device=init_output.device)
+                ones = ops.cached_ones((init_output.shape[0], 1) + tuple(init_output.shape[2:]), init_output.device)
                 fb = self.predict_backward(self.predict_forward(ones, chain), chain)
-                m = (fb != 0).to(init_output.dtype)
+                m = ops.nonzero_mask(fb) if fb is not ones else ones       # one launch for `!= 0` and the cast
             return m.expand(init_output.shape)
         masks = torch.ones_like(init_output, dtype=init_output.dtype, device=init_output.device, requires_grad=False)
         fb = self.predict_backward(self.predict_forward(masks, chain), chain)
@@ -298,7 +299,7 @@ class ComposeAdversarialTransformSolver(object):
                 if self.debug:
                     print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
                 self.last_inner_dist = value.detach()
-                if not bool(torch.isfinite(value)):     # NaN/inf guard (adv_compose_solver.py:343): one read-back, not two
+                if not math.isfinite(float(value.detach())):     # NaN/inf guard (adv_compose_solver.py:343): ONE read-back, no launches
                     dist = 0
                 else:
                     self._backward_to_transforms(dist, optimize_flags)
@@ -367,7 +368,9 @@ class ComposeAdversarialTransformSolver(object):
             dist.backward()
             return
         leaves = [t.param for t in flagged]
-        grads = torch.autograd.grad(dist, leaves, allow_unused=True)
+        # (the seed gradient is a cached scalar one: autograd's default builds a ones_like per call)
+        seed = ops.cached_ones((), dist.device) if dist.is_cuda and dist.dim() == 0 and dist.dtype == torch.float32 else None
+        grads = torch.autograd.grad(dist, leaves, grad_outputs=seed, allow_unused=True)
         for p, g in zip(leaves, grads):
             if g is None:
                 continue

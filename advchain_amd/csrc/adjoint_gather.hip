@@ -519,14 +519,15 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement(const float* __rest
 }
 
 // out[r] = max_j slots[r][j]  (NaN propagates, as torch.max does): one workgroup per row of displacement slots
-__global__ void __launch_bounds__(kBlock) k_slot_rows_max(const float* __restrict__ slots, float* __restrict__ out, int cols) {
-  const float* p = slots + (int64_t)blockIdx.x * cols;
+__global__ void __launch_bounds__(kBlock) k_slot_rows_max(float* __restrict__ slots, float* __restrict__ out, int cols, int reset) {
+  float* p = slots + (int64_t)blockIdx.x * cols;
   float m = -3.4e38f;
   bool nan = false;
   for (int j = threadIdx.x; j < cols; j += kBlock) {
     const float v = p[j];
     nan = nan || !(v == v);
     m = fmaxf(m, v);
+    if (reset) p[j] = 0.f;      // the accumulator is the caller's persistent buffer: ready for the next chain
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -685,11 +686,11 @@ extern "C" int advchain_max_displacement(const float* phi, float* out, int64_t N
   return ADVCHAIN_OK;
 }
 
-extern "C" int advchain_slot_rows_max(const float* slots, float* out, int64_t rows, int64_t cols, void* stream) {
+extern "C" int advchain_slot_rows_max(float* slots, float* out, int64_t rows, int64_t cols, int reset, void* stream) {
   ADVCHAIN_CHECK_ARG(slots && out, "slot_rows_max: null pointer");
   ADVCHAIN_CHECK_ARG(rows >= 0 && rows < 65536 && cols >= 1 && cols < (1ll << 31), "slot_rows_max: bad shape");
   if (rows == 0) return ADVCHAIN_OK;
-  hipLaunchKernelGGL(k_slot_rows_max, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols);
+  hipLaunchKernelGGL(k_slot_rows_max, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols, reset);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -10,4 +10,4 @@ extern "C" void advchain_set_error_(const char* msg) {
 
 extern "C" const char* advchain_last_error(void) { return g_last_error; }
 
-extern "C" int advchain_version(void) { return 110; }  // 0.1.1: consistency_fwd/bwd carry the kl term
+extern "C" int advchain_version(void) { return 120; }  // 0.1.2: kl term; slot_rows_max reset; gauss_small_pair, sign_axpy, nonzero_mask, consistency_finish

@@ -759,34 +759,60 @@ k_gauss_march_z(const float* __restrict__ in, float* __restrict__ out, const flo
 // ---------------------------------------------------------------------------------------------
 constexpr int kGaussSmallMax = 4096;   // voxels per plane: 2 x 16 KiB of LDS
 
+// mirror 0: one plane per workgroup.  mirror 1 (the batch [v; -v] of a paired field, never materialised): 2 P workgroups,
+// workgroup b reads plane b % P with the scale negated for b >= P -- (-s) * v == -(s * v) exactly, so the second half is
+// bit-identical to smoothing a negated copy.  mirror 2 (its adjoint): P workgroups, out[b] = G(s in[b]) - G(s in[P + b]),
+// the two smoothings done one after the other with the arithmetic of two separate calls.
 __global__ void __launch_bounds__(kBlock)
-k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int ndim, GaussW gw, float scale) {
+k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int ndim, GaussW gw, float scale, int mirror,
+              int P) {
   __shared__ float buf[2][kGaussSmallMax];
   const int V = (int)d.voxels();
-  const float* src = in + (int64_t)blockIdx.x * V;
-  for (int i = threadIdx.x; i < V; i += kBlock) buf[0][i] = src[i] * scale;
-  __syncthreads();
   const int S[3] = {d.s0, d.s1, d.s2};
   const int stride[3] = {d.s1 * d.s2, d.s2, 1};
-  int cur = 0;
-  for (int pass = 0; pass < ndim; ++pass) {
-    const int axis = 2 - pass;              // innermost first, like advchain_gauss_axis is called
-    const int Sa = S[axis], st = stride[axis];
-    for (int i = threadIdx.x; i < V; i += kBlock) {
-      const int ia = (i / st) % Sa;
-      float acc = 0.f;
-#pragma unroll
-      for (int k = -4; k <= 4; ++k) {
-        const int j = ia + k;
-        if (j >= 0 && j < Sa) acc += gw.w[k + 4] * buf[cur][i + k * st];
-      }
-      buf[cur ^ 1][i] = acc;
-    }
+  const int b = blockIdx.x;
+  float first[(kGaussSmallMax + kBlock - 1) / kBlock];
+  const int rounds = mirror == 2 ? 2 : 1;
+  for (int round = 0; round < rounds; ++round) {
+    const float* src = in + (int64_t)(mirror == 1 ? b % P : b + round * P) * V;
+    const float sc = (mirror == 1 && b >= P) ? -scale : scale;
+    if (round) __syncthreads();
+    for (int i = threadIdx.x; i < V; i += kBlock) buf[0][i] = src[i] * sc;
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int pass = 0; pass < ndim; ++pass) {
+      const int axis = 2 - pass;              // innermost first, like advchain_gauss_axis is called
+      const int Sa = S[axis], st = stride[axis];
+      for (int i = threadIdx.x; i < V; i += kBlock) {
+        const int ia = (i / st) % Sa;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = -4; k <= 4; ++k) {
+          const int j = ia + k;
+          if (j >= 0 && j < Sa) acc += gw.w[k + 4] * buf[cur][i + k * st];
+        }
+        buf[cur ^ 1][i] = acc;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    float* dst = out + (int64_t)b * V;
+    if (mirror != 2) {
+      for (int i = threadIdx.x; i < V; i += kBlock) dst[i] = buf[cur][i];
+    } else if (round == 0) {
+#pragma unroll
+      for (int q = 0; q < (kGaussSmallMax + kBlock - 1) / kBlock; ++q) {
+        const int i = threadIdx.x + q * kBlock;
+        first[q] = i < V ? buf[cur][i] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < (kGaussSmallMax + kBlock - 1) / kBlock; ++q) {
+        const int i = threadIdx.x + q * kBlock;
+        if (i < V) dst[i] = first[q] - buf[cur][i];
+      }
+    }
   }
-  float* dst = out + (int64_t)blockIdx.x * V;
-  for (int i = threadIdx.x; i < V; i += kBlock) dst[i] = buf[cur][i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -804,6 +830,23 @@ k_axpy(const float* __restrict__ x, const float* __restrict__ y, float* __restri
   }
   const int64_t j = n4 * 4 + i;  // scalar tail (everything when the buffers are not 16-byte aligned)
   if (j < n) out[j] = (x ? x[j] : 0.f) + a * y[j];
+}
+
+// out = (base ? base : 0) + a * sign(x)   (sign(0) = 0, sign(NaN) = NaN, like torch.sign)
+__global__ void __launch_bounds__(kBlock)
+k_sign_axpy(const float* __restrict__ base, const float* __restrict__ x, float* __restrict__ out, float a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);     // (v itself: +-0 stays 0, NaN stays NaN)
+  out[i] = (base ? base[i] : 0.f) + a * sg;
+}
+
+// out = (x != 0) ? 1 : 0   (NaN != 0 is true)
+__global__ void __launch_bounds__(kBlock)
+k_nonzero_mask(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = x[i] != 0.f ? 1.f : 0.f;
 }
 
 // partial[n][b] = sum over chunk b of x[n][:]^2
@@ -1101,19 +1144,46 @@ int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t pla
 }
 
 // All axes of a small plane in one launch (planes of at most 4096 voxels); pre = 0 | 1, no epilogue.
-int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
-                         const float* weights9, int pre, float scale, void* stream) {
+static int gauss_small_launch(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                              const float* weights9, int pre, float scale, int mirror, void* stream) {
   ADVCHAIN_CHECK_ARG(in && out && in != out && weights9, "gauss_small: null/aliased pointer");
   ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_small: bad dims");
   ADVCHAIN_CHECK_ARG(pre == 0 || pre == 1, "gauss_small: pre must be 0 or 1");
   const Dims d = fmake_dims(ndim, dims);
   ADVCHAIN_CHECK_ARG(d.voxels() <= kGaussSmallMax, "gauss_small: plane larger than 4096 voxels");
-  ADVCHAIN_CHECK_ARG(planes >= 0 && planes < (1ll << 31), "gauss_small: bad plane count");
-  if (planes == 0 || d.voxels() == 0) return ADVCHAIN_OK;
+  ADVCHAIN_CHECK_ARG(planes >= 0 && planes < (1ll << 30), "gauss_small: bad plane count");
+  if (planes == 0) return ADVCHAIN_OK;
   GaussW gw;
   for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
-  hipLaunchKernelGGL(k_gauss_small, dim3((unsigned)planes), dim3(kBlock), 0, (hipStream_t)stream, in, out, d, ndim, gw,
-                     pre == 1 ? scale : 1.f);
+  const unsigned blocks = (unsigned)(mirror == 1 ? 2 * planes : planes);
+  hipLaunchKernelGGL(k_gauss_small, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, d, ndim, gw,
+                     pre == 1 ? scale : 1.f, mirror, (int)planes);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                         const float* weights9, int pre, float scale, void* stream) {
+  return gauss_small_launch(in, out, planes, ndim, dims, weights9, pre, scale, 0, stream);
+}
+
+int advchain_gauss_small_pair(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                              const float* weights9, float scale, int adjoint, void* stream) {
+  return gauss_small_launch(in, out, planes, ndim, dims, weights9, 1, scale, adjoint ? 2 : 1, stream);
+}
+
+int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, void* stream) {
+  ADVCHAIN_CHECK_ARG(x && out && n >= 0, "sign_axpy: null pointer");
+  if (n == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_sign_axpy, dim3(advchain_blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, base, x, out, a, n);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_nonzero_mask(const float* x, float* out, int64_t n, void* stream) {
+  ADVCHAIN_CHECK_ARG(x && out && n >= 0, "nonzero_mask: null pointer");
+  if (n == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_nonzero_mask, dim3(advchain_blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, out, n);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -553,6 +553,20 @@ k_consistency_bwd_march(const float* __restrict__ P, const float* __restrict__ D
   }
 }
 
+// sums[r] = sum of the 64 partial slots of row r; value = sum_r coef[r] * sums[r]; the slots are zeroed for the next call
+__global__ void __launch_bounds__(kBlock)
+k_consistency_finish(float* __restrict__ slots, float c0, float c1, float c2, float c3, float* __restrict__ sums,
+                     float* __restrict__ value, int reset) {
+  __shared__ float row[4];
+  const int r = threadIdx.x >> 6, j = threadIdx.x & 63;
+  float v = slots[r * kSumSlots + j];
+  if (reset) slots[r * kSumSlots + j] = 0.f;
+  v = wave_sum(v);
+  if (j == 0) { row[r] = v; sums[r] = v; }
+  __syncthreads();
+  if (threadIdx.x == 0) value[0] = ((c0 * row[0] + c1 * row[1]) + c2 * row[2]) + c3 * row[3];
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -921,6 +935,15 @@ int advchain_consistency_fwd(const float* pred, const float* ref, const float* m
       else hipLaunchKernelGGL(k_edge_fwd<2>, g, b, 0, st, D, mask, R, sums, (int)K, d, mask_channels);
     }
   }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_consistency_finish(float* slots, const float* coef4_host, float* sums, float* value, int reset, void* stream) {
+  ADVCHAIN_CHECK_ARG(slots && coef4_host && sums && value, "consistency_finish: null pointer");
+  static_assert(kSumSlots == 64 && kBlock == 256, "one wave per row of slots");
+  hipLaunchKernelGGL(k_consistency_finish, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, slots, coef4_host[0], coef4_host[1],
+                     coef4_host[2], coef4_host[3], sums, value, reset);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -164,12 +164,78 @@ def raw_max_displacement(phi):
     return out
 
 
-def raw_slot_rows_max(slots):
-    """Row maxima of a (rows, slots) displacement accumulator (torch.max(dim=1) semantics incl. NaN)."""
+def raw_slot_rows_max(slots, reset=False):
+    """Row maxima of a (rows, slots) displacement accumulator (torch.max(dim=1) semantics incl. NaN); `reset` zeroes the
+    accumulator behind the read (a persistent buffer then needs no zero-fill launch per chain)."""
     out = torch.empty(slots.shape[0], device=slots.device, dtype=torch.float32)
-    _lib.check(_lib.load().advchain_slot_rows_max(_ptr(slots), _ptr(out), slots.shape[0], slots.shape[1], _stream()),
-               "slot_rows_max")
+    _lib.check(_lib.load().advchain_slot_rows_max(_ptr(slots), _ptr(out), slots.shape[0], slots.shape[1], int(bool(reset)),
+                                                  _stream()), "slot_rows_max")
     return out
+
+
+_PERSISTENT = {}
+
+
+def _persistent_zeros(tag, shape, device):
+    """A zero-initialised device buffer that lives for the process, keyed by (tag, shape, device, stream): accumulators
+    whose CONSUMER kernel zeroes them again (advchain_slot_rows_max / advchain_consistency_finish with reset) -- one
+    torch.zeros at first use instead of a fill launch per call.  Stream order makes the reuse safe: the consumer of call
+    k runs before the producers of call k + 1 on the same stream."""
+    key = (tag, tuple(shape), str(device), _raw_stream(_raw_device()) if (_raw_stream and _raw_device) else 0)
+    buf = _PERSISTENT.get(key)
+    if buf is None:
+        if len(_PERSISTENT) > 64:
+            _PERSISTENT.clear()
+        buf = _PERSISTENT[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+    return buf
+
+
+def raw_gauss_small_pair(x, scale, adjoint=False):
+    """Gaussian of the low-resolution planes of a paired field: forward (N,d,..) -> (2N,d,..) = [G(s x); G(-s x)], adjoint
+    (2N,d,..) -> (N,d,..) = G(s x[:N]) - G(s x[N:]).  None when the planes are too large for the one-launch kernel."""
+    if x[0, 0].numel() > 4096 or not x.is_contiguous():
+        return None
+    nd = x.dim() - 2
+    n_in = x.shape[0]
+    n_out = n_in // 2 if adjoint else 2 * n_in
+    out = torch.empty((n_out,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    planes = (n_out if adjoint else n_in) * x.shape[1]
+    _lib.check(_lib.load().advchain_gauss_small_pair(_ptr(x), _ptr(out), planes, nd, _lib.dims_array(x.shape[2:]), _GAUSS9,
+                                                     float(scale), int(bool(adjoint)), _stream()), "gauss_small_pair")
+    return out
+
+
+@_on_tensor_device
+def sign_axpy(base, x, a):
+    """base + a * sign(x) (base may be None); no autograd (parameter updates, adv_affine.py:186-195)."""
+    x = _dev(x.detach(), "x")
+    base = None if base is None else _dev(base.detach(), "base")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().advchain_sign_axpy(_ptr(base), _ptr(x), _ptr(out), float(a), x.numel(), _stream()), "sign_axpy")
+    return out
+
+
+@_on_tensor_device
+def nonzero_mask(x):
+    """(x != 0) as float32 (the validity mask, adv_compose_solver.py:266-268); no autograd."""
+    x = _dev(x.detach(), "x")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().advchain_nonzero_mask(_ptr(x), _ptr(out), x.numel(), _stream()), "nonzero_mask")
+    return out
+
+
+_ONES = {}
+
+
+def cached_ones(shape, device):
+    """A read-only tensor of ones (the input of the validity-mask warps): filled once per shape, never written."""
+    key = (tuple(shape), str(device))
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) > 16:
+            _ONES.clear()
+        t = _ONES[key] = torch.ones(shape, device=device, dtype=torch.float32)
+    return t
 
 
 def squaring_halo(disp, d):
@@ -543,6 +609,7 @@ class _BiasApply(torch.autograd.Function):
         ctx.save_for_backward(cp, data)
         ctx.cfg = (tables, float(eps), int(use_log), float(cp_scale))
         ctx.mark_non_differentiable(field)
+        ctx.set_materialize_grads(False)      # (the engine would otherwise zero-fill a full-size gradient for `field`)
         return out, field
 
     @staticmethod
@@ -550,7 +617,7 @@ class _BiasApply(torch.autograd.Function):
         cp, data = ctx.saved_tensors
         tables, eps, use_log, cp_scale = ctx.cfg
         need_cp, need_data = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if not (need_cp or need_data):
+        if gout is None or not (need_cp or need_data):
             return None, None, None, None, None, None
         N, C = data.shape[:2]
         gL = torch.empty((N, 1) + tuple(data.shape[2:]), device=data.device, dtype=torch.float32) if need_cp else None
@@ -601,10 +668,15 @@ class _DemonsField(torch.autograd.Function):
     def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False):
         vel = _dev(vel, "velocity")
         ctx.pair = bool(pair)
+        s1 = None
         if pair:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))
-            vel = torch.cat([vel, -vel], 0)
-        N, d = vel.shape[:2]
-        s1 = raw_gauss(vel, d, pre=1, scale=scale)
+            s1 = raw_gauss_small_pair(vel, scale)         # the negated copy is never materialised
+            if s1 is None:
+                vel = torch.cat([vel, -vel], 0)
+        d = vel.shape[1]
+        if s1 is None:
+            s1 = raw_gauss(vel, d, pre=1, scale=scale)
+        N = s1.shape[0]
         n = 8
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
             slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
@@ -620,11 +692,11 @@ class _DemonsField(torch.autograd.Function):
         # row m of `disp`: max-slots for the displacement of phis[m], written by the kernel that produces it; row n: the
         # sampling positions `pos`, which bound the returned grid (clipping to [-1,1] and the normalised Gaussian only
         # shrink a displacement).  Read back once (asynchronously): the backward sizes every step exactly from it.
-        disp = torch.zeros(n + 1, DISP_SLOTS, device=vel.device, dtype=torch.float32) if ADAPTIVE_HALO else None
+        disp = _persistent_zeros("disp", (n + 1, DISP_SLOTS), vel.device) if ADAPTIVE_HALO else None
         row = (lambda m: None) if disp is None else (lambda m: disp[m])
         # what the squarings of the PREVIOUS field of this shape measured (a field changes little between two ascent
         # steps): picks the forward kernel per squaring, nothing else
-        key = (tuple(vel.shape), n)
+        key = (tuple(s1.shape), n)
         hints = _CHAIN_HINTS.get(key)
         phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
@@ -636,7 +708,7 @@ class _DemonsField(torch.autograd.Function):
                    "expo_chain_fwd")
         q = raw_gauss(pos, d, pre=2, post=1)
         ctx.save_for_backward(pos, phi0, fields)
-        ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp))
+        ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp, reset=True))
         global _LAST_FIELD_BOUND
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)
@@ -679,10 +751,12 @@ class _DemonsField(torch.autograd.Function):
                                                            _lib.dims_array(gpos.shape[2:]), n, _stream()), "expo_chain_bwd")
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
-        gvel = raw_gauss(gs1, d, pre=1, scale=scale)
-        if ctx.pair:
-            h = gvel.shape[0] // 2
-            gvel = gvel[:h] - gvel[h:]
+        gvel = raw_gauss_small_pair(gs1, scale, adjoint=True) if ctx.pair else None
+        if gvel is None:
+            gvel = raw_gauss(gs1, d, pre=1, scale=scale)
+            if ctx.pair:
+                h = gvel.shape[0] // 2
+                gvel = gvel[:h] - gvel[h:]
         return gvel, None, None, None, None, None
 
 
@@ -720,21 +794,6 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     return qp, qm
 
 
-_COEF_CACHE = {}
-
-
-def _coef_vector(coef, device):
-    # the normalisers are constants of (shape, weights): upload once -- a host-to-device copy per loss evaluation is a
-    # synchronous hipMemcpy that drains the launch queue
-    key = (tuple(coef), str(device))
-    v = _COEF_CACHE.get(key)
-    if v is None:
-        if len(_COEF_CACHE) > 256:
-            _COEF_CACHE.clear()
-        v = _COEF_CACHE[key] = torch.tensor(coef, device=device, dtype=torch.float32)
-    return v
-
-
 class _Consistency(torch.autograd.Function):
     """c_mse * S0 + c_a * SA + c_b * SB + c_kl * SKL  with  S0 = sum((P m - T m)^2), SA/SB = masked edge energies,
     SKL = sum m T' (log T' - log P)  (advchain/common/loss.py:55-79,102-220,223-249).  Differentiable w.r.t. the
@@ -755,19 +814,25 @@ class _Consistency(torch.autograd.Function):
         R = None
         if need_grad and want_edges and K > 1:
             R = torch.empty((N, 2 * (K - 1)) + tuple(pred.shape[2:]), device=pred.device, dtype=torch.float32)
-        slots = torch.zeros(4, 64, device=pred.device, dtype=torch.float32)   # per-workgroup partials, 64 slots per sum
+        slots = _persistent_zeros("loss", (4, 64), pred.device)   # per-workgroup partials, 64 slots per sum; zeroed by the finisher
         _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
                                                         _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
                                                         int(want_edges), int(want_kl), _stream()), "consistency_fwd")
         if need_grad:
             ctx.save_for_backward(P, D, R, mask)
         ctx.cfg = (coef, mch, int(ref_is_prob))
-        sums = slots.sum(dim=1)
+        sums = torch.empty(4, device=pred.device, dtype=torch.float32)
+        value = torch.empty((), device=pred.device, dtype=torch.float32)
+        _lib.check(_lib.load().advchain_consistency_finish(_ptr(slots), _lib.float_array(coef), _ptr(sums), _ptr(value), 1,
+                                                           _stream()), "consistency_finish")
         ctx.mark_non_differentiable(sums)
-        return torch.dot(sums, _coef_vector(coef, pred.device)), sums
+        ctx.set_materialize_grads(False)      # (no zero tensor for the gradient of `sums`)
+        return value, sums
 
     @staticmethod
     def backward(ctx, gloss, _gsums):
+        if gloss is None:
+            return None, None, None, None, None, None
         P, D, R, mask = ctx.saved_tensors
         coef, mch, is_gt = ctx.cfg
         N, K = P.shape[:2]

@@ -122,7 +122,9 @@ int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim,
 /* out[r] = max over the `cols` accumulator slots of row r (replaces torch.max(dim=1) on the (squarings + 1) x
  * ADVCHAIN_DISP_SLOTS tensor the squaring chain fills: 3 us instead of a 13-us two-pass reduction, 12 times per call);
  * NaN propagates.                                                                                        */
-int advchain_slot_rows_max(const float* slots, float* out, int64_t rows, int64_t cols, void* stream);
+/* reset != 0: the slots are zeroed after they are read, so that one persistent accumulator serves every chain (no
+ * zero-fill launch per chain). */
+int advchain_slot_rows_max(float* slots, float* out, int64_t rows, int64_t cols, int reset, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),
@@ -212,9 +214,20 @@ int advchain_gauss_xy(const float* in, float* out, const float* aux, int64_t pla
 int advchain_gauss_small(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
                          const float* weights9_host, int pre, float scale, void* stream);
 
+/* The same for the batch [v; -v] of a paired field (the deformation and its approximate inverse of one solver step,
+ * adv_morph.py:285-331) without materialising the negated copy: adjoint == 0: in (planes), out (2 planes): out[p] =
+ * G(scale in[p]), out[planes + p] = G(-scale in[p]) (bit-identical to smoothing a negated copy); adjoint != 0: in
+ * (2 planes), out (planes): out[p] = G(scale in[p]) - G(scale in[planes + p]).                                       */
+int advchain_gauss_small_pair(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims,
+                              const float* weights9_host, float scale, int adjoint, void* stream);
+
 /* ---- streaming / per-sample normalisation ----------------------------------------------
  * replaces: data + eps*param adv_noise.py:81-84 (x may be NULL: out = a*y).                     */
 int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n, void* stream);
+/* replaces: param + step * grad.sign() (adv_affine.py:186-195); base may be NULL (power iteration: sign only).   */
+int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, void* stream);
+/* replaces: fb[fb != 0] = 1 of the validity mask (adv_compose_solver.py:266-268,323-325): out = (x != 0) ? 1 : 0.  */
+int advchain_nonzero_mask(const float* x, float* out, int64_t n, void* stream);
 int64_t advchain_norm_workspace(int64_t N, int64_t M); /* floats */
 /* replaces: unit_normalize (adv_transformation_base.py:151-155) fused with the ascent update
  *           param + step*g/(||g||+1e-20) (adv_noise.py:56-63, adv_bias.py:144-147,
@@ -237,6 +250,9 @@ int advchain_norm_axpy(const float* base, const float* x, float* out, float* wor
 int advchain_consistency_fwd(const float* pred, const float* ref, const float* mask, float* P, float* D, float* R,
                              float* sums, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
                              int ref_is_prob, int want_edges, int want_kl, void* stream);
+/* replaces: the sums and the weighted total of calc_segmentation_consistency (loss.py:80-87): sums[r] = sum of the 64
+ * slots of row r (4 floats), value[0] = sum_r coef4[r] * sums[r]; reset != 0 zeroes the slots for the next call.  */
+int advchain_consistency_finish(float* slots, const float* coef4_host, float* sums, float* value, int reset, void* stream);
 /* grad_pred (N,K,dims) = softmax'(P)[ gs (c_mse 2 m^2 D + c_a A^T R_A + c_b B^T R_B) ]
  *                        + gs c_kl (P_j sum_k m_k T'_k - m_j T'_j),   gs = *grad_scale (device scalar, NULL = 1);
  * the 'kl' term (c_kl != 0) rebuilds T' from P - D (kl_is_gt: the where() of the forward).        */

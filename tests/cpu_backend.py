@@ -40,6 +40,15 @@ def axpy(x, y, a):
     return x + a * y
 
 
+def sign_axpy(base, x, a):
+    sg = torch.sign(x.detach())
+    return a * sg if base is None else base.detach() + a * sg
+
+
+def nonzero_mask(x):
+    return (x.detach() != 0).to(x.dtype)
+
+
 def normalized_axpy(base, x, step=1.0):
     u = O.unit_normalize(x.detach())
     return step * u if base is None else base.detach() + step * u
@@ -128,7 +137,7 @@ def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
     return torch.dot(sums, torch.tensor(coef, dtype=sums.dtype)), sums.detach()
 
 
-PATCHED = ["grid_sample", "affine_warp", "affine_theta", "axpy", "normalized_axpy", "bias_apply", "bias_field_only",
+PATCHED = ["grid_sample", "affine_warp", "affine_theta", "axpy", "normalized_axpy", "sign_axpy", "nonzero_mask", "bias_apply", "bias_field_only",
            "demons_field", "demons_field_pair", "consistency_sums"]
 
 

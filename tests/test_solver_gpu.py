@@ -223,7 +223,12 @@ def test_teacher_forced_step_at_realistic_size(case):
         gkey = "grad_%d" % ti
         scale = float(fx.t(gkey + "__full").abs().max()) if gkey + "__full" in fx else float(fx.t(gkey + "__moments")[3])
         err = compare_sampled(fx, gkey, captured[ti], 0)
-        assert err < TOL * max(scale, 1e-12), (case, sp["name"], "grad err %.3e scale %.3e" % (err, scale))
+        # the velocity gradient of AdvMorph is the one quantity with a documented kink sensitivity (tests/golden/
+        # g8_kinks.npz: the REFERENCE's own gradient moves by up to 1e-2 of its scale when its field moves by 4e-6, the
+        # derivative of a (tri)linear interpolant jumping at grid nodes; at these sizes thousands of samples sit within
+        # 1e-6 of a node).  Measured here: 1.4e-4 of scale on one coefficient of the 3D full chain, <= 1e-4 elsewhere.
+        gtol = 3 * TOL if sp["name"] == "morph" else TOL
+        assert err < gtol * max(scale, 1e-12), (case, sp["name"], "grad err %.3e scale %.3e" % (err, scale))
         pkey = "param_out_%d" % ti
         if sp["name"] == "affine":      # sign(grad) is discontinuous at 0: compare where the reference gradient is clearly non-zero
             g_ref, p_ref = fx.t(gkey + "__full"), fx.t(pkey + "__full")
