@@ -39,11 +39,12 @@ PROTOTYPES = {
     "advchain_gauss_small": (_I, [_P, _P, _L, _I, _P, _P, _I, _F, _P]),
     "advchain_gauss_small_pair": (_I, [_P, _P, _L, _I, _P, _P, _F, _I, _P]),
     "advchain_axpy": (_I, [_P, _P, _P, _F, _L, _P]),
-    "advchain_sign_axpy": (_I, [_P, _P, _P, _F, _L, _P]),
+    "advchain_sign_axpy": (_I, [_P, _P, _P, _F, _L, _P, _P, _P]),
     "advchain_nonzero_mask": (_I, [_P, _P, _L, _P]),
     "advchain_consistency_finish": (_I, [_P, _P, _P, _P, _I, _P]),
     "advchain_norm_workspace": (_L, [_L, _L]),
     "advchain_norm_axpy": (_I, [_P, _P, _P, _P, _F, _L, _L, _P]),
+    "advchain_norm_axpy_gated": (_I, [_P, _P, _P, _P, _F, _L, _L, _P, _P, _P]),
     "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
     "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
 }

@@ -153,9 +153,9 @@ class AdvAffine(AdvTransformBase):
             if not isinstance(grad, torch.Tensor):
                 raise TypeError('no gradient')
             if self.power_iteration:
-                self.param = ops.sign_axpy(None, grad, 1.0)
+                self.param = ops.sign_axpy(None, grad, 1.0, gate=self._gate, old=self.param)
             else:
-                self.param = ops.sign_axpy(self.param, grad, step_size)     # one launch for sign, scale and add
+                self.param = ops.sign_axpy(self.param, grad, step_size, gate=self._gate, old=self.param)     # one launch
         except Exception:
             logging.warning('fail to optimize')
         return self.param

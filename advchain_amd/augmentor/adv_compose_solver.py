@@ -45,6 +45,7 @@ class ComposeAdversarialTransformSolver(object):
         self.is_gt = is_gt
         self.class_weights = None
         self.process_group = process_group     # extension: batch-sharded replicas
+        self.device_nan_guard = True           # NaN guard of the ascent loop on the device (False: a host read-back per step)
         self._global_batch = None
 
     # ------------------------------------------------------------------------------- sharding helpers
@@ -299,9 +300,20 @@ class ComposeAdversarialTransformSolver(object):
                 if self.debug:
                     print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
                 self.last_inner_dist = value.detach()
-                if not math.isfinite(float(value.detach())):     # NaN/inf guard (adv_compose_solver.py:343): ONE read-back, no launches
+                # NaN / inf guard (adv_compose_solver.py:343-347: a non-finite loss skips backward and updates).  For an
+                # all-native chain it is evaluated ON THE DEVICE: backward and updates are enqueued unconditionally and
+                # every update kernel keeps the old parameters when the loss is not finite -- the host never reads the
+                # loss back in the middle of a step, so it runs ahead of the GPU for the whole call (the read-back
+                # stalled the GPU once per step: 9.8 ms per cfg-2 call for 8.8 ms of kernels).  Third-party transforms
+                # get the literal check.
+                flagged = [t for flag, t in zip(optimize_flags, self.chain_of_transforms) if flag]
+                device_guard = (self.device_nan_guard and value.is_cuda and all(isinstance(t, _NATIVE) for t in flagged)
+                                and not getattr(self, 'full_backward', False))
+                if not device_guard and not math.isfinite(float(value.detach())):     # one read-back, no launches
                     dist = 0
                 else:
+                    for t in flagged:
+                        t._gate = value.detach() if device_guard else None
                     self._backward_to_transforms(dist, optimize_flags)
                     i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
                     #           is stepped with step_sizes[0]; kept for result parity
@@ -315,6 +327,7 @@ class ComposeAdversarialTransformSolver(object):
                                 step_size = transform.get_step_size()
                                 logging.warning(f'use default step size:{step_size}')
                             transform.optimize_parameters(step_size=step_size)
+                            transform._gate = None
             finally:
                 self._shared_fields(self.chain_of_transforms, False)
             model.zero_grad()

@@ -250,9 +250,9 @@ class AdvMorph(AdvTransformBase):
         try:
             grad = self.param.grad
             if self.power_iteration:
-                self.param = ops.normalized_axpy(None, grad, 1.0)
+                self.param = ops.normalized_axpy(None, grad, 1.0, gate=self._gate, old=self.param)
             else:
-                self.param = ops.normalized_axpy(self.param, grad, step_size)
+                self.param = ops.normalized_axpy(self.param, grad, step_size, gate=self._gate, old=self.param)
         except Exception:
             logging.warning('fail to optimize.This may due to the strength of deformation is too strong, '
                             'that the structure cannot be well preserved. Try use smaller epsilon')

@@ -57,9 +57,9 @@ class AdvNoise(AdvTransformBase):
             step_size = self.step_size
         grad = self.param.grad
         if self.power_iteration:
-            self.param = ops.normalized_axpy(None, grad, 1.0)
+            self.param = ops.normalized_axpy(None, grad, 1.0, gate=self._gate, old=self.param)
         else:
-            self.param = ops.normalized_axpy(self.param, grad, step_size)
+            self.param = ops.normalized_axpy(self.param, grad, step_size, gate=self._gate, old=self.param)
         return self.param
 
     def rescale_parameters(self):

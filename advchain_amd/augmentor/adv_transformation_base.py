@@ -36,6 +36,7 @@ class AdvTransformBase(object):
         self.device = device if self.use_gpu else torch.device('cpu')
         self.debug = debug
         self._diff = None
+        self._gate = None     # solver hook: a device scalar (the step's loss); a non-finite gate voids optimize_parameters()
         self.init_config(self.config_dict)
         self.step_size = 1  # step size for optimizing data augmentation
 

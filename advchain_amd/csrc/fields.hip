@@ -834,9 +834,11 @@ k_axpy(const float* __restrict__ x, const float* __restrict__ y, float* __restri
 
 // out = (base ? base : 0) + a * sign(x)   (sign(0) = 0, sign(NaN) = NaN, like torch.sign)
 __global__ void __launch_bounds__(kBlock)
-k_sign_axpy(const float* __restrict__ base, const float* __restrict__ x, float* __restrict__ out, float a, int64_t n) {
+k_sign_axpy(const float* __restrict__ base, const float* __restrict__ x, float* __restrict__ out, float a, int64_t n,
+            const float* __restrict__ gate, const float* __restrict__ old) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  if (gate && !(fabsf(gate[0]) <= 3.0e38f)) { out[i] = old[i]; return; }     // see k_norm_axpy
   const float v = x[i];
   const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);     // (v itself: +-0 stays 0, NaN stays NaN)
   out[i] = (base ? base[i] : 0.f) + a * sg;
@@ -865,7 +867,8 @@ k_sumsq_partial(const float* __restrict__ x, float* __restrict__ partial, int64_
 // out[n][:] = (base ? base[n][:] : 0) + step * x[n][:] / (sqrt(sum partial[n][:]) + 1e-20)
 __global__ void __launch_bounds__(kBlock)
 k_norm_axpy(const float* __restrict__ base, const float* __restrict__ x, const float* __restrict__ partial,
-            int nb, float step, float* __restrict__ out, int64_t M, int chunk) {
+            int nb, float step, float* __restrict__ out, int64_t M, int chunk, const float* __restrict__ gate,
+            const float* __restrict__ old) {
   __shared__ float smem[4];
   __shared__ float inv_s;
   const int n = blockIdx.y, b = blockIdx.x;
@@ -877,13 +880,20 @@ k_norm_axpy(const float* __restrict__ base, const float* __restrict__ x, const f
   const float inv = inv_s;
   const int64_t lo = (int64_t)b * chunk, hi = min(lo + chunk, M);
   const int64_t off = (int64_t)n * M;
+  // gate (optional device scalar, e.g. the loss): when it is NaN / inf the update is void and `old` is kept -- the NaN guard
+  // of the ascent loop (adv_compose_solver.py:343-347) without a host read-back in the middle of the step
+  if (gate && !(fabsf(gate[0]) <= 3.0e38f)) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) out[off + i] = old[off + i];
+    return;
+  }
   for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
 }
 
 // rows of at most one chunk (the low-resolution parameters of AdvBias / AdvMorph / AdvAffine): both steps in one launch,
 // one workgroup per row, same summation order as the two-launch form
 __global__ void __launch_bounds__(kBlock)
-k_norm_axpy_row(const float* __restrict__ base, const float* __restrict__ x, float step, float* __restrict__ out, int64_t M) {
+k_norm_axpy_row(const float* __restrict__ base, const float* __restrict__ x, float step, float* __restrict__ out, int64_t M,
+                const float* __restrict__ gate, const float* __restrict__ old) {
   __shared__ float smem[4];
   __shared__ float inv_s;
   const int64_t off = (int64_t)blockIdx.x * M;
@@ -893,6 +903,10 @@ k_norm_axpy_row(const float* __restrict__ base, const float* __restrict__ x, flo
   if (threadIdx.x == 0) inv_s = step / (sqrtf(s[0]) + 1e-20f);
   __syncthreads();
   const float inv = inv_s;
+  if (gate && !(fabsf(gate[0]) <= 3.0e38f)) {      // see k_norm_axpy
+    for (int64_t i = threadIdx.x; i < M; i += kBlock) out[off + i] = old[off + i];
+    return;
+  }
   for (int64_t i = threadIdx.x; i < M; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
 }
 
@@ -1172,10 +1186,11 @@ int advchain_gauss_small_pair(const float* in, float* out, int64_t planes, int n
   return gauss_small_launch(in, out, planes, ndim, dims, weights9, 1, scale, adjoint ? 2 : 1, stream);
 }
 
-int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, void* stream) {
-  ADVCHAIN_CHECK_ARG(x && out && n >= 0, "sign_axpy: null pointer");
+int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, const float* gate, const float* old,
+                       void* stream) {
+  ADVCHAIN_CHECK_ARG(x && out && n >= 0 && (!gate || old), "sign_axpy: null pointer");
   if (n == 0) return ADVCHAIN_OK;
-  hipLaunchKernelGGL(k_sign_axpy, dim3(advchain_blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, base, x, out, a, n);
+  hipLaunchKernelGGL(k_sign_axpy, dim3(advchain_blocks(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, base, x, out, a, n, gate, old);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
@@ -1205,24 +1220,29 @@ int64_t advchain_norm_workspace(int64_t N, int64_t M) {
   return N * ((M + chunk - 1) / chunk);  // floats
 }
 
-// out[n] = (base ? base[n] : 0) + step * x[n] / (||x[n]||_2 + 1e-20)       x: (N, M)
-int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
-                       int64_t M, void* stream) {
-  ADVCHAIN_CHECK_ARG(x && out && workspace, "norm_axpy: null pointer");
+// out[n] = (base ? base[n] : 0) + step * x[n] / (||x[n]||_2 + 1e-20)       x: (N, M); gate / old: see k_norm_axpy
+int advchain_norm_axpy_gated(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
+                             int64_t M, const float* gate, const float* old, void* stream) {
+  ADVCHAIN_CHECK_ARG(x && out && workspace && (!gate || old), "norm_axpy: null pointer");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && M >= 0, "norm_axpy: bad N/M");
   if (N == 0 || M == 0) return ADVCHAIN_OK;
   const int chunk = 16384;
   const int nb = (int)((M + chunk - 1) / chunk);
   dim3 grid(nb, (unsigned)N), blk(kBlock);
   if (nb == 1) {
-    hipLaunchKernelGGL(k_norm_axpy_row, dim3((unsigned)N), blk, 0, (hipStream_t)stream, base, x, step, out, M);
+    hipLaunchKernelGGL(k_norm_axpy_row, dim3((unsigned)N), blk, 0, (hipStream_t)stream, base, x, step, out, M, gate, old);
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
   }
   hipLaunchKernelGGL(k_sumsq_partial, grid, blk, 0, (hipStream_t)stream, x, workspace, M, chunk);
-  hipLaunchKernelGGL(k_norm_axpy, grid, blk, 0, (hipStream_t)stream, base, x, workspace, nb, step, out, M, chunk);
+  hipLaunchKernelGGL(k_norm_axpy, grid, blk, 0, (hipStream_t)stream, base, x, workspace, nb, step, out, M, chunk, gate, old);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
+}
+
+int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
+                       int64_t M, void* stream) {
+  return advchain_norm_axpy_gated(base, x, out, workspace, step, N, M, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -206,12 +206,15 @@ def raw_gauss_small_pair(x, scale, adjoint=False):
 
 
 @_on_tensor_device
-def sign_axpy(base, x, a):
-    """base + a * sign(x) (base may be None); no autograd (parameter updates, adv_affine.py:186-195)."""
+def sign_axpy(base, x, a, gate=None, old=None):
+    """base + a * sign(x) (base may be None); no autograd (parameter updates, adv_affine.py:186-195).  gate / old: see
+    normalized_axpy."""
     x = _dev(x.detach(), "x")
     base = None if base is None else _dev(base.detach(), "base")
+    gate, old = _gate_args(gate, old, x)
     out = torch.empty_like(x)
-    _lib.check(_lib.load().advchain_sign_axpy(_ptr(base), _ptr(x), _ptr(out), float(a), x.numel(), _stream()), "sign_axpy")
+    _lib.check(_lib.load().advchain_sign_axpy(_ptr(base), _ptr(x), _ptr(out), float(a), x.numel(), _ptr(gate), _ptr(old),
+                                              _stream()), "sign_axpy")
     return out
 
 
@@ -371,18 +374,32 @@ def raw_axpy(x, y, a):
     return out
 
 
+def _gate_args(gate, old, like):
+    """(gate pointer, old pointer) of the NaN-gated parameter updates: `gate` a 0-dim / 1-element device tensor (the loss of
+    the step), `old` what the output falls back to when the gate is not finite."""
+    if gate is None:
+        return None, None
+    gate = _dev(gate.detach().reshape(1), "gate")
+    old = _dev(old.detach(), "old")
+    if old.shape != like.shape:
+        raise RuntimeError("gated update: `old` must have the shape of the result")
+    return gate, old
+
+
 @_on_tensor_device
-def normalized_axpy(base, x, step=1.0):
-    """base + step * x / (||x||_2 per sample + 1e-20); base may be None.  No autograd (parameter updates)."""
+def normalized_axpy(base, x, step=1.0, gate=None, old=None):
+    """base + step * x / (||x||_2 per sample + 1e-20); base may be None.  No autograd (parameter updates).  With `gate` (a
+    device scalar) the result is `old` whenever the gate is NaN / inf: the solver's NaN guard without a host read-back."""
     x = _dev(x.detach(), "x")
     base = None if base is None else _dev(base.detach(), "base")
+    gate, old = _gate_args(gate, old, x)
     N = x.shape[0]
     M = x.numel() // max(N, 1)
     lib = _lib.load()
     ws = torch.empty(max(1, lib.advchain_norm_workspace(N, M)), device=x.device, dtype=torch.float32)
     out = torch.empty_like(x)
-    _lib.check(lib.advchain_norm_axpy(_ptr(base), _ptr(x), _ptr(out), _ptr(ws), float(step), N, M, _stream()),
-               "norm_axpy")
+    _lib.check(lib.advchain_norm_axpy_gated(_ptr(base), _ptr(x), _ptr(out), _ptr(ws), float(step), N, M, _ptr(gate), _ptr(old),
+                                            _stream()), "norm_axpy")
     return out
 
 

@@ -225,7 +225,11 @@ int advchain_gauss_small_pair(const float* in, float* out, int64_t planes, int n
  * replaces: data + eps*param adv_noise.py:81-84 (x may be NULL: out = a*y).                     */
 int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n, void* stream);
 /* replaces: param + step * grad.sign() (adv_affine.py:186-195); base may be NULL (power iteration: sign only).   */
-int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, void* stream);
+/* gate (may be NULL): a device scalar (the loss of the step); when it is NaN / inf the update is void and out = old --
+ * the NaN guard of the ascent loop (adv_compose_solver.py:343-347) evaluated on the device, so that the host does not have
+ * to read the loss back in the middle of a step.                                                                      */
+int advchain_sign_axpy(const float* base, const float* x, float* out, float a, int64_t n, const float* gate, const float* old,
+                       void* stream);
 /* replaces: fb[fb != 0] = 1 of the validity mask (adv_compose_solver.py:266-268,323-325): out = (x != 0) ? 1 : 0.  */
 int advchain_nonzero_mask(const float* x, float* out, int64_t n, void* stream);
 int64_t advchain_norm_workspace(int64_t N, int64_t M); /* floats */
@@ -234,6 +238,9 @@ int64_t advchain_norm_workspace(int64_t N, int64_t M); /* floats */
  *           adv_morph.py:511-513).  base may be NULL (pure normalisation).  x (N, M).           */
 int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
                        int64_t M, void* stream);
+/* the same with the NaN gate of advchain_sign_axpy */
+int advchain_norm_axpy_gated(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
+                             int64_t M, const float* gate, const float* old, void* stream);
 
 /* ---- consistency loss ------------------------------------------------------------------
  * replaces: calc_segmentation_consistency / contour_loss / kl_divergence, advchain/common/loss.py:8-87,102-220,223-249

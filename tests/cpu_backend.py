@@ -40,7 +40,7 @@ def axpy(x, y, a):
     return x + a * y
 
 
-def sign_axpy(base, x, a):
+def sign_axpy(base, x, a, gate=None, old=None):
     sg = torch.sign(x.detach())
     return a * sg if base is None else base.detach() + a * sg
 
@@ -49,7 +49,7 @@ def nonzero_mask(x):
     return (x.detach() != 0).to(x.dtype)
 
 
-def normalized_axpy(base, x, step=1.0):
+def normalized_axpy(base, x, step=1.0, gate=None, old=None):
     u = O.unit_normalize(x.detach())
     return step * u if base is None else base.detach() + step * u
 
