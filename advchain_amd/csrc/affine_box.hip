@@ -407,6 +407,164 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// grad_in as an OWNER-COMPUTES scatter (zeros padding, linear).  The lattice gather of sampler.hip enumerates, per input
+// voxel u, the samples v with |p(v) - u| < 1 through slab tests: ~1500 VALU wave-instructions per 64 voxels at C = 4 and
+// the kernel is VALU-bound (profiles/r03/affine/pmc_sq_box.csv: 160 us at 4x4x128x128x64).  The forward taps of a sample
+// are far cheaper than that enumeration (a position, three floors): here a workgroup owns a TX x TY x TZ tile of u, walks
+// the bounding box of the samples that can reach it (the image of the tile +-1 under the inverse map, from
+// k_affine_geometry), builds each sample's taps with the forward's arithmetic and deposits the corners that fall in ITS
+// tile into LDS accumulators -- 32-bit fixed point scaled by the max |grad_out| over its own box (LDS integer atomics run
+// at LDS rate, float ones do not: DESIGN lesson 1).  No global atomics, no zero fill, integer adds commute: deterministic,
+// and a sample's result does not depend on what else is in the batch.  A sample is visited by every tile whose box holds
+// it (2.7-6x), which is still 2.5-4x fewer instructions than the enumeration.
+//   geo[n] = { M (3x3, xyz order), t (3), Minv (3x3), ext (3) }; mode[n] != 0: the sample goes through the global-atomic
+//   kernel (zero-fill here).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGeoFloatsBox = 24;   // = kGeoFloats of sampler.hip
+
+template <int DIM, int CMAX>
+__global__ void __launch_bounds__(kBlock)
+k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta, const float* __restrict__ geo,
+                 const int* __restrict__ mode, float* __restrict__ gin, int C, Dims d) {
+  constexpr int TZ = DIM == 3 ? 8 : 1;
+  using G = BoxGeom<DIM, TZ>;
+  constexpr int TILE = G::TX * G::TY * G::TZ;
+  constexpr int VPT = TILE / kBlock;
+  __shared__ int acc[CMAX * TILE];
+  __shared__ float wmax[kBlock / 64];
+  const int V = (int)d.voxels();
+  const int n = blockIdx.y;
+  int ux0, uy0, uz0;
+  tile_origin<DIM, TZ>(d, ux0, uy0, uz0);
+  float* ginn = gin + (int64_t)n * C * V;
+  if (mode[n] != 0) {  // this sample goes through the atomic kernel: start from zero
+#pragma unroll 1
+    for (int k = 0; k < VPT; ++k) {
+      int lx, ly, lz;
+      local_voxel<DIM>(k, lx, ly, lz);
+      const int ux = ux0 + lx, uy = uy0 + ly, uz = uz0 + lz;
+      if (ux < d.s2 && uy < d.s1 && uz < d.s0)
+        for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + (uz * d.s1 + uy) * d.s2 + ux] = 0.f;
+    }
+    return;
+  }
+  const Theta<DIM> th = load_theta<DIM>(theta, n);
+  const float* gn = geo + (int64_t)n * kGeoFloatsBox;
+  // ---- the box of samples that can reach the tile: p(v) in (u0 - 1, u0 + T) on every axis, v = Minv (p - t)
+  int blo[3], bhi[3];
+  {
+    const int T[3] = {G::TX, G::TY, G::TZ};
+    const int U0[3] = {ux0, uy0, uz0};
+    const int S[3] = {d.s2, d.s1, d.s0};
+    float plo[3], phi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { plo[r] = (float)(U0[r] - 1) - gn[9 + r]; phi[r] = (float)(U0[r] + T[r]) - gn[9 + r]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float m = gn[12 + a * 3 + r];
+        lo += m >= 0.f ? m * plo[r] : m * phi[r];
+        hi += m >= 0.f ? m * phi[r] : m * plo[r];
+      }
+      // (positions carry ~1e-4 voxel of rounding at these sizes: 0.05 of slack; the taps below decide what is deposited)
+      const bool fin = lo > -1.0e8f && hi < 1.0e8f;
+      blo[a] = fin ? max(0, (int)floorf(lo - 0.05f)) : 0;
+      bhi[a] = fin ? min(S[a] - 1, (int)ceilf(hi + 0.05f)) : -1;
+      if (a >= DIM) { blo[a] = 0; bhi[a] = 0; }
+    }
+  }
+  const int bex = max(bhi[0] - blo[0] + 1, 0), bey = max(bhi[1] - blo[1] + 1, 0), bez = max(bhi[2] - blo[2] + 1, 0);
+  const int ncell = bex * bey * bez;
+  const float inv_ex = 1.f / (float)max(bex, 1), inv_exy = 1.f / (float)max(bex * bey, 1);
+  const float* gon = gout + (int64_t)n * C * V;
+  auto cell_voxel = [&](int i, int& vx, int& vy, int& vz) {
+    vz = DIM == 3 ? (int)(((float)i + 0.5f) * inv_exy) : 0;
+    const int rem = i - vz * (bex * bey);
+    vy = (int)(((float)rem + 0.5f) * inv_ex);
+    vx = rem - vy * bex + blo[0];
+    vy += blo[1];
+    vz += blo[2];
+  };
+  // ---- pass 1: max |grad_out| over the box (the fixed-point scale), accumulators to zero
+  for (int i = threadIdx.x; i < CMAX * TILE; i += kBlock) acc[i] = 0;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < ncell; i += kBlock) {
+    int vx, vy, vz;
+    cell_voxel(i, vx, vy, vz);
+    const int v = (vz * d.s1 + vy) * d.s2 + vx;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) m = fmaxf(m, fabsf(gon[(int64_t)(c < C ? c : 0) * V + v]));
+    // (a NaN gradient: fmaxf drops it here; it is re-detected below through the sum test)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float gmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  // a cell receives at most prod(2 ext + 1) corners of weight <= 1
+  float cnt = 1.f;
+#pragma unroll
+  for (int a = 0; a < DIM; ++a) cnt *= floorf(2.f * gn[21 + a]) + 2.f;
+  const bool finite = gmax < 3.0e38f;
+  const float scale = (gmax > 0.f && finite) ? 1073741824.f / (cnt * gmax) : 0.f;
+  const float inv = (gmax > 0.f && finite) ? (cnt * gmax) / 1073741824.f : 0.f;
+  // ---- pass 2: deposits
+  bool bad = false;
+  for (int i = threadIdx.x; i < ncell; i += kBlock) {
+    int vx, vy, vz;
+    cell_voxel(i, vx, vy, vz);
+    const int v = (vz * d.s1 + vy) * d.s2 + vx;
+    float go[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) go[c] = gon[(int64_t)(c < C ? c : 0) * V + v];
+    float bx, by, bz, gx, gy, gz;
+    affine_position_xyz<DIM>(th, vx, vy, vz, d, bx, by, bz, gx, gy, gz);
+    const AxisTap tx = make_tap<PAD_ZEROS>(gx, d.s2), ty = make_tap<PAD_ZEROS>(gy, d.s1);
+    AxisTap tz;
+    if (DIM == 3) tz = make_tap<PAD_ZEROS>(gz, d.s0);
+    else { tz.i0 = 0; tz.w0 = 1.f; tz.w1 = 0.f; }
+    const int px = tx.i0 - ux0, py = ty.i0 - uy0, pz = DIM == 3 ? tz.i0 - uz0 : 0;
+    const bool reach = px >= -1 && px < G::TX && py >= -1 && py < G::TY && (DIM == 2 || (pz >= -1 && pz < G::TZ));
+    if (!reach) continue;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) bad = bad || (c < C && !(go[c] == go[c]));
+#pragma unroll
+    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const int qx = px + cx, qy = py + cy, qz = pz + cz;
+          if ((unsigned)qx >= (unsigned)G::TX || (unsigned)qy >= (unsigned)G::TY || (unsigned)qz >= (unsigned)G::TZ) continue;
+          float w = (cx ? tx.w1 : tx.w0) * (cy ? ty.w1 : ty.w0);
+          if (DIM == 3) w *= (cz ? tz.w1 : tz.w0);
+          const float ws = w * scale;
+          int* cell = acc + (qz * G::TY + qy) * G::TX + qx;
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c)
+            if (c < C) atomicAdd(cell + c * TILE, __float2int_rn(ws * go[c]));
+        }
+  }
+  // non-finite gradients must not come out as finite numbers: the whole tile turns NaN
+  const bool poison = __syncthreads_or((int)(bad || !finite)) != 0;
+  const float nanv = __int_as_float(0x7fc00000);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    int lx, ly, lz;
+    local_voxel<DIM>(k, lx, ly, lz);
+    const int ux = ux0 + lx, uy = uy0 + ly, uz = uz0 + lz;
+    if (!(ux < d.s2 && uy < d.s1 && uz < d.s0)) continue;
+    const int cellu = (lz * G::TY + ly) * G::TX + lx;
+    const int u = (uz * d.s1 + uy) * d.s2 + ux;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) ginn[(int64_t)c * V + u] = poison ? nanv : (float)acc[c * TILE + cellu] * inv;
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -447,3 +605,21 @@ int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const 
   return nb;
 }
 
+
+// grad_in through the owner-computes LDS scatter (after k_affine_geometry filled geo / mode); false = shape not taken.
+bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
+                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st) {
+  static const bool no_gin = getenv("ADVCHAIN_NO_AFFINE_BOX_GIN") != nullptr;   // A/B knob: the lattice gather of sampler.hip
+  if (no_gin || g_no_affine_box || C > 4) return false;
+  dim3 b(kBlock);
+  if (ndim == 3) {
+    dim3 g(box_tiles<3, 8>(d), (unsigned)N);
+    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<3, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+    else hipLaunchKernelGGL((k_affine_box_gin<3, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+  } else {
+    dim3 g(box_tiles<2, 1>(d), (unsigned)N);
+    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<2, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+    else hipLaunchKernelGGL((k_affine_box_gin<2, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+  }
+  return true;
+}

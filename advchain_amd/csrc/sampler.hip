@@ -726,6 +726,8 @@ bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* 
                                     hipStream_t st);
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
                                       int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st);
+bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
+                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st);
 
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
@@ -1093,12 +1095,14 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     int* md = reinterpret_cast<int*>(geo + N * kGeoFloats);
     if (ndim == 3) {
       hipLaunchKernelGGL(k_affine_geometry<3>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
-      if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<3, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st)) {}
+      else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<3, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<3, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else hipLaunchKernelGGL((k_affine_gather_bwd<3, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
     } else {
       hipLaunchKernelGGL(k_affine_geometry<2>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
-      if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<2, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
+      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st)) {}
+      else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<2, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<2, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else hipLaunchKernelGGL((k_affine_gather_bwd<2, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
     }

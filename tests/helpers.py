@@ -209,7 +209,7 @@ def sampled_record(t):
 
 def compare_sampled(fx, key, t, tol_abs):
     """Max |difference| of tensor `t` against the record `key` of fixture `fx` (full tensor, or the strided sample and
-    the moments: sums normalised by the element count so that they are on the scale of one element)."""
+    the moments: sums divided by the element count, i.e. mean differences, and the maximum)."""
     flat = t.detach().reshape(-1).double().cpu()
     if key + "__full" in fx:
         return maxdiff(t.detach().cpu(), fx.t(key + "__full"))
@@ -217,6 +217,6 @@ def compare_sampled(fx, key, t, tol_abs):
     m = fx.t(key + "__moments").double()
     n = flat.numel()
     mine = torch.stack([flat.sum(), flat.abs().sum(), (flat ** 2).sum(), flat.abs().max()])
-    err = max(err, float((mine[0] - m[0]).abs()) / n ** 0.5, float((mine[1] - m[1]).abs()) / n ** 0.5,
-              float((mine[3] - m[3]).abs()))
+    # moments: mean signed / absolute difference (sums over the count) and the maximum
+    err = max(err, float((mine[0] - m[0]).abs()) / n, float((mine[1] - m[1]).abs()) / n, float((mine[3] - m[3]).abs()))
     return err

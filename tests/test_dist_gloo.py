@@ -21,6 +21,9 @@ def _specs(sd, n):
                               interpolation_order=3, init_mode="random", space="log")),
                 ("morph", dict(epsilon=1.5, data_size=ds, vector_size=[4, 4])),
                 ("affine", dict(rot=30 / 180., scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=ds))]
+    if sd == "3a":      # cfg-5's class: morph only + anatomy mask (the retry ladder, adv_compose_solver.py:369-403)
+        ds = [n, 1, 12, 12, 8]
+        return [("morph", dict(epsilon=1.5, data_size=ds, vector_size=[3, 3, 2]))]
     ds = [n, 1, 12, 12, 8]
     return [("bias", dict(epsilon=0.3, control_point_spacing=[6, 6, 4], downscale=2, data_size=ds,
                           interpolation_order=3, init_mode="random", space="log")),
@@ -29,17 +32,64 @@ def _specs(sd, n):
                             shift_y=0.1, shift_z=0.1, data_size=ds))]
 
 
-def _run(sd, data, params, group, if_norm):
+def _anatomy(n, dims):
+    axes = torch.meshgrid([torch.linspace(-1, 1, s) for s in dims], indexing="ij")
+    return (sum(a ** 2 for a in axes) <= 0.45).float()[None, None].repeat(n, 1, *([1] * len(dims))).contiguous()
+
+
+def seeded_morph_class(base, shard, global_n):
+    """AdvMorph whose (re-)initialisations do not depend on how the batch is sharded: every init_parameters() call draws
+    the WHOLE batch from a seed that counts the calls and keeps this rank's slice -- the anatomy ladder re-initialises
+    the transforms at random (adv_compose_solver.py:388-395), which a sharded run could otherwise not reproduce."""
+    from oracle import advchain_oracle as O
+    from tests.helpers import rand
+
+    class SeededMorph(base):
+        _draws = 0
+
+        def init_parameters(self):
+            p = super().init_parameters()
+            SeededMorph._draws += 1
+            shape = (global_n,) + tuple(self.param.shape[1:])
+            full = O.unit_normalize(rand(shape, 900 + SeededMorph._draws))
+            self.param = full[shard].contiguous().to(self.param.device)
+            return self.param if p is not None else None
+    return SeededMorph
+
+
+def _run(sd, data, params, group, if_norm, device=torch.device("cpu"), shard=None, global_n=None):
     from advchain_amd.augmentor import AdvAffine, AdvBias, AdvMorph, AdvNoise, ComposeAdversarialTransformSolver
     from tests.helpers import make_model
+    nsd = 3 if sd == "3a" else sd
     cls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
-    chain = [cls[nm](spatial_dims=sd, config_dict=cfg, device=torch.device("cpu")) for nm, cfg in _specs(sd, data.shape[0])]
+    if sd == "3a":
+        cls["morph"] = seeded_morph_class(AdvMorph, shard if shard is not None else slice(None), global_n or data.shape[0])
+    chain = [cls[nm](spatial_dims=nsd, config_dict=cfg, device=device) for nm, cfg in _specs(sd, data.shape[0])]
     for t, p in zip(chain, params):
         t.init_parameters()
-        t.set_parameters(p)
+        t.set_parameters(p.to(device))
     solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, if_norm_image=if_norm, process_group=group)
-    loss = solver.adversarial_training(data=data, model=make_model(sd), n_iter=2, lazy_load=True)
-    return float(loss), [t.param.detach().clone() for t in chain], solver.adv_data.detach().clone()
+    kw, scores = {}, []
+    if sd == "3a":
+        # the anatomy score is all-reduced (sum of squared errors / GLOBAL element count): every rank must see the
+        # whole-batch value at every check and walk the ladder (one more step / re-initialise / give up) identically
+        full = _anatomy(global_n or data.shape[0], data.shape[2:])
+        kw = dict(anatomy_mask_images=full[shard if shard is not None else slice(None)].contiguous().to(device),
+                  anatomy_reg_weight=50, volume_preserve_tolerance=2e-3)
+        orig = solver.compute_anatomy_misoverlapping_loss
+
+        def rec(anatomy_mask_images):
+            v = orig(anatomy_mask_images)
+            scores.append(float(v))
+            return v
+        solver.compute_anatomy_misoverlapping_loss = rec
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = solver.adversarial_training(data=data.to(device), model=make_model(nsd).to(device), n_iter=2, lazy_load=True, **kw)
+    out = [float(loss), [t.param.detach().cpu().clone() for t in solver.chain_of_transforms[:len(chain)]],
+           solver.adv_data.detach().cpu().clone()]
+    return out + [scores] if sd == "3a" else out
 
 
 def _inputs(sd):
@@ -48,6 +98,7 @@ def _inputs(sd):
     n = 4
     specs = _specs(sd, n)
     data = smooth_data(n, 1, specs[0][1]["data_size"][2:], 77)
+    sd = 3 if sd == "3a" else sd
     params = []
     for i, (nm, cfg) in enumerate(specs):
         ds = cfg["data_size"]
@@ -74,27 +125,40 @@ def _worker(rank, world, initfile, sd, if_norm, out):
     data, params = _inputs(sd)
     per = data.shape[0] // world
     sl = slice(rank * per, (rank + 1) * per)
-    loss, new_params, adv = _run(sd, data[sl].contiguous(), [p[sl].contiguous() for p in params], dist.group.WORLD, if_norm)
-    torch.save(dict(loss=loss, params=new_params, adv=adv), os.path.join(out, "rank%d.pt" % rank))
+    res = _run(sd, data[sl].contiguous(), [p[sl].contiguous() for p in params], dist.group.WORLD, if_norm, shard=sl,
+               global_n=data.shape[0])
+    torch.save(dict(loss=res[0], params=res[1], adv=res[2], scores=res[3] if len(res) > 3 else None),
+               os.path.join(out, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sd,if_norm", [(2, True), (3, False)])
+def check_parts(parts, ref, tol_loss, tol_param, tol_adv):
+    ref_loss, ref_params, ref_adv = ref[:3]
+    for p in parts:   # every rank returns the WHOLE-batch loss
+        assert abs(p["loss"] - ref_loss) < 1e-7 + tol_loss * abs(ref_loss), (p["loss"], ref_loss)
+    for i in range(len(ref_params)):
+        got = torch.cat([p["params"][i] for p in parts], dim=0)
+        assert float((got - ref_params[i]).abs().max()) < tol_param, i
+    got_adv = torch.cat([p["adv"] for p in parts], dim=0)
+    assert float((got_adv - ref_adv).abs().max()) < tol_adv
+    if len(ref) > 3:   # anatomy ladder: the same number of checks with the same (whole-batch) scores on every rank
+        assert len(ref[3]) >= 2, "the ladder was not exercised"
+        for p in parts:
+            assert len(p["scores"]) == len(ref[3]), (p["scores"], ref[3])
+            for a, b in zip(p["scores"], ref[3]):
+                assert abs(a - b) < 1e-7 + 1e-4 * abs(b), (p["scores"], ref[3])
+
+
+@pytest.mark.parametrize("sd,if_norm", [(2, True), (3, False), ("3a", False)])
 def test_two_rank_sharding_matches_whole_batch(sd, if_norm, monkeypatch):
     from tests import cpu_backend
     cpu_backend.install(monkeypatch)
     data, params = _inputs(sd)
-    ref_loss, ref_params, ref_adv = _run(sd, data, params, None, if_norm)
+    ref = _run(sd, data, params, None, if_norm)
+    ref_loss, ref_params, ref_adv = ref[:3]
     with tempfile.TemporaryDirectory() as tmp:
         initfile = os.path.join(tmp, "init")
         mp.spawn(_worker, args=(2, initfile, sd, if_norm, tmp), nprocs=2, join=True)
         parts = [torch.load(os.path.join(tmp, "rank%d.pt" % r)) for r in range(2)]
-    # every rank returns the WHOLE-batch loss
-    for p in parts:
-        assert abs(p["loss"] - ref_loss) < 1e-7 + 1e-5 * abs(ref_loss), (p["loss"], ref_loss)
-    for i in range(len(ref_params)):
-        got = torch.cat([p["params"][i] for p in parts], dim=0)
-        assert float((got - ref_params[i]).abs().max()) < 2e-5, i
-    got_adv = torch.cat([p["adv"] for p in parts], dim=0)
-    assert float((got_adv - ref_adv).abs().max()) < 5e-5
+    check_parts(parts, ref, 1e-5, 2e-5, 5e-5)
