@@ -729,6 +729,10 @@ int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const 
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
                                     int64_t N, int64_t C, int ndim, Dims d, hipStream_t st);
 
+// sample_march.hip: two squarings per launch (f1 experiment, ADVCHAIN_FUSE2)
+int advchain_compose2_march_launch(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
+                                   hipStream_t st);
+
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
@@ -1028,7 +1032,21 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_fwd: bad dims");
   const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
   const float* src = phi0;
+  // f1 experiment: ADVCHAIN_FUSE2=1 fuses pairs of squarings whose hints say "below one voxel" (phi_m and phi_m+1), =2 the
+  // first three pairs whatever the hints say (results do not depend on it: lanes beyond the ring fall back)
+  static const int fuse2 = getenv("ADVCHAIN_FUSE2") ? atoi(getenv("ADVCHAIN_FUSE2")) : 0;
   for (int m = 0; m + 1 < n; ++m) {
+    if (fuse2 && ndim == 3 && m + 2 < n &&
+        (fuse2 >= 2 ? m < 6 : (hints && (hints[m] & 0xff) == 1 && (hints[m + 1] & 0xff) == 1))) {
+      float* mid = fields + (int64_t)m * F;
+      float* dst2 = fields + (int64_t)(m + 1) * F;
+      const int rc2 = advchain_compose2_march_launch(src, mid, dst2, N, make_dims(ndim, dims),
+                                                     disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr,
+                                                     disp_rows ? disp_rows + (int64_t)(m + 2) * kDispSlots : nullptr,
+                                                     (hipStream_t)stream);
+      if (rc2 == ADVCHAIN_OK) { src = dst2; ++m; continue; }
+      if (rc2 != ADVCHAIN_ERR_UNSUPPORTED) return rc2;
+    }
     float* dst = fields + (int64_t)m * F;
     const int rc = advchain_compose_self_fwd(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
                                              disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, stream);
