@@ -28,6 +28,16 @@ struct Dims {
 // sampling grid of adv_morph.py:14-55 and F.affine_grid's base grid are both built from it; we
 // evaluate it in registers instead of reading a materialised (N,d,...) base grid from HBM.
 // ---------------------------------------------------------------------------------------------
+// A product that is never contracted into an fma with a neighbouring sum.  HIP compiles with -ffp-contract=fast-honor-
+// pragmas and `acc += v * w` / `t * top - floor(..)` are fused in one kernel and not in another (it depends on the
+// surrounding code); mul_nc() is a plain `*` on this toolchain and fuses as well.  The forward samplers (direct gathers,
+// LDS tiles, z-marching ring) must agree BIT FOR BIT -- the displacement hint that picks the 3D kernel comes from
+// asynchronous read-backs, so anything else makes results depend on timing, 2^8-fold amplified by the squaring chain.
+__device__ __forceinline__ float mul_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 __device__ __forceinline__ float lin_coord(int i, int S) {
   if (S <= 1) return S == 1 ? -1.f : 0.f;
   const float step = 2.f / (float)(S - 1);

@@ -173,7 +173,8 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
 #pragma unroll
             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-              for (int cx = 0; cx < 2; ++cx) acc += p[oz[cz] + oy[cy] + ox[cx]] * w[(cz * 2 + cy) * 2 + cx];
+              for (int cx = 0; cx < 2; ++cx)     // see tap_acc() (sampler_common.h): the same rounding in every forward kernel
+                acc = tap_acc<DIM>(acc, p[oz[cz] + oy[cy] + ox[cx]], w[(cz * 2 + cy) * 2 + cx]);
           res[c] = acc;
         }
       } else {

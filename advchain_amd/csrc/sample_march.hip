@@ -191,7 +191,8 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 #pragma unroll
             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-              for (int cx = 0; cx < 2; ++cx) acc += ((cz ? q1 : q0) + (c * R + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
+              for (int cx = 0; cx < 2; ++cx)     // product then sum, never contracted: see tap_acc() (sampler_common.h)
+                acc = tap_acc<3>(acc, ((cz ? q1 : q0) + (c * R + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
           res[c][o] = acc;
         }
       } else if (xowned) {
@@ -367,7 +368,7 @@ k_compose2_march(const float* __restrict__ in, float* __restrict__ mid, float* _
 #pragma unroll
               for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-                for (int cx = 0; cx < 2; ++cx) a += ((cz ? q1 : q0) + (c * RA + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
+                for (int cx = 0; cx < 2; ++cx) a = tap_acc<3>(a, ((cz ? q1 : q0) + (c * RA + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
             res[c] = a;
           }
         } else if (xowned) {
@@ -448,7 +449,7 @@ k_compose2_march(const float* __restrict__ in, float* __restrict__ mid, float* _
 #pragma unroll
             for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-              for (int cx = 0; cx < 2; ++cx) a += ((cz ? q1 : q0) + (c * RB + cy) * P)[cx] * w[(cz * 2 + cy) * 2 + cx];
+              for (int cx = 0; cx < 2; ++cx) a = tap_acc<3>(a, ((cz ? q1 : q0) + (c * RB + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
           res[c][o] = a;
         }
       } else if (xowned) {
@@ -462,7 +463,7 @@ k_compose2_march(const float* __restrict__ in, float* __restrict__ mid, float* _
           fuse2_phi1_global(inn, V, d, min(ix + cx, d.s2 - 1), min(iy + cy, d.s1 - 1), min(iz + cz, d.s0 - 1), v);
           const float wk = ((cx ? wx1 : wx0) * (cy ? wy1 : wy0)) * (cz ? wz1 : wz0);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) a[c] += v[c] * wk;
+          for (int c = 0; c < 3; ++c) a[c] = tap_acc<3>(a[c], v[c], wk);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) res[c][o] = a[c];

@@ -51,6 +51,17 @@ struct CornerOffsets {
   __device__ __forceinline__ int at(int cz, int cy, int cx) const { return z[cz] + y[cy] + x[cx]; }
 };
 
+// One term of a (bi/tri)linear tap sum, with the rounding PINNED so that every forward kernel (direct gathers, LDS tiles,
+// z-marching ring) produces the same bits -- `acc += v * w` is contracted to an fma in one kernel and not in another, and
+// the displacement hint that picks the 3D kernel comes from asynchronous read-backs: results depended on timing at the
+// ulp level, amplified 2^8-fold by the squaring chain.  3D: product, then sum (what ATen's scalar CPU loop does: the
+// 9-squaring golden field is reproduced to 1.6e-5 with it, to 3e-5 with the fma chain); 2D: fma (the form the 2D goldens
+// were pinned with).
+template <int DIM>
+__device__ __forceinline__ float tap_acc(float acc, float v, float w) {
+  return DIM == 3 ? acc + mul_nc(v, w) : fmaf(v, w, acc);
+}
+
 template <int DIM, int PAD>
 __device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
   const CornerOffsets<DIM, PAD> o(t, d);
@@ -68,7 +79,7 @@ __device__ __forceinline__ float sample_linear(const float* __restrict__ in, con
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
       for (int cx = 0; cx < 2; ++cx)   // a select, not a branch: control flow here would make the next sample's loads wait
-        acc = fmaf(t.ok(cz, cy, cx) ? v[(cz * 2 + cy) * 2 + cx] : 0.f, t.w(cz, cy, cx), acc);
+        acc = tap_acc<DIM>(acc, t.ok(cz, cy, cx) ? v[(cz * 2 + cy) * 2 + cx] : 0.f, t.w(cz, cy, cx));
   return acc;
 }
 

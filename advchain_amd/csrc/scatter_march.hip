@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
   const int V = (int)d.voxels();
   const float* p = x + (int64_t)n * ctot * V;
   float m[RW];
+  bool bad[RW];
 #pragma unroll
-  for (int r = 0; r < RW; ++r) m[r] = 0.f;
+  for (int r = 0; r < RW; ++r) { m[r] = 0.f; bad[r] = false; }
   for (int xx = lane; xx < d.s2; xx += 64) {
     float v[RW][C];
 #pragma unroll
@@ -98,18 +99,24 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int c = 0; c < C; ++c) m[r] = fmaxf(m[r], fabsf(v[r][c]));
+      for (int c = 0; c < C; ++c) {
+        m[r] = fmaxf(m[r], fabsf(v[r][c]));
+        bad[r] = bad[r] || !(fabsf(v[r][c]) <= 3.0e38f);      // NaN (which fmaxf drops) or inf
+      }
   }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m[r] = fmaxf(m[r], __shfl_xor(m[r], o, 64));
+    // a non-finite gradient must not come out as finite numbers: the row's maximum becomes +inf, the fixed-point scale of
+    // every workgroup that visits it 0 and its conversion factor inf -- its outputs are 0 * inf = NaN
+    if (__ballot(bad[r]) != 0) m[r] = __int_as_float(0x7f800000);
   }
   if (lane < RW && row0 + lane < rows_per_n) {
     float mine = m[0];
 #pragma unroll
     for (int r = 1; r < RW; ++r) mine = lane == r ? m[r] : mine;
-    rowmax[(int64_t)n * rows_per_n + row0 + lane] = mine < 3.0e38f ? mine : 0.f;   // (an inf row scales like an empty one)
+    rowmax[(int64_t)n * rows_per_n + row0 + lane] = mine;
   }
 }
 

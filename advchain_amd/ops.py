@@ -63,10 +63,14 @@ def _on_tensor_device(fn):
     @functools.wraps(fn)
     def guarded(*args, **kwargs):
         for a in args:
+            if isinstance(a, (tuple, list)) and a and isinstance(a[0], torch.Tensor):
+                a = a[0]
             if isinstance(a, torch.Tensor):
-                if a.is_cuda and _raw_device is not None and a.device.index != _raw_device():
-                    with torch.cuda.device(a.device):
-                        return fn(*args, **kwargs)
+                if a.is_cuda:
+                    cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+                    if a.device.index != cur:
+                        with torch.cuda.device(a.device):
+                            return fn(*args, **kwargs)
                 break
         return fn(*args, **kwargs)
     return guarded
@@ -431,7 +435,7 @@ def grid_displacement(grid):
     and then the prediction)."""
     hit = getattr(grid, "_advchain_disp", None)
     if hit is None or hit[2] != grid._version:
-        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, tuple(grid.shape[2:])]
+        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, (str(grid.device),) + tuple(grid.shape[2:])]
         grid._advchain_disp = hit
     return hit
 
@@ -448,7 +452,7 @@ def forward_hint(grid):
                 _WARP_HINTS[hit[4]] = hit[1]
         if hit[1] is not None:
             return hit[1]
-    return _WARP_HINTS.get(tuple(grid.shape[2:]))
+    return _WARP_HINTS.get((str(grid.device),) + tuple(grid.shape[2:]))
 
 
 def warp_halo(entry, d):
@@ -713,7 +717,7 @@ class _DemonsField(torch.autograd.Function):
         row = (lambda m: None) if disp is None else (lambda m: disp[m])
         # what the squarings of the PREVIOUS field of this shape measured (a field changes little between two ascent
         # steps): picks the forward kernel per squaring, nothing else
-        key = (tuple(s1.shape), n)
+        key = (str(s1.device), tuple(s1.shape), n)
         hints = _CHAIN_HINTS.get(key)
         phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
@@ -778,8 +782,18 @@ class _DemonsField(torch.autograd.Function):
 
 
 _LAST_FIELD_BOUND = None
-_CHAIN_HINTS = {}     # (velocity shape, n) -> displacement of phi_0..phi_n measured by the last backward of such a chain
-_WARP_HINTS = {}      # spatial dims -> displacement of the last grid of that shape whose bound was read
+class _HintCache(dict):
+    """A small bounded map (kernel-selection hints keyed by device and shape; cleared when it outgrows its cap)."""
+    CAP = 256
+
+    def __setitem__(self, key, value):
+        if len(self) >= self.CAP and key not in self:
+            self.clear()
+        dict.__setitem__(self, key, value)
+
+
+_CHAIN_HINTS = _HintCache()     # (device, velocity shape, n) -> displacement of phi_0..phi_n measured by the last backward of such a chain
+_WARP_HINTS = _HintCache()      # (device, spatial dims) -> displacement of the last grid of that shape whose bound was read
 
 
 @_on_tensor_device
@@ -789,7 +803,7 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, False)
     if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
         rb, idx = _LAST_FIELD_BOUND
-        q._advchain_disp = [rb, None, q._version, idx, tuple(q.shape[2:])]
+        q._advchain_disp = [rb, None, q._version, idx, (str(q.device),) + tuple(q.shape[2:])]
         _LAST_FIELD_BOUND = None
     return q
 
@@ -805,8 +819,8 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
-        qp._advchain_disp = [rb, None, qp._version, idx, tuple(qp.shape[2:])]
-        qm._advchain_disp = [rb, None, qm._version, idx, tuple(qm.shape[2:])]
+        qp._advchain_disp = [rb, None, qp._version, idx, (str(qp.device),) + tuple(qp.shape[2:])]
+        qm._advchain_disp = [rb, None, qm._version, idx, (str(qm.device),) + tuple(qm.shape[2:])]
         _LAST_FIELD_BOUND = None
     return qp, qm
 

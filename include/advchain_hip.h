@@ -98,7 +98,8 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * violating the guarantee would be dropped.  Exact bounds beyond the gather form (3D: 2..4 voxels; 2D: 4, 8, 16 px; both
  * entries) select the owner-computes scatters of scatter_march.hip: LDS 32-bit fixed-point accumulators scaled by the
  * max|grad_out| over the rows a workgroup visits, plain stores, no zero fill, bit-reproducible, relative error of the
- * accumulation <= 2^-21 of that local maximum per deposit.  (Launches that do not track max|result| -- strict gather,
+ * accumulation <= 2^-23 / 2^-22 / 2^-21 (bounds of 2 / 3 / 4; 2^-18 for 5..8) of that local maximum per deposit; a NaN / inf in
+ * grad_out turns the outputs of the workgroups that visit its row into NaN (it is not dropped).  (Launches that do not track max|result| -- strict gather,
  * window scatter, owner-computes scatters -- leave a marker in the workspace, and a chained scatter call after them
  * recomputes max|grad_out| on the device.) */
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,

@@ -1104,6 +1104,48 @@ def test_kl_term_in_every_kernel_variant(dims, K):
     assert abs(float(v) - float(O.consistency_loss(pred, ref, ["kl"], [1.0]))) < 1e-7 + 2e-5 * abs(float(v))
 
 
+@pytest.mark.parametrize("dims,amp", [((24, 21, 44), 0.4), ((24, 21, 44), 2.6), ((16, 32, 64), 0.6), ((16, 32, 64), 3.4)])
+def test_forward_results_do_not_depend_on_the_displacement_hint(dims, amp):
+    """The displacement hint (bits 8..15 of clamp_grid / final_mode) only selects the 3D forward kernel -- z-marching ring
+    or LDS tiles, include/advchain_hip.h -- and comes from asynchronous read-backs and the history of earlier calls
+    (ops.forward_hint, ops._CHAIN_HINTS): the two kernels must therefore agree BIT FOR BIT, or solver results would
+    depend on timing.  Sub-voxel and multi-voxel fields, image warps (C = 1, 4) and the self-composition."""
+    ops = _ops()
+    phi = _smooth_field(dims, amp, 67).to(DEV)
+    for C in (1, 4):
+        x = rand((2, C) + dims, 68 + C).to(DEV)
+        for clamp in (True, False):
+            outs = [ops.raw_grid_sample_fwd(x, phi, 0, 0, clamp, disp_hint=h) for h in (None, 0.5, 4.5, 9.0)]
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), (C, clamp)
+    comps = [ops.raw_compose_self_fwd(phi, disp_hint=h) for h in (None, 0.5, 4.5, 9.0)]
+    for o in comps[1:]:
+        assert torch.equal(o, comps[0])
+    finals = [ops.raw_compose_self_fwd(phi, phi0=phi, final_mode=1, disp_hint=h) for h in (None, 0.5, 4.5)]
+    for o in finals[1:]:
+        assert torch.equal(o, finals[0])
+
+
+@pytest.mark.parametrize("dims,amp,bound", [((12, 20, 16), 2.7, 3), ((9, 18, 64), 3.6, 4), ((40, 72), 3.3, 4), ((37, 100), 6.5, 8)])
+def test_owner_computes_scatters_propagate_non_finite_gradients(dims, amp, bound):
+    """A NaN / inf in grad_out must not come out of the fixed-point scatters as finite numbers (the row-maxima pass used
+    to drop NaN and map an inf row to scale 0): the affected region turns NaN, the rest stays finite and correct."""
+    ops = _ops()
+    d = len(dims)
+    phi = _smooth_field(dims, amp, 61).to(DEV)
+    ws = ops._scatter_workspace(2, dims, DEV)
+    w = rand((2, d) + dims, 62).to(DEV)
+    clean = ops.raw_compose_self_bwd(w, phi, ws, chain=False, halo=-bound)
+    assert torch.isfinite(clean).all()
+    for poison in (float("nan"), float("inf")):
+        wp = w.clone()
+        idx = (0, 1) + tuple(s // 2 for s in dims)
+        wp[idx] = poison
+        g = ops.raw_compose_self_bwd(wp, phi, ws, chain=False, halo=-bound)
+        assert not torch.isfinite(g[0]).all(), poison          # it surfaces ...
+        assert torch.isfinite(g[1]).all() and torch.equal(g[1], clean[1])      # ... and the other sample is untouched
+
+
 @pytest.mark.parametrize("dims", [(9, 11), (5, 6, 7)])
 def test_out_of_range_corners_do_not_read_the_image(dims):
     """Corner loads are unconditional (indices clamped into the volume) and an out-of-range corner's VALUE is
