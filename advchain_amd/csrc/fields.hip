@@ -1216,7 +1216,7 @@ int advchain_axpy(const float* x, const float* y, float* out, float a, int64_t n
 }
 
 int64_t advchain_norm_workspace(int64_t N, int64_t M) {
-  const int64_t chunk = 16384;
+  const int64_t chunk = 4096;   // (16384 left a 32 x 65536 parameter with 128 workgroups on 256 CUs)
   return N * ((M + chunk - 1) / chunk);  // floats
 }
 
@@ -1226,10 +1226,10 @@ int advchain_norm_axpy_gated(const float* base, const float* x, float* out, floa
   ADVCHAIN_CHECK_ARG(x && out && workspace && (!gate || old), "norm_axpy: null pointer");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && M >= 0, "norm_axpy: bad N/M");
   if (N == 0 || M == 0) return ADVCHAIN_OK;
-  const int chunk = 16384;
+  const int chunk = 4096;
   const int nb = (int)((M + chunk - 1) / chunk);
   dim3 grid(nb, (unsigned)N), blk(kBlock);
-  if (nb == 1) {
+  if (M <= 16384) {      // low-resolution parameters: one workgroup per sample does both steps in one launch
     hipLaunchKernelGGL(k_norm_axpy_row, dim3((unsigned)N), blk, 0, (hipStream_t)stream, base, x, step, out, M, gate, old);
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;

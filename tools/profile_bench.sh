@@ -11,11 +11,13 @@ cd /tmp
 run() {  # name, command...
   local name=$1; shift
   rm -rf /tmp/rp_$name
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$name -o $name -- "$@" > "$out/${name}_under_rocprof.log" 2>&1
   cp "$(find /tmp/rp_$name -name "${name}_kernel_stats.csv" | head -1)" "$out/${name}_kernel_stats.csv"
 }
 run cfg2 python $repo/bench.py --steps 10 --warmup 3 --only-workload
 run cfg3 python $repo/bench.py --workload cfg3 --steps 5 --warmup 2 --only-workload
+run cfg5 python $repo/bench.py --workload cfg5 --steps 3 --warmup 1 --only-workload
 run kb3d python $repo/tools/kernel_bench.py --shape 3d
 python $repo/tools/stats_per_call.py "$out/cfg2_kernel_stats.csv" 14 30
 python $repo/tools/stats_per_call.py "$out/cfg3_kernel_stats.csv" 8 30
+python $repo/tools/stats_per_call.py "$out/cfg5_kernel_stats.csv" 4 30

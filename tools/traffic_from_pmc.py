@@ -53,9 +53,13 @@ for _e, _self in (("advchain_grid_sample_bwd", "false"), ("advchain_compose_self
     ENTRIES[_e] = (ENTRIES[_e][0] + _p, ENTRIES[_e][1] + "|" + "|".join(_p))
 ENTRIES["advchain_grid_sample_bwd"][0].append(r"k_march_rowmax<[14]>")
 ENTRIES["advchain_compose_self_bwd"][0].append(r"k_march_rowmax<[23]>")
-ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd"], r"k_affine_warp_fwd")
+ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd", r"k_affine_box_fwd"], r"k_affine_warp_fwd|k_affine_box_fwd")
+# round 3: LDS-box theta gradient and owner-computes grad_in scatter; one entry launch = one k_affine_geometry-less count of
+# the theta kernel (every backward call launches exactly one k_reduce_partials)
+ENTRIES["advchain_affine_warp_bwd"] = ([r"k_affine_warp_bwd<", r"k_affine_gather_bwd<", r"k_affine_geometry<", r"k_reduce_partials",
+                                        r"k_affine_box_gtheta<", r"k_affine_box_gin<"], r"k_reduce_partials")
 WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
-                  r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4")   # 16 B / lane
+                  r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4|k_affine_box_fwd|k_affine_box_gtheta")   # 16 B / lane
 MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
 
 
@@ -76,7 +80,7 @@ def load(path):
 
 def main(root, out):
     res = {"_doc": __doc__.strip().split("\n\n")[1]}
-    for wl in ("cfg2", "cfg3"):
+    for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
         fetch = load(os.path.join(root, "pmc_fetch_size_%s.csv" % wl))
         write = load(os.path.join(root, "pmc_write_size_%s.csv" % wl))
         if not fetch:
