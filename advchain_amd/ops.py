@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .bands import gaussian_weights_1d
 
-_INTERP = {"bilinear": 0, "trilinear": 0, "linear": 0, "nearest": 1}
+_INTERP = {"bilinear": 0, "trilinear": 0, "linear": 0, "nearest": 1, "bicubic": 2}
 _PAD = {"zeros": 0, "border": 1, "reflection": 2}
 _GAUSS9 = _lib.float_array(gaussian_weights_1d(1.0))
 
@@ -79,7 +79,7 @@ def _on_tensor_device(fn):
 def interp_code(interp):
     if interp not in _INTERP:
         raise NotImplementedError("interpolation mode %r is not implemented by the HIP sampler "
-                                  "(supported: bilinear/trilinear, nearest)" % (interp,))
+                                  "(supported: bilinear/trilinear, nearest, bicubic (2D))" % (interp,))
     return _INTERP[interp]
 
 
@@ -504,12 +504,74 @@ def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=F
         raise RuntimeError("grid_sample(): expected grid and input to have same batch size, but got input with sizes "
                            "%s and grid with sizes %s" % (list(inp.shape), list(grid.shape)))
     _same_device(inp, grid)
+    if code == 2:
+        if nd != 2:      # F.grid_sample's own message for 5-D input
+            raise RuntimeError("grid_sampler(): bicubic interpolation only supports 4D input")
+        return _GridSampleBicubic.apply(inp, torch.clamp(grid, -1, 1) if clamp_grid else grid, pad_code(padding_mode))
     disp = None
     if (ADAPTIVE_HALO and code == 0 and torch.is_grad_enabled() and inp.requires_grad and grid.is_cuda
             and inp.shape[2:] == grid.shape[2:] and grid.dtype == torch.float32 and grid.is_contiguous()):
         disp = grid_displacement(grid)       # the backward sizes its halo / picks the gather form from it
     hint = forward_hint(grid) if (code == 0 and nd == 3 and grid.is_cuda) else None
     return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp, hint)
+
+
+class _GridSampleBicubic(torch.autograd.Function):
+    """F.grid_sample(inp, grid^T, mode='bicubic', padding_mode, align_corners=True) with a PLANAR grid (N,2,OH,OW); 2D only
+    (adv_morph.py:255-258,546-557 with forward_interp / backward_interp = 'bicubic')."""
+
+    @staticmethod
+    def forward(ctx, inp, grid, padding):
+        inp, grid = _dev(inp, "input"), _dev(grid, "grid")
+        N, C = inp.shape[:2]
+        out = torch.empty((N, C) + tuple(grid.shape[2:]), device=inp.device, dtype=torch.float32)
+        _lib.check(_lib.load().advchain_grid_sample_bicubic2d_fwd(_ptr(inp), _ptr(grid), _ptr(out), N, C,
+                                                                  _lib.dims_array(inp.shape[2:]), _lib.dims_array(grid.shape[2:]),
+                                                                  padding, _stream()), "grid_sample_bicubic2d_fwd")
+        ctx.save_for_backward(inp, grid)
+        ctx.padding = padding
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        inp, grid = ctx.saved_tensors
+        need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_in or need_grid):
+            return None, None, None
+        gin = torch.empty_like(inp) if need_in else None
+        ggrid = torch.empty_like(grid) if need_grid else None
+        N, C = inp.shape[:2]
+        _lib.check(_lib.load().advchain_grid_sample_bicubic2d_bwd(_ptr(_dev(gout, "grad")), _ptr(inp), _ptr(grid), _ptr(gin), _ptr(ggrid),
+                                                                  N, C, _lib.dims_array(inp.shape[2:]), _lib.dims_array(grid.shape[2:]),
+                                                                  ctx.padding, _stream()), "grid_sample_bicubic2d_bwd")
+        return gin, ggrid, None
+
+
+class _AffineGrid2D(torch.autograd.Function):
+    """F.affine_grid(theta, (N, C, H, W), align_corners=True) as a planar grid (N,2,H,W) (bicubic affine warps only: the
+    linear / nearest ones never materialise the grid)."""
+
+    @staticmethod
+    def forward(ctx, theta, H, W):
+        theta = _dev(theta, "theta")
+        N = theta.shape[0]
+        grid = torch.empty((N, 2, H, W), device=theta.device, dtype=torch.float32)
+        _lib.check(_lib.load().advchain_affine_grid2d_fwd(_ptr(theta), _ptr(grid), N, _lib.dims_array((H, W)), _stream()),
+                   "affine_grid2d_fwd")
+        ctx.dims = (H, W)
+        return grid
+
+    @staticmethod
+    def backward(ctx, ggrid):
+        H, W = ctx.dims
+        ggrid = _dev(ggrid, "grad")
+        N = ggrid.shape[0]
+        lib = _lib.load()
+        dims = _lib.dims_array((H, W))
+        ws = torch.empty(max(1, lib.advchain_affine_grid2d_bwd_workspace(N, dims)), device=ggrid.device, dtype=torch.float32)
+        gth = torch.empty((N, 2, 3), device=ggrid.device, dtype=torch.float32)
+        _lib.check(lib.advchain_affine_grid2d_bwd(_ptr(ggrid), _ptr(gth), _ptr(ws), N, dims, _stream()), "affine_grid2d_bwd")
+        return gth, None, None
 
 
 class _AffineWarp(torch.autograd.Function):
@@ -554,7 +616,13 @@ def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
         raise RuntimeError("Expected a batch of %dD affine matrices of shape Nx%dx%d for size %s. Got %s."
                            % (nd, nd, nd + 1, list(inp.shape), list(theta.shape)))
     _same_device(inp, theta)
-    return _AffineWarp.apply(inp, theta, interp_code(interp), pad_code(padding_mode))
+    code = interp_code(interp)
+    if code == 2:
+        if nd != 2:
+            raise RuntimeError("grid_sampler(): bicubic interpolation only supports 4D input")
+        grid = _AffineGrid2D.apply(theta, int(inp.shape[2]), int(inp.shape[3]))
+        return _GridSampleBicubic.apply(inp, grid, pad_code(padding_mode))
+    return _AffineWarp.apply(inp, theta, code, pad_code(padding_mode))
 
 
 class _AffineTheta(torch.autograd.Function):

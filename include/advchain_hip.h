@@ -33,6 +33,7 @@ extern "C" {
 
 #define ADVCHAIN_INTERP_LINEAR 0  /* 'bilinear' (4-D) / trilinear (5-D) */
 #define ADVCHAIN_INTERP_NEAREST 1
+#define ADVCHAIN_INTERP_BICUBIC 2  /* 2D only; its own entry points (advchain_grid_sample_bicubic2d_*) */
 #define ADVCHAIN_PAD_ZEROS 0
 #define ADVCHAIN_PAD_BORDER 1
 #define ADVCHAIN_PAD_REFLECTION 2
@@ -140,6 +141,25 @@ int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* d
 int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
                              float* grad_theta, float* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* dims, int interp, int padding, void* stream);
+
+/* ---- bicubic sampling (2D) ----------------------------------------------------------------
+ * replaces: F.grid_sample(data, grid, mode='bicubic', padding_mode, align_corners=True), reached through the
+ *           forward_interp / backward_interp config keys (adv_morph.py:255-258,546-557; adv_affine.py:297-313; ATen has
+ *           no 5-D bicubic: 2D only).  Cubic convolution, A = -0.75, every tap's coordinate padded on its own.
+ * in (N,C,H,W), grid (N,2,OH,OW) planar, out (N,C,OH,OW).  bwd: grad_in is zero-filled here and accumulated with
+ * atomics, grad_grid overwritten; either may be NULL.                                                              */
+int advchain_grid_sample_bicubic2d_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C,
+                                       const int64_t* in_dims, const int64_t* out_dims, int padding, void* stream);
+int advchain_grid_sample_bicubic2d_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
+                                       float* grad_grid, int64_t N, int64_t C, const int64_t* in_dims,
+                                       const int64_t* out_dims, int padding, void* stream);
+/* replaces: F.affine_grid(theta, size, align_corners=True) for the bicubic affine warp (adv_affine.py:297-305): theta
+ *           (N,2,3) -> planar grid (N,2,H,W), and its adjoint grad_grid -> grad_theta (deterministic two-stage sum;
+ *           workspace: advchain_affine_grid2d_bwd_workspace floats).                                                */
+int advchain_affine_grid2d_fwd(const float* theta, float* grid, int64_t N, const int64_t* dims, void* stream);
+int64_t advchain_affine_grid2d_bwd_workspace(int64_t N, const int64_t* dims);
+int advchain_affine_grid2d_bwd(const float* grad_grid, float* grad_theta, float* workspace, int64_t N, const int64_t* dims,
+                               void* stream);
 
 /* ---- affine parameters -> matrices -----------------------------------------------------
  * replaces: AdvAffine.gen_batch_affine_matrix adv_affine.py:210-273 (Hardtanh, Euler z-y'-x''

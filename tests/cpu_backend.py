@@ -19,12 +19,12 @@ def _planar_to_last(grid):
 def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
     if clamp_grid:
         grid = torch.clamp(grid, -1, 1)
-    mode = "nearest" if interp == "nearest" else "bilinear"
+    mode = interp if interp in ("nearest", "bicubic") else "bilinear"
     return F.grid_sample(inp, _planar_to_last(grid), mode=mode, padding_mode=padding_mode, align_corners=True)
 
 
 def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
-    mode = "nearest" if interp == "nearest" else "bilinear"
+    mode = interp if interp in ("nearest", "bicubic") else "bilinear"
     g = F.affine_grid(theta, inp.size(), align_corners=True)
     return F.grid_sample(inp, g, mode=mode, padding_mode=padding_mode, align_corners=True)
 

@@ -685,6 +685,71 @@ def test_affine_warp(dims, C, pad):
     assert float((n_out.cpu() != n_ref).float().mean()) < 2e-3  # rounding ties at .5 may differ by fp order
 
 
+@pytest.mark.parametrize("dims,C", [((17, 23), 3), ((32, 40), 1), ((64, 48), 4)])
+@pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
+def test_bicubic_grid_sample_and_affine_warp(dims, C, pad):
+    """mode='bicubic' (2D; adv_morph.py:255-258,546-557, adv_affine.py:297-313 through forward_interp / backward_interp or an
+    explicit interp argument): advchain_grid_sample_bicubic2d_fwd/bwd and advchain_affine_grid2d_fwd/bwd against
+    F.grid_sample / F.affine_grid on the CPU -- values, grad_input, grad_grid / grad_theta; grid points inside, on the
+    border and outside the image."""
+    ops = _ops()
+    inp = rand((2, C) + dims, 41)
+    w = rand((2, C) + dims, 42)
+    grid = rand((2,) + dims + (2,), 43, -1.3, 1.3)
+    grid.view(-1, 2)[0] = torch.tensor([1.0, -1.0])
+    grid.view(-1, 2)[1] = torch.tensor([-1.0, 0.5])
+    a, g = inp.clone().requires_grad_(True), grid.clone().requires_grad_(True)
+    ref = F.grid_sample(a, g, mode="bicubic", padding_mode=pad, align_corners=True)
+    (ref * w).sum().backward()
+    a2, g2 = inp.to(DEV).requires_grad_(True), to_planar(grid).to(DEV).requires_grad_(True)
+    out = ops.grid_sample(a2, g2, "bicubic", pad)
+    (out * w.to(DEV)).sum().backward()
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(a2.grad.cpu(), a.grad) < TOL * max(1.0, float(a.grad.abs().max()))
+    assert maxdiff(g2.grad.cpu(), to_planar(g.grad)) < 1e-4 * max(1.0, float(g.grad.abs().max()))
+    theta = (torch.eye(2, 3).repeat(2, 1, 1) + 0.2 * rand((2, 2, 3), 44)).contiguous()
+    a, t = inp.clone().requires_grad_(True), theta.clone().requires_grad_(True)
+    ref = F.grid_sample(a, F.affine_grid(t, inp.size(), align_corners=True), mode="bicubic", padding_mode=pad, align_corners=True)
+    (ref * w).sum().backward()
+    a2, t2 = inp.to(DEV).requires_grad_(True), theta.to(DEV).requires_grad_(True)
+    out = ops.affine_warp(a2, t2, "bicubic", pad)
+    (out * w.to(DEV)).sum().backward()
+    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(a2.grad.cpu(), a.grad) < TOL * max(1.0, float(a.grad.abs().max()))
+    assert rel(t2.grad.cpu(), t.grad) < 5e-5
+    with pytest.raises(RuntimeError):      # ATen's own restriction: no 5-D bicubic
+        ops.grid_sample(torch.zeros(1, 1, 4, 4, 4, device=DEV), torch.zeros(1, 3, 4, 4, 4, device=DEV), "bicubic", "zeros")
+
+
+def test_transforms_with_bicubic_interpolation():
+    """AdvMorph / AdvAffine called with interp='bicubic' (2D) against the oracle (which hands the mode to F.grid_sample as
+    the reference does): forward, backward and the parameter gradients."""
+    from advchain_amd.augmentor import AdvAffine, AdvMorph
+    from oracle import advchain_oracle as O
+    ds = [2, 1, 32, 40]
+    data = smooth_data(2, 1, ds[2:], 51)
+    w = rand(tuple(ds), 52)
+    cfgs = [(AdvMorph, O.OracleMorph, dict(epsilon=1.5, data_size=ds, vector_size=[4, 5])),
+            (AdvAffine, O.OracleAffine, dict(rot=30 / 180., scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=ds))]
+    for cls, ocls, cfg in cfgs:
+        o = ocls(2, cfg)
+        o.init_parameters()
+        p0 = o.param.detach().clone()
+        t = cls(spatial_dims=2, config_dict=cfg, device=torch.device(DEV))
+        t.init_parameters()
+        po = p0.clone().requires_grad_(True)
+        o.param = po
+        ref = o.forward(data, interp="bicubic")
+        (ref * w).sum().backward()
+        pg = p0.to(DEV).requires_grad_(True)
+        t.param = pg
+        out = t.forward(data.to(DEV), interp="bicubic")
+        (out * w.to(DEV)).sum().backward()
+        assert maxdiff(out.cpu(), ref) < TOL, cls.__name__
+        assert maxdiff(pg.grad.cpu(), po.grad) < 1e-4 * max(1.0, float(po.grad.abs().max())), cls.__name__
+        assert maxdiff(t.backward(data.to(DEV), interp="bicubic").cpu(), o.backward(data, interp="bicubic")) < TOL, cls.__name__
+
+
 @pytest.mark.parametrize("nd", [2, 3])
 def test_affine_theta(nd):
     from oracle import advchain_oracle as O
