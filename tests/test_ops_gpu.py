@@ -704,7 +704,7 @@ def test_bicubic_grid_sample_and_affine_warp(dims, C, pad):
     a2, g2 = inp.to(DEV).requires_grad_(True), to_planar(grid).to(DEV).requires_grad_(True)
     out = ops.grid_sample(a2, g2, "bicubic", pad)
     (out * w.to(DEV)).sum().backward()
-    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(out.cpu(), ref) < 5e-5      # (cubic taps overshoot: a position ulp moves a value by up to ~2x what it does bilinearly; contract 1e-4)
     assert maxdiff(a2.grad.cpu(), a.grad) < TOL * max(1.0, float(a.grad.abs().max()))
     assert maxdiff(g2.grad.cpu(), to_planar(g.grad)) < 1e-4 * max(1.0, float(g.grad.abs().max()))
     theta = (torch.eye(2, 3).repeat(2, 1, 1) + 0.2 * rand((2, 2, 3), 44)).contiguous()
@@ -714,7 +714,7 @@ def test_bicubic_grid_sample_and_affine_warp(dims, C, pad):
     a2, t2 = inp.to(DEV).requires_grad_(True), theta.to(DEV).requires_grad_(True)
     out = ops.affine_warp(a2, t2, "bicubic", pad)
     (out * w.to(DEV)).sum().backward()
-    assert maxdiff(out.cpu(), ref) < TOL
+    assert maxdiff(out.cpu(), ref) < 5e-5      # (cubic taps overshoot: a position ulp moves a value by up to ~2x what it does bilinearly; contract 1e-4)
     assert maxdiff(a2.grad.cpu(), a.grad) < TOL * max(1.0, float(a.grad.abs().max()))
     assert rel(t2.grad.cpu(), t.grad) < 5e-5
     with pytest.raises(RuntimeError):      # ATen's own restriction: no 5-D bicubic
