@@ -23,6 +23,15 @@
 
 namespace advchain {
 
+// 32-bit byte offsets from a wave-uniform base: the load takes the base from SGPRs (global_load v, v_off, s[base]) instead of
+// a 64-bit address built in VGPRs per load (39 v_lshl_add_u64 in the C = 1 kernel).  The launchers bound a volume by 2^31 bytes.
+__device__ __forceinline__ float ld_off(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 // d(sample)/d(unnormalised coordinate) * go in difference form: ax = go * sum_zy wz wy (v[z][y][1] - v[z][y][0]) and so on
 // -- a third of the instructions of the signed-product form of sample_linear_bwd (these kernels are VALU bound), the same
 // value up to the rounding of the differences.
@@ -36,7 +45,7 @@ __device__ __forceinline__ void coord_path_diff(const float* __restrict__ in, fl
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-      for (int cx = 0; cx < 2; ++cx) v[cz][cy][cx] = in[o.at(cz, cy, cx)];
+      for (int cx = 0; cx < 2; ++cx) v[cz][cy][cx] = ld_off(in, (unsigned)o.at(cz, cy, cx) * 4u);
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
@@ -120,6 +129,54 @@ __global__ void __launch_bounds__(kBlock) k_march_rowmax(const float* __restrict
   }
 }
 
+// The same for rows of exactly 64 voxels, 16 bytes per lane: 16 lanes a row, 4 rows per load instruction, 16 rows a wave
+// in flight (7.1 -> 4 us at 4 x 1 x 128 x 128 x 64: the dword form is a quarter of the bytes per vector-memory instruction).
+template <int C>
+__global__ void __launch_bounds__(kBlock) k_march_rowmax64(const float* __restrict__ x, float* __restrict__ rowmax, int rows_per_n, int ctot) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (4 * U) + (lane >> 4);
+  const int n = blockIdx.y;
+  if (row0 - (lane >> 4) >= rows_per_n) return;
+  const int64_t V = (int64_t)rows_per_n * 64;
+  const float* p = x + (int64_t)n * ctot * V + (lane & 15) * 4;
+  float4 v[U][C];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = min(row0 + 4 * u, rows_per_n - 1);
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[u][c] = *reinterpret_cast<const float4*>(p + (int64_t)c * V + (int64_t)row * 64);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float m = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float q = fmaxf(fmaxf(fabsf(v[u][c].x), fabsf(v[u][c].y)), fmaxf(fabsf(v[u][c].z), fabsf(v[u][c].w)));
+      m = fmaxf(m, q);
+      bad = bad || !(fabsf(v[u][c].x) <= 3.0e38f) || !(fabsf(v[u][c].y) <= 3.0e38f) || !(fabsf(v[u][c].z) <= 3.0e38f) ||
+            !(fabsf(v[u][c].w) <= 3.0e38f);
+    }
+    if (bad) m = __int_as_float(0x7f800000);                       // (fmaxf keeps +inf through the reduction below)
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int row = row0 + 4 * u;
+    if ((lane & 15) == 0 && row < rows_per_n) rowmax[(int64_t)n * rows_per_n + row] = m;
+  }
+}
+
+// launch of the row maxima (either form)
+template <int C>
+static void launch_rowmax(const float* x, float* rowmax, Dims d, int rows, int64_t N, int ctot, hipStream_t st) {
+  if (d.s2 == 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int per_block = (kBlock / 64) * 16;
+    hipLaunchKernelGGL(k_march_rowmax64<C>, dim3((unsigned)((rows + per_block - 1) / per_block), (unsigned)N), dim3(kBlock), 0, st, x, rowmax, rows, ctot);
+  } else {
+    hipLaunchKernelGGL(k_march_rowmax<C>, dim3((unsigned)((rows + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N), dim3(kBlock), 0, st, x, rowmax, d, rows, ctot);
+  }
+}
+
 // SELF : in == grid == phi (C == 3); gin receives value path + coordinate path     (advchain_compose_self_bwd)
 // !SELF: gin <- value path; GG: ggrid <- coordinate path                            (advchain_grid_sample_bwd)
 // NWV waves per workgroup share one accumulator tile, so LDS does not cap the waves of a CU: 8 for 8 owned rows, 4 for 4
@@ -134,6 +191,9 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
                   float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int TY, int H, int NS,
                   int clamp_grid, int32_t* __restrict__ ws, int nseg, int c0) {
   constexpr bool SL = CT != C;
+  // grad_grid of an image warp: the coordinate path of a workgroup's OWN samples is evaluated when their row is visited for
+  // its deposits (the taps are built once, no second set of loads), and leaves at once -- it needs nothing from the accumulator
+  constexpr bool EARLY = GG && !SELF && !SL;
   extern __shared__ int acc[];                   // [slot 2H+3][C][TY][64]
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
@@ -193,24 +253,24 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
       const int r = wave + k * NWV;
       if (r >= nrows) continue;                                      // wave-uniform
       const int ys = min(max(y0 - H + r, 0), d.s1 - 1);              // clamped: no per-lane branch around the loads
-      const int s = (zq * d.s1 + ys) * d.s2 + xl;
+      const unsigned s = (unsigned)((zq * d.s1 + ys) * d.s2 + xl) * 4u;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) g[k][a] = gn[(int64_t)a * V + s];
+      for (int a = 0; a < 3; ++a) g[k][a] = ld_off(gn + (int64_t)a * V, s);
 #pragma unroll
-      for (int c = 0; c < C; ++c) go[k][c] = gon[(int64_t)c * V + s];
+      for (int c = 0; c < C; ++c) go[k][c] = ld_off(gon + (int64_t)c * V, s);
     }
   };
   auto load_own = [&](int zt, float (&g)[MAXF][3], float (&go)[MAXF][C]) {
-    if (!(SELF || GG)) return;
+    if (!(SELF || GG) || EARLY) return;
     const int zq = min(max(zt, 0), d.s0 - 1);
 #pragma unroll
     for (int k = 0; k < MAXF; ++k) {
       const int uy = min(y0 + wave + k * NWV, d.s1 - 1);
-      const int s = (zq * d.s1 + uy) * d.s2 + xl;
+      const unsigned s = (unsigned)((zq * d.s1 + uy) * d.s2 + xl) * 4u;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) g[k][a] = gn[(int64_t)a * V + s];
+      for (int a = 0; a < 3; ++a) g[k][a] = ld_off(gn + (int64_t)a * V, s);
 #pragma unroll
-      for (int c = 0; c < C; ++c) go[k][c] = gon[(int64_t)c * V + s];
+      for (int c = 0; c < C; ++c) go[k][c] = ld_off(gon + (int64_t)c * V, s);
     }
   };
   float g[MAXR][3], go[MAXR][C], fg[MAXF][3], fgo[MAXF][C];
@@ -235,35 +295,88 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         const int r = wave + k * NWV;
         const int ys = y0 - H + r;
         if (r >= nrows || ys < 0 || ys >= d.s1) continue;            // wave-uniform
-        if (clamp_grid) { g[k][0] = clamp_unit(g[k][0]); g[k][1] = clamp_unit(g[k][1]); g[k][2] = clamp_unit(g[k][2]); }
+        const bool own = EARLY && ys >= y0 && ys < yend && zp >= za && zp < zb;   // wave-uniform
+        bool pass[3] = {true, true, true};
+        if (clamp_grid) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { pass[a] = g[k][a] >= -1.f && g[k][a] <= 1.f; g[k][a] = clamp_unit(g[k][a]); }
+        }
         // The kernel is VALU bound (4 waves a SIMD, each 22% of its cycles in VALU issue) and most visits of halo rows
         // and halo planes deposit nothing here: the y and z taps alone decide that, for the whole wave.
         Taps<3, PAD> t;
         t.y = make_tap<PAD>(g[k][1], d.s1);
         t.z = make_tap<PAD>(g[k][2], d.s0);
         const bool reach = xin && t.y.i0 + 1 >= y0 && t.y.i0 < yend && t.z.i0 + 1 >= max(za, zp - H) && t.z.i0 < min(zb, zp + H + 2);
-        if (__ballot(reach) == 0) continue;
+        const bool any = __ballot(reach) != 0;
+        if (!any && !own) continue;
         t.x = make_tap<PAD>(g[k][0], d.s2);
+        if (any) {
+        // Per-axis masked weights (a corner outside this workgroup's columns / rows / planes, or outside the ring's reach
+        // of this step, gets weight 0; what is owned lies inside the volume, so the corner's own validity is implied) and
+        // per-axis clamped cell coordinates: the eight deposits need no per-corner branch (the branchy form spent ~20
+        // instructions and two exec-mask regions per corner).  One wave-uniform test per (z, y) corner pair remains: half
+        // of the visits are halo rows that reach the tile with one of their two rows / planes only.
+        float wxm[2], wym[2], wzm[2];
+        int colx[2], rowy[2], slotz[2];
+        bool anyy[2], anyz[2];
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const int pxx = t.x.i0 + cx;
+          // (a masked lane deposits its zero into its OWN column: clamped to the row ends, the lanes beyond a short row or
+          // in the halo columns of an x segment all hit one cell, and same-address LDS atomics serialise -- rows of 80
+          // voxels ran 2.4x slower)
+          const bool okx = xin && pxx >= xo0 && pxx < xo1;
+          wxm[cx] = okx ? t.wx(cx) : 0.f;
+          colx[cx] = okx ? pxx - xbase : lane;
+        }
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+          const int py = t.y.i0 + cy;
+          anyy[cy] = py >= y0 && py < yend;
+          wym[cy] = anyy[cy] ? t.wy(cy) : 0.f;
+          rowy[cy] = min(max(py - y0, 0), TY - 1) * 64;
+        }
+        const int zlo = max(za, zp - H), zhi = min(zb, zp + H + 2);
 #pragma unroll
         for (int cz = 0; cz < 2; ++cz) {
           const int pz = t.z.i0 + cz;
-          const bool okz = pz >= za && pz < zb && pz >= zp - H && pz <= zp + H + 1;
-          int slot = sz + (pz - zp);
+          anyz[cz] = pz >= zlo && pz < zhi;
+          wzm[cz] = anyz[cz] ? t.wz(cz) : 0.f;
+          int slot = sz + min(max(pz - zp, -H), H + 1);
           slot += slot < 0 ? NS : 0;
           slot -= slot >= NS ? NS : 0;
+          slotz[cz] = slot * plane_cells;
+        }
+        float a[C][2];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float gsc = go[k][c] * scale;
+          a[c][0] = wxm[0] * gsc;
+          a[c][1] = wxm[1] * gsc;
+        }
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
           for (int cy = 0; cy < 2; ++cy) {
-            const int py = t.y.i0 + cy;
-            const bool oky = py >= y0 && py < yend;
+            if (__ballot(anyz[cz] && anyy[cy]) == 0) continue;       // wave-uniform
+            const float wzy = wzm[cz] * wym[cy];
+            int* cell = acc + slotz[cz] + rowy[cy];
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-              const int pxx = t.x.i0 + cx;
-              if (!(xin && okz && oky && t.ok(cz, cy, cx) && pxx >= xo0 && pxx < xo1)) continue;
-              const float wsc = t.w(cz, cy, cx) * scale;
-              int* cell = acc + slot * plane_cells + (py - y0) * 64 + (pxx - xbase);
+            for (int cx = 0; cx < 2; ++cx)
 #pragma unroll
-              for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * 64, __float2int_rn(wsc * go[k][c]));
-            }
+              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * TY * 64, __float2int_rn(wzy * a[c][cx]));
+          }
+        }
+        if (own) {
+          float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, go[k][c], t, d, ax, ay, az);
+          if (xown) {
+            float* gq = ggrid + (int64_t)n * 3 * V;
+            const unsigned so = (unsigned)((zp * d.s1 + ys) * d.s2 + xl) * 4u;
+            st_off(gq, so, pass[0] ? t.x.mult * ax : 0.f);
+            st_off(gq + V, so, pass[1] ? t.y.mult * ay : 0.f);
+            st_off(gq + (int64_t)2 * V, so, pass[2] ? t.z.mult * az : 0.f);
           }
         }
       }
@@ -272,7 +385,7 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
     const int zt = zp - H;
     const bool fin = zt >= za && zt < zb;
     float gg[MAXF][3];
-    if (fin && (SELF || GG)) {
+    if (fin && (SELF || GG) && !EARLY) {
 #pragma unroll
       for (int k = 0; k < MAXF; ++k) {
         float q[3] = {fg[k][0], fg[k][1], fg[k][2]};
@@ -289,7 +402,7 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         if (SL) {
           const int so = (min(max(zt, 0), d.s0 - 1) * d.s1 + min(y0 + wave + k * NWV, d.s1 - 1)) * d.s2 + xl;   // the own sample
 #pragma unroll
-          for (int c = 0; c < CT; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, gon_all[(int64_t)c * V + so], t, d, ax, ay, az);
+          for (int c = 0; c < CT; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, ld_off(gon_all + (int64_t)c * V, (unsigned)so * 4u), t, d, ax, ay, az);
         }
         gg[k][0] = pass[0] ? t.x.mult * ax : 0.f;
         gg[k][1] = pass[1] ? t.y.mult * ay : 0.f;
@@ -314,18 +427,18 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
           v[c] = (float)cell[c * TY * 64] * inv;
           cell[c * TY * 64] = 0;
         }
-        const int s = (zt * d.s1 + uy) * d.s2 + xl;
+        const unsigned s = (unsigned)((zt * d.s1 + uy) * d.s2 + xl) * 4u;
         if (SELF) {
 #pragma unroll
           for (int c = 0; c < C; ++c) v[c] += SL ? (c0 == 0 ? gg[k][0] : (c0 == 1 ? gg[k][1] : gg[k][2])) : gg[k][c < 3 ? c : 0];
-        } else if (GG && xown) {
-          float* gq = ggrid + (int64_t)n * 3 * V + s;
+        } else if (GG && !EARLY && xown) {
+          float* gq = ggrid + (int64_t)n * 3 * V;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) gq[(int64_t)a * V] = gg[k][a];
+          for (int a = 0; a < 3; ++a) st_off(gq + (int64_t)a * V, s, gg[k][a]);
         }
         if (xown) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
+          for (int c = 0; c < C; ++c) st_off(ginn + (int64_t)c * V, s, v[c]);
         }
       }
     }
@@ -346,6 +459,310 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
       for (int c = 0; c < C; ++c) fgo[k][c] = fgo1[k][c];
     }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same march for an image warp (C == 1, rows of at most 64 voxels) with everything that crosses the memory pipeline
+// 16 bytes wide.  k_scatter_march3d is bound by vector-memory ISSUE, not by bytes or VALU (lesson 4: a CU retires one
+// vector-memory wave-instruction per ~26 clk whatever it carries): per step and CU it issues 4 dword loads per visited
+// sample row (3x the rows it owns at H = 4), 8 dword gathers per own row for the coordinate path and 4 dword stores per
+// own row -- 288 instructions x 26 clk x 24 steps = the 82 us measured (4 x 1 x 128 x 128 x 64, H = 4).  Here
+//   * a step's sample rows (grid x, y, z and grad_out, rows y0-H .. y0+TY+H-1 of plane zp) are fetched by the whole
+//     workgroup with 16-byte loads one step ahead (registers), written to an LDS stage and picked up by the wave that
+//     visits the row -- 1 KiB per wave-instruction instead of 256 B;
+//   * the coordinate path (grad_grid) of an own sample is evaluated when its row is visited for its deposits (taps built
+//     once), its 8 corner values come from an LDS ring of 2H+1 planes x TY+2H rows of `in` (the exact bound H puts every
+//     corner inside it), staged with 16-byte loads, zero outside the volume and with a zero column either side: zeros
+//     padding is data, no validity selects;
+//   * grad_in leaves from the accumulator ring as 16-byte stores (16 lanes a row);
+//   * two stages and one spare plane in each ring: ONE barrier per step.
+// 16 waves own 16 rows (2.25 visits per sample at H = 4 instead of 3); 156 KiB of LDS, one workgroup a CU.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int H>
+struct WideCfg {
+  static constexpr int TY = 16, NWV = 16, NT = NWV * 64, XS = 68;
+  // accumulator ring: one plane more than a step reaches, so that the plane being emptied and the next step's deposits never
+  // meet; `in` ring: one plane more than the own samples reach, so that the plane joining for the next step can be written
+  // while slower waves still read; two stages: ONE barrier per step
+  static constexpr int NS = 2 * H + 3, NP = 2 * H + 2, R = TY + 2 * H;
+  static constexpr int ACC = NS * TY * 64, STAGE = 4 * R * 64, RING = NP * R * XS + 4;
+  static constexpr int NI = 4 * R * 16;                      // 16-byte items of a step's sample rows
+  static constexpr int KI = (NI + NT - 1) / NT;
+  static constexpr size_t lds(bool gg) { return (size_t)(ACC + 2 * STAGE + (gg ? RING : 0)) * 4; }
+};
+
+template <int PAD, bool GG, int H>
+__global__ void __launch_bounds__(WideCfg<H>::NT)
+k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
+                       float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int clamp_grid,
+                       int32_t* __restrict__ ws) {
+  using G = WideCfg<H>;
+  constexpr int TY = G::TY, NWV = G::NWV, NT = G::NT, XS = G::XS, NS = G::NS, NP = G::NP, R = G::R;
+  extern __shared__ int acc[];                                // [NS][TY][64]
+  float* stage = reinterpret_cast<float*>(acc + G::ACC);      // [2][4][R][64]: grid x, y, z, grad_out of a step's rows
+  float* ring = stage + 2 * G::STAGE;                         // [NP][R][XS]: `in`, data at columns 4 .. 67; column 68 of a
+                                                              // row is column 0 of the next one: zero either way
+  const int V = (int)d.voxels();
+  // blocks are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of tiles (y fastest, then z, then the batch),
+  // so that the halo rows and planes neighbouring workgroups share come from one L2
+  const int nb = gridDim.x, ntile = n1 * ((d.s0 + zc - 1) / zc);
+  const int tl = (nb & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+  const int n = tl / ntile, trem = tl - n * ntile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty = trem % n1, tz = trem / n1;
+  const int y0 = ty * TY, yend = min(y0 + TY, d.s1);
+  const int za = tz * zc, zb = min(za + zc, d.s0);
+  const float* gn = grid + (int64_t)n * 3 * V;
+  const float* gon = gout + (int64_t)n * V;
+  const float* inn = in + (int64_t)n * V;
+  float* ginn = gin + (int64_t)n * V;
+  float* ggn = ggrid + (int64_t)n * 3 * V;
+  const bool xin = lane < d.s2;
+  const int xl = min(lane, d.s2 - 1);
+
+  auto ring_slot = [&](int z) { return ((z % NP) + NP) % NP; };
+  // Requests are unconditional, from addresses clamped into the volume, into registers nothing else writes (a zero-fill
+  // followed by a conditional load made the compiler wait for ALL outstanding memory operations before the fill); what lies
+  // outside the volume or beyond the row end becomes zero on the way to LDS.
+  // one plane of `in` for the ring: rows y0-H .. y0+TY+H-1 (threads 0 .. 16 R - 1)
+  const int qx = min(4 * (tid & 15), max(d.s2 - 4, 0));
+  auto fetch_in = [&](int z, float4& v) {
+    if (!GG) return;
+    const int r = min(tid >> 4, R - 1);
+    const int y = min(max(y0 - H + r, 0), d.s1 - 1), zq = min(max(z, 0), d.s0 - 1);
+    v = *reinterpret_cast<const float4*>(inn + (unsigned)((zq * d.s1 + y) * d.s2 + qx));
+  };
+  auto commit_in = [&](int z, const float4& v) {
+    if (!GG || tid >= R * 16) return;
+    const int r = tid >> 4, q = tid & 15, y = y0 - H + r;
+    const bool ok = z >= 0 && z < d.s0 && y >= 0 && y < d.s1 && 4 * q < d.s2;
+    *reinterpret_cast<float4*>(ring + (ring_slot(z) * R + r) * XS + 4 + 4 * q) = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  // the sample rows of plane zp (rows outside the volume are never visited)
+  auto fetch_rows = [&](int zp, float4 (&v)[G::KI]) {
+    const int zq = min(max(zp, 0), d.s0 - 1);
+#pragma unroll
+    for (int k = 0; k < G::KI; ++k) {
+      const int i = min(tid + k * NT, G::NI - 1);
+      const int ch = i / (R * 16), rem = i - ch * (R * 16), r = rem >> 4;
+      const int yq = min(max(y0 - H + r, 0), d.s1 - 1);
+      const float* base = ch < 3 ? gn + (int64_t)ch * V : gon;
+      v[k] = *reinterpret_cast<const float4*>(base + (unsigned)((zq * d.s1 + yq) * d.s2 + qx));
+    }
+  };
+  auto commit_rows = [&](float* st, const float4 (&v)[G::KI]) {
+#pragma unroll
+    for (int k = 0; k < G::KI; ++k) {
+      const int i = tid + k * NT;
+      if (i < G::NI) *reinterpret_cast<float4*>(st + i * 4) = 4 * (tid & 15) < d.s2 ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  // ---- prologue: ring planes za-H .. za (plane zp+H+1 joins during step zp), the first step's rows; requests run TWO
+  // steps ahead (a step is about as long as a memory round trip under load: one step ahead every step ended waiting for
+  // its own requests), in two register sets that swap roles
+  // (all of the prologue's requests are in flight together: one round trip, not H + 3)
+  __shared__ float wmax[NWV];
+  float4 rowA[G::KI], rowB[G::KI], inA = make_float4(0.f, 0.f, 0.f, 0.f), inB = inA;
+  {
+    float4 pin[H + 1];
+#pragma unroll
+    for (int p = 0; p <= H; ++p) fetch_in(za - H + p, pin[p]);
+    fetch_rows(za - H, rowB);
+    fetch_rows(za - H + 1, rowA);
+    fetch_in(za + 1, inA);
+    // ... and while they travel: the fixed-point scale from the row maxima of the rows this workgroup visits, zeroed rings
+    {
+      const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s0 * d.s1;
+      const int ya = max(y0 - H, 0), yn = min(y0 + TY + H, d.s1) - ya;
+      const int zlo = max(za - H, 0), zn = min(zb + H, d.s0) - zlo;
+      float m = 0.f;
+      for (int i = tid; i < yn * zn; i += NT) m = fmaxf(m, rowmax[(zlo + i / yn) * d.s1 + ya + i % yn]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (lane == 0) wmax[wave] = m;
+    }
+    for (int i = tid; i < G::ACC; i += NT) acc[i] = 0;
+    if (GG) for (int i = tid; i < G::RING; i += NT) ring[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p <= H; ++p) commit_in(za - H + p, pin[p]);
+    commit_rows(stage, rowB);
+  }
+  __syncthreads();
+  float gmax = wmax[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) gmax = fmaxf(gmax, wmax[w]);
+  const float fix = march_fix_scale(H);
+  const float scale = gmax > 0.f ? fix / gmax : 0.f, inv = gmax / fix;
+
+  // Stores never make a wave wait: on gfx9 the source registers of a store stay busy until it is acknowledged (vmcnt), and
+  // the compiler puts `s_waitcnt vmcnt(0)` in front of the first instruction that reuses them.  With the grad_grid values
+  // stored from where they were computed, and the converted output plane from where it was read, every step waited out a
+  // store round trip (42-49 % of the wave-cycles parked).  So: a step's grad_grid values are stored at the TOP of the next
+  // step, ahead of its loads; the source registers of both kinds of store are kept alive (an empty asm that reads them)
+  // until the wait that the step's LDS commit needs anyway -- by then a whole step has passed.
+  float gg_prev[3] = {0.f, 0.f, 0.f};
+  unsigned so_prev = 0;
+  bool have_prev = false;
+  float4 fprev = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned fo_prev = 0;
+  int cur = 0;
+  // rc / ic: requested a step ago for step zp+1, committed at the end of this one; rl / il: requested now for step zp+2
+  auto step = [&](int zp, float4 (&rc)[G::KI], float4& ic, float4 (&rl)[G::KI], float4& il) {
+    const float* st = stage + cur * G::STAGE;
+    const bool more = zp + 1 < zb + H;
+    if (GG && have_prev) {
+      st_off(ggn, so_prev, gg_prev[0]);
+      st_off(ggn + V, so_prev, gg_prev[1]);
+      st_off(ggn + (int64_t)2 * V, so_prev, gg_prev[2]);
+    }
+    float gg_new[3] = {0.f, 0.f, 0.f};
+    unsigned so_new = 0;
+    bool have_new = false;
+    fetch_rows(zp + 2, rl);                                       // unconditional: clamped addresses
+    fetch_in(zp + 2 + H, il);
+    // ---- deposits of sample plane zp; coordinate path of the own rows among them
+    if (zp >= 0 && zp < d.s0) {
+      const int sz = ((zp % NS) + NS) % NS;
+      const bool own_plane = GG && zp >= za && zp < zb;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        // every wave visits one own row; the 2H halo rows go to waves 8 .. 8 + 2H - 1 (waves 0 .. 3 empty the output
+        // plane, waves 0 .. 7 carry the second fetch item: with rows dealt out in order they also had two visits each and
+        // the other half of the workgroup waited at the barrier)
+        const int hrow = wave - 8;
+        const int r = k == 0 ? H + wave : (hrow >= 0 && hrow < 2 * H ? (hrow < H ? hrow : TY + hrow) : R);
+        const int ys = y0 - H + r;
+        if (r >= R || ys < 0 || ys >= d.s1) continue;              // wave-uniform
+        const bool own = own_plane && k == 0 && ys < yend;
+        float g[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] = st[(a * R + r) * 64 + lane];
+        const float go = st[(3 * R + r) * 64 + lane];
+        bool pass[3] = {true, true, true};
+        if (clamp_grid) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { pass[a] = g[a] >= -1.f && g[a] <= 1.f; g[a] = clamp_unit(g[a]); }
+        }
+        Taps<3, PAD> t;
+        t.y = make_tap<PAD>(g[1], d.s1);
+        t.z = make_tap<PAD>(g[2], d.s0);
+        const int zlo = max(za, zp - H), zhi = min(zb, zp + H + 2);
+        const bool reach = xin && t.y.i0 + 1 >= y0 && t.y.i0 < yend && t.z.i0 + 1 >= zlo && t.z.i0 < zhi;
+        const bool any = __ballot(reach) != 0;
+        if (!any && !own) continue;
+        t.x = make_tap<PAD>(g[0], d.s2);
+        if (any) {
+          float wxm[2], wym[2], wzm[2];
+          int colx[2], rowy[2], slotz[2];
+          bool anyy[2], anyz[2];
+#pragma unroll
+          for (int cx = 0; cx < 2; ++cx) {
+            const int pxx = t.x.i0 + cx;
+            const bool okx = xin && pxx >= 0 && pxx < d.s2;          // (masked lanes: own column, see k_scatter_march3d)
+            wxm[cx] = okx ? t.wx(cx) : 0.f;
+            colx[cx] = okx ? pxx : lane;
+          }
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const int py = t.y.i0 + cy;
+            anyy[cy] = py >= y0 && py < yend;
+            wym[cy] = anyy[cy] ? t.wy(cy) : 0.f;
+            rowy[cy] = min(max(py - y0, 0), TY - 1) * 64;
+          }
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz) {
+            const int pz = t.z.i0 + cz;
+            anyz[cz] = pz >= zlo && pz < zhi;
+            wzm[cz] = anyz[cz] ? t.wz(cz) : 0.f;
+            int slot = sz + min(max(pz - zp, -H), H + 1);
+            slot += slot < 0 ? NS : 0;
+            slot -= slot >= NS ? NS : 0;
+            slotz[cz] = slot * (TY * 64);
+          }
+          const float gsc = go * scale;
+          const float a0 = wxm[0] * gsc, a1 = wxm[1] * gsc;
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+              const float wzy = wzm[cz] * wym[cy];
+              int* cell = acc + slotz[cz] + rowy[cy];
+              atomicAdd(cell + colx[0], __float2int_rn(wzy * a0));
+              atomicAdd(cell + colx[1], __float2int_rn(wzy * a1));
+            }
+        }
+        if (own) {
+          // corners from the ring.  The exact bound puts them inside it; a sample that breaks the contract (NaN: make_tap
+          // sends it to -16) reads clamped cells and contributes nothing.
+          const int rx = t.x.i0 + 4, ry = t.y.i0 - (y0 - H), rz = t.z.i0 - (zp - H);
+          const bool inside = rx >= 3 && rx <= 67 && ry >= 0 && ry < R - 1 && rz >= 0 && rz < 2 * H;
+          const int cxr = min(max(rx, 3), 67), cyr = min(max(ry, 0), R - 2);
+          const int pz0 = (zp - H) + min(max(rz, 0), 2 * H - 1);
+          const int s0 = ring_slot(pz0), s1 = ring_slot(pz0 + 1);
+          float v[2][2][2];
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const float* p0 = ring + (s0 * R + cyr + cy) * XS + cxr;
+            const float* p1 = ring + (s1 * R + cyr + cy) * XS + cxr;
+            v[0][cy][0] = p0[0]; v[0][cy][1] = p0[1];
+            v[1][cy][0] = p1[0]; v[1][cy][1] = p1[1];
+          }
+          const float gq = inside ? go : 0.f;
+          float sx = 0.f, sy = 0.f, sw = 0.f;
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz) {
+            sx = fmaf(t.wz(cz), fmaf(t.y.w1, v[cz][1][1] - v[cz][1][0], t.y.w0 * (v[cz][0][1] - v[cz][0][0])), sx);
+            sy = fmaf(t.wz(cz), fmaf(t.x.w1, v[cz][1][1] - v[cz][0][1], t.x.w0 * (v[cz][1][0] - v[cz][0][0])), sy);
+          }
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy)
+            sw = fmaf(t.wy(cy), fmaf(t.x.w1, v[1][cy][1] - v[0][cy][1], t.x.w0 * (v[1][cy][0] - v[0][cy][0])), sw);
+          so_new = (unsigned)((zp * d.s1 + ys) * d.s2 + xl) * 4u;
+          gg_new[0] = pass[0] ? t.x.mult * (gq * sx) : 0.f;
+          gg_new[1] = pass[1] ? t.y.mult * (gq * sy) : 0.f;
+          gg_new[2] = pass[2] ? t.z.mult * (gq * sw) : 0.f;
+          have_new = xin;
+        }
+      }
+    }
+    // ---- the next step's rows and ring plane go to the other stage / the free ring slot; one barrier; then the output
+    // plane zp-H, which has seen every sample that can reach it, leaves as 16-byte stores while the next step begins
+    if (more) {
+      commit_rows(stage + (cur ^ 1) * G::STAGE, rc);
+      if (zp + 1 < zb) commit_in(zp + 1 + H, ic);
+    }
+    asm volatile("" ::"v"(gg_prev[0]), "v"(gg_prev[1]), "v"(gg_prev[2]), "v"(so_prev), "v"(fprev.x), "v"(fprev.y), "v"(fprev.z),
+                 "v"(fprev.w), "v"(fo_prev));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gg_prev[a] = gg_new[a];
+    so_prev = so_new;
+    have_prev = have_new;
+    __syncthreads();
+    const int zt = zp - H;
+    if (tid < TY * 16 && zt >= za && zt < zb) {
+      const int row = tid >> 4, q = tid & 15, uy = y0 + row;
+      int4* cell = reinterpret_cast<int4*>(acc + (((zt % NS) + NS) % NS) * (TY * 64) + row * 64 + 4 * q);
+      const int4 c = *cell;
+      *cell = make_int4(0, 0, 0, 0);
+      if (uy < d.s1 && 4 * q < d.s2) {
+        fprev = make_float4((float)c.x * inv, (float)c.y * inv, (float)c.z * inv, (float)c.w * inv);
+        fo_prev = (unsigned)((zt * d.s1 + uy) * d.s2 + 4 * q) * 4u;
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(ginn) + fo_prev) = fprev;
+      }
+    }
+    cur ^= 1;
+  };
+  for (int zp = za - H; zp < zb + H; zp += 2) {
+    step(zp, rowA, inA, rowB, inB);
+    if (zp + 1 < zb + H) step(zp + 1, rowB, inB, rowA, inA);
+  }
+  if (GG && have_prev) {       // the last step's own row
+    st_off(ggn, so_prev, gg_prev[0]);
+    st_off(ggn + V, so_prev, gg_prev[1]);
+    st_off(ggn + (int64_t)2 * V, so_prev, gg_prev[2]);
   }
 }
 
@@ -566,7 +983,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     hipLaunchKernelGGL((k_scatter_march3d<PAD_, 1, SELF_, GG_, 8, CT_, true>), gb, bb, ldsb, st, gout, in, grid, gin, ggrid, d, n1b, zcb, TYb, H, NSb, clamp_grid, workspace, nseg, c0)
 #define GOB_PAD(GG_, CT_) do { if (padding == PAD_BORDER) GOB(PAD_BORDER, false, GG_, CT_); else GOB(PAD_ZEROS, false, GG_, CT_); } while (0)
     for (int c0 = 0; c0 < (int)C; ++c0) {
-      hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout + (int64_t)c0 * d.voxels(), rowmax, d, rows, (int)C);
+      launch_rowmax<1>(gout + (int64_t)c0 * d.voxels(), rowmax, d, rows, N, (int)C, st);
       if (self) GOB(PAD_BORDER, true, false, 3);
       else if (C == 1) { if (ggb) GOB_PAD(true, 1); else GOB_PAD(false, 1); }
       else if (ggb && c0 == 0) GOB_PAD(true, 4);
@@ -574,6 +991,35 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     }
 #undef GOB_PAD
 #undef GOB
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
+  // image warps with rows of at most 64 voxels: the 16-byte form
+  static const bool no_wide = getenv("ADVCHAIN_NO_SCATTER_MARCH_WIDE") != nullptr;   // A/B knob
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!no_wide && !self && C == 1 && H <= 4 && d.s2 <= 64 && d.s2 % 4 == 0 && aligned16(gout) && aligned16(in) && aligned16(grid) &&
+      aligned16(gin) && aligned16(ggrid)) {
+    const bool ggw = ggrid != nullptr;
+    const int n1w = (int)((d.s1 + 15) / 16);
+    int zcw = (int)d.s0;
+    while (zcw > 16 && N * n1w * ((d.s0 + zcw - 1) / zcw) < 256) zcw = (zcw + 1) / 2;
+    static const int zcw_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+    if (zcw_forced > 0) zcw = zcw_forced;
+    const int n0w = (int)((d.s0 + zcw - 1) / zcw);
+    const int rows = (int)(d.s0 * d.s1);
+    dim3 rg((unsigned)((rows + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N);
+    launch_rowmax<1>(gout, reinterpret_cast<float*>(workspace + 4), d, rows, N, 1, st);
+    dim3 gw((unsigned)(n1w * n0w * N));
+#define GOW(PAD_, GG_, H_) do { \
+      auto kern = k_scatter_march3d_wide<PAD_, GG_, H_>; \
+      static bool attr_set = false; \
+      if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<H_>::lds(GG_)); attr_set = true; } \
+      hipLaunchKernelGGL(kern, gw, dim3(WideCfg<H_>::NT), WideCfg<H_>::lds(GG_), st, gout, in, grid, gin, ggrid, d, n1w, zcw, clamp_grid, workspace); } while (0)
+#define GOW_H(PAD_, GG_) do { if (H == 2) GOW(PAD_, GG_, 2); else if (H == 3) GOW(PAD_, GG_, 3); else GOW(PAD_, GG_, 4); } while (0)
+    if (padding == PAD_BORDER) { if (ggw) GOW_H(PAD_BORDER, true); else GOW_H(PAD_BORDER, false); }
+    else { if (ggw) GOW_H(PAD_ZEROS, true); else GOW_H(PAD_ZEROS, false); }
+#undef GOW_H
+#undef GOW
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
   }
@@ -596,9 +1042,9 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     const int rows = (int)(d.s0 * d.s1);
     dim3 rg((unsigned)((rows + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N);
     float* rowmax = reinterpret_cast<float*>(workspace + 4);       // the overflow list of the tiled kernels: unused here
-    if (C == 1) hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout, rowmax, d, rows);
-    else if (C == 3) hipLaunchKernelGGL(k_march_rowmax<3>, rg, dim3(kBlock), 0, st, gout, rowmax, d, rows);
-    else hipLaunchKernelGGL(k_march_rowmax<4>, rg, dim3(kBlock), 0, st, gout, rowmax, d, rows);
+    if (C == 1) launch_rowmax<1>(gout, rowmax, d, rows, N, 1, st);
+    else if (C == 3) launch_rowmax<3>(gout, rowmax, d, rows, N, 3, st);
+    else launch_rowmax<4>(gout, rowmax, d, rows, N, 4, st);
   }
   const int nwv = TY > 4 ? 8 : 4;
   dim3 g((unsigned)(n1 * n0 * nseg), (unsigned)N), b(nwv * 64);
