@@ -258,6 +258,10 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
                                  int64_t C, Dims d, int padding, int clamp_grid, int final_mode, float* disp_out,
                                  hipStream_t st);
 
+// sample_ring.hip: z-marching form with a ring of 2H+2 planes (3D image warps, C == 1, hints of 2 .. 4 voxels)
+int advchain_sample_ring_launch(const float* in, const float* grid, float* out, int64_t N, Dims d, int padding, int clamp_grid,
+                                int hint, hipStream_t st);
+
 // Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify (caller uses the direct-gather kernels).
 // The z-marching kernel keeps three planes of its rows in LDS and sends a lane whose taps leave them to global gathers:
 // unbeatable below one voxel (self-composition 29 against 42 us at 4 x 3 x 128 x 128 x 64), equal at 1-2 voxels, slower
@@ -279,6 +283,10 @@ int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, 
   if (off || C < 1 || C > 4) return ADVCHAIN_ERR_UNSUPPORTED;
   if (ndim == 3 && march_forward_pays(self, C, d, disp_hint)) {
     const int rc = advchain_sample_march_launch(self, in, grid, out, phi0, N, C, d, padding, clamp_grid, final_mode, disp_out, st);
+    if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
+  }
+  if (ndim == 3 && !self && C == 1 && disp_hint >= 2) {   // 2 .. 4 voxels: the ring of 2H+2 planes (sample_ring.hip)
+    const int rc = advchain_sample_ring_launch(in, grid, out, N, d, padding, clamp_grid, disp_hint, st);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   const int unaligned = (reinterpret_cast<uintptr_t>(in) & 15) != 0 || (d.s2 & 3) != 0;   // only `in` is read 16 bytes at a time

@@ -47,10 +47,16 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
   float* const ring = lds;                  // [slot 4][C][R][P]
   float* const trbuf = lds + 4 * PS;        // [wave][TRW]
   const int V = (int)d.voxels();
-  const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // workgroup L runs on XCD L % 8 (observed dispatch order; speed only): give every XCD a contiguous run of tiles, so
+  // that the halo rows / planes two neighbouring workgroups both stage are served by the same L2 (nseg < 0: off)
+  int tile = blockIdx.x + gridDim.x * blockIdx.y;
+  const int tiles = gridDim.x * gridDim.y;
+  if (nseg > 0 && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);
+  nseg = nseg < 0 ? -nseg : nseg;
+  const int n = tile / (int)gridDim.x;
   // rows longer than 64 voxels: x segments of 56 owned lanes with 4 halo lanes either side (16-byte aligned staging)
-  int rem = blockIdx.x;
+  int rem = tile - n * (int)gridDim.x;
   const int seg = rem % nseg;
   rem /= nseg;
   const int xbase = nseg > 1 ? seg * kFwdSegOwn - 4 : 0;      // x of lane 0
@@ -532,8 +538,9 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
   const int nseg = d.s2 <= 64 ? 1 : (d.s2 + kFwdSegOwn - 1) / kFwdSegOwn;
   const int zc = fwd_march_zc(d, N * nseg, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
+  static const bool no_xcd = getenv("ADVCHAIN_NO_XCD_MAP") != nullptr;   // A/B knob
   hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
-                     final_mode, disp_out, nseg);
+                     final_mode, disp_out, no_xcd ? -nseg : nseg);
 }
 
 template <int C>

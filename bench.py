@@ -288,9 +288,11 @@ def profiled_traffic(workload, entry):
     return None, None
 
 
-def _time_pair(x, go, q, halo, reps):
+def _time_pair(x, go, q, halo, reps, disp=None):
     """Average launch duration of grid_sample fwd and bwd on field `q`: `reps` launches back to back between two events
-    on the launch stream (one event pair per single launch would add the ~5 us launch gap of an empty queue)."""
+    on the launch stream (one event pair per single launch would add the ~5 us launch gap of an empty queue).  `disp`: the
+    measured displacement of q, handed to the forward as the hint the product passes (ops.forward_hint: it picks the forward
+    kernel, results do not depend on it); `halo`: the backward's bound from the same measurement (ops.warp_halo)."""
     from advchain_amd import _lib, ops
     lib = _lib.load()
     N = x.shape[0]
@@ -299,13 +301,14 @@ def _time_pair(x, go, q, halo, reps):
     ws = ops._scatter_workspace(N, dims, x.device)
     da = _lib.dims_array(dims)
     for _ in range(3):
-        ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        ops.raw_grid_sample_fwd(x, q, 0, 0, True, disp_hint=disp)
         ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
+    cg = 1 | ops._hint_bits(disp)
     ef = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     torch.cuda.synchronize()
     ef[0].record()
     for _ in range(reps):
-        _lib.check(lib.advchain_grid_sample_fwd(ops._ptr(x), ops._ptr(q), ops._ptr(out), N, 1, 3, da, da, 0, 0, 1,
+        _lib.check(lib.advchain_grid_sample_fwd(ops._ptr(x), ops._ptr(q), ops._ptr(out), N, 1, 3, da, da, 0, 0, cg,
                                                 ops._stream()), "fwd")
     ef[1].record()
     for _ in range(reps):
@@ -345,7 +348,7 @@ def grid_sample3d_roofline(device, reps=20):
         # the displacement bound the product measures in forward (ops._GridSample) and hands to the backward
         entry = ops.grid_displacement(q)
         halo = ops.warp_halo(entry, 3)
-        tf, tb = _time_pair(x, go, q, halo, reps)
+        tf, tb = _time_pair(x, go, q, halo, reps, float(entry[1]))
         levels[tag] = {"max_displacement_voxels": round(float(entry[1]), 3), "bwd_form": _bwd_form(halo),
                        "fwd_us": round(tf * 1e6, 2), "bwd_us": round(tb * 1e6, 2),
                        "achieved": round((bf + bb) / (tf + tb) / 1e9, 1),

@@ -1179,10 +1179,11 @@ def test_forward_results_do_not_depend_on_the_displacement_hint(dims, amp):
     phi = _smooth_field(dims, amp, 67).to(DEV)
     for C in (1, 4):
         x = rand((2, C) + dims, 68 + C).to(DEV)
-        for clamp in (True, False):
-            outs = [ops.raw_grid_sample_fwd(x, phi, 0, 0, clamp, disp_hint=h) for h in (None, 0.5, 4.5, 9.0)]
+        for pad, clamp in ((0, True), (0, False), (1, False)):
+            # (hints of 2 .. 4 voxels: the ring of 2H+2 planes of sample_ring.hip for C = 1 and rows of at most 64 voxels)
+            outs = [ops.raw_grid_sample_fwd(x, phi, 0, pad, clamp, disp_hint=h) for h in (None, 0.5, 1.5, 2.5, 3.5, 4.5, 9.0)]
             for o in outs[1:]:
-                assert torch.equal(o, outs[0]), (C, clamp)
+                assert torch.equal(o, outs[0]), (C, pad, clamp)
     comps = [ops.raw_compose_self_fwd(phi, disp_hint=h) for h in (None, 0.5, 4.5, 9.0)]
     for o in comps[1:]:
         assert torch.equal(o, comps[0])

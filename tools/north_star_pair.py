@@ -47,7 +47,7 @@ def main():
     entry = ops.grid_displacement(q)
     halo = ops.warp_halo(entry, 3)
     for _ in range(args.reps):
-        ops.raw_grid_sample_fwd(x, q, 0, 0, True)
+        ops.raw_grid_sample_fwd(x, q, 0, 0, True, disp_hint=entry[1])
         ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
     torch.cuda.synchronize()
     print("level %s displacement %.3f halo %d reps %d" % (args.level, entry[1], halo, args.reps))
