@@ -51,15 +51,21 @@ ENTRIES["advchain_compose_self_bwd"] = ([p for p in ENTRIES["advchain_compose_se
 for _e, _self in (("advchain_grid_sample_bwd", "false"), ("advchain_compose_self_bwd", "true")):
     _p = [r"k_scatter_march3d<\d, \d, %s" % _self, r"k_scatter_rows2d<\d, \d, %s" % _self]
     ENTRIES[_e] = (ENTRIES[_e][0] + _p, ENTRIES[_e][1] + "|" + "|".join(_p))
-ENTRIES["advchain_grid_sample_bwd"][0].append(r"k_march_rowmax<[14]>")
-ENTRIES["advchain_compose_self_bwd"][0].append(r"k_march_rowmax<[23]>")
+ENTRIES["advchain_grid_sample_bwd"][0].append(r"k_march_rowmax(64)?<[14]>")
+ENTRIES["advchain_compose_self_bwd"][0].append(r"k_march_rowmax(64)?<[23]>")
+# round 3: the 16-byte form of the 3D march scatter for image warps, the ring forward for 2..4-voxel fields
+ENTRIES["advchain_grid_sample_bwd"] = (ENTRIES["advchain_grid_sample_bwd"][0] + [r"k_scatter_march3d_wide<"],
+                                       ENTRIES["advchain_grid_sample_bwd"][1] + r"|k_scatter_march3d_wide<")
+ENTRIES["advchain_grid_sample_fwd"] = (ENTRIES["advchain_grid_sample_fwd"][0] + [r"k_sample_ring<"],
+                                       ENTRIES["advchain_grid_sample_fwd"][1] + r"|k_sample_ring<")
 ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd", r"k_affine_box_fwd"], r"k_affine_warp_fwd|k_affine_box_fwd")
 # round 3: LDS-box theta gradient and owner-computes grad_in scatter; one entry launch = one k_affine_geometry-less count of
 # the theta kernel (every backward call launches exactly one k_reduce_partials)
 ENTRIES["advchain_affine_warp_bwd"] = ([r"k_affine_warp_bwd<", r"k_affine_gather_bwd<", r"k_affine_geometry<", r"k_reduce_partials",
                                         r"k_affine_box_gtheta<", r"k_affine_box_gin<"], r"k_reduce_partials")
 WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
-                  r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4|k_affine_box_fwd|k_affine_box_gtheta")   # 16 B / lane
+                  r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4|k_affine_box_fwd|k_affine_box_gtheta|"
+                  r"k_scatter_march3d_wide|k_march_rowmax64|k_sample_ring")   # 16 B / lane
 MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
 
 
@@ -112,7 +118,7 @@ def main(root, out):
         if not fetch:
             continue
         skip = re.compile(r"k_max_displacement|elementwise|distribution|fillBuffer|copyBuffer|Cijk|reduce_kernel")
-        main_calls = max((c for k, (c, _) in fetch.items() if re.search(r"k_sample_march|k_sample_tiled|k_grid_sample_fwd", k)),
+        main_calls = max((c for k, (c, _) in fetch.items() if re.search(r"k_sample_march|k_sample_tiled|k_grid_sample_fwd|k_sample_ring", k)),
                          default=0)
         if not main_calls:
             continue
