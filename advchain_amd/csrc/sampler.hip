@@ -809,9 +809,12 @@ static int launch_grid_sample_bwd(const float* gout, const float* in, const floa
 
 static inline bool dims_ok(int ndim, const int64_t* s) {
   if (ndim != 2 && ndim != 3) return false;
-  for (int i = 0; i < ndim; ++i)
+  int64_t v = 1;
+  for (int i = 0; i < ndim; ++i) {
     if (s[i] < 1 || s[i] > (1 << 24)) return false;
-  return true;
+    v *= s[i];
+  }
+  return v >= 2;          // (the paired corner gathers read two neighbouring elements: sampler_common.h)
 }
 static inline Dims make_dims(int ndim, const int64_t* s) {
   Dims d;

@@ -33,12 +33,25 @@ struct Taps {
 // unconditionally and back to back, and an invalid corner's value is discarded by a select.  (With `if (ok) acc +=
 // in[off] * w` the compiler wraps every load in its own branch with an `s_waitcnt vmcnt(0)` inside: the 2D squaring
 // kernel made 32 SERIAL memory round trips per thread -- that, not instruction issue, was its "ceiling".)
+// The two x corners of a (z, y) row are neighbours in memory: ONE 8-byte gather fetches both (a CU retires a
+// vector-memory wave-instruction per ~26 clk whatever it carries, lesson 4; tools/microbench/pairbench.hip: 8 dword
+// gathers 19.6 us, 4 dwordx2 gathers 14.4 us for the same corners).  The pair of a row starts at its element
+// clamp(i0, 0, S2-2) and a corner takes the first or the second element -- exactly the value in[clamp(i0 + cx, 0, S2-1)]
+// the dword form loads.  The address is only 4-byte aligned: gfx9+ under ROCm runs in unaligned access mode and the
+// compiler emits global_load_dwordx2 for an aligned(4) packed pair.  No branch (control flow between the channels of a
+// sample would serialise their round trips): rows of one voxel (S2 == 1) pair an element with its predecessor in
+// memory, which needs a volume of at least two voxels (the C entries check it).
+struct __attribute__((packed, aligned(4))) FloatPair { float lo, hi; };
+
 template <int DIM, int PAD>
 struct CornerOffsets {
   int x[2], y[2], z[2];   // x index, y index * S2, z index * S1 * S2
+  int base[2][2];         // first element of the x pair of row (cz, cy)
+  bool second[2][2][2];   // corner (cz, cy, cx) is the pair's second element
   __device__ __forceinline__ CornerOffsets(const Taps<DIM, PAD>& t, const Dims& d) {
     x[0] = min(max(t.x.i0, 0), d.s2 - 1);
     x[1] = min(max(t.x.i0 + 1, 0), d.s2 - 1);
+    const int xa = min(x[0], d.s2 - 2);                    // (-1 for rows of one voxel)
     y[0] = min(max(t.y.i0, 0), d.s1 - 1) * d.s2;
     y[1] = min(max(t.y.i0 + 1, 0), d.s1 - 1) * d.s2;
     if (DIM == 3) {
@@ -47,8 +60,27 @@ struct CornerOffsets {
     } else {
       z[0] = z[1] = 0;
     }
+#pragma unroll
+    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
+        base[cz][cy] = max(z[cz] + y[cy] + xa, 0);
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) second[cz][cy][cx] = z[cz] + y[cy] + x[cx] != base[cz][cy];
+      }
   }
   __device__ __forceinline__ int at(int cz, int cy, int cx) const { return z[cz] + y[cy] + x[cx]; }
+  // all corner values, v[(cz * 2 + cy) * 2 + cx], loaded unconditionally and back to back
+  __device__ __forceinline__ void load(const float* __restrict__ in, float (&v)[8]) const {
+#pragma unroll
+    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
+        const FloatPair p = *reinterpret_cast<const FloatPair*>(in + base[cz][cy]);
+        v[(cz * 2 + cy) * 2 + 0] = second[cz][cy][0] ? p.hi : p.lo;
+        v[(cz * 2 + cy) * 2 + 1] = second[cz][cy][1] ? p.hi : p.lo;
+      }
+  }
 };
 
 // One term of a (bi/tri)linear tap sum, with the rounding PINNED so that every forward kernel (direct gathers, LDS tiles,
@@ -66,12 +98,7 @@ template <int DIM, int PAD>
 __device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
   const CornerOffsets<DIM, PAD> o(t, d);
   float v[8];
-#pragma unroll
-  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
-#pragma unroll
-    for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-      for (int cx = 0; cx < 2; ++cx) v[(cz * 2 + cy) * 2 + cx] = in[o.at(cz, cy, cx)];
+  o.load(in, v);
   float acc = 0.f;
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
@@ -91,12 +118,7 @@ __device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, 
   float v[8];
   if (NEED_GGRID) {   // corner values first, unconditionally (see CornerOffsets)
     const CornerOffsets<DIM, PAD> o(t, d);
-#pragma unroll
-    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
-#pragma unroll
-      for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-        for (int cx = 0; cx < 2; ++cx) v[(cz * 2 + cy) * 2 + cx] = in[o.at(cz, cy, cx)];
+    o.load(in, v);
   }
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)

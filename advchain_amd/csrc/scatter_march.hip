@@ -39,13 +39,15 @@ template <int DIM, int PAD>
 __device__ __forceinline__ void coord_path_diff(const float* __restrict__ in, float go, const Taps<DIM, PAD>& t, const Dims& d,
                                                 float& ax, float& ay, float& az) {
   const CornerOffsets<DIM, PAD> o(t, d);
+  float vl[8];
+  o.load(in, vl);
   float v[2][2][2];
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-      for (int cx = 0; cx < 2; ++cx) v[cz][cy][cx] = ld_off(in, (unsigned)o.at(cz, cy, cx) * 4u);
+      for (int cx = 0; cx < 2; ++cx) v[cz][cy][cx] = vl[(cz * 2 + cy) * 2 + cx];
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
