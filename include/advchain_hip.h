@@ -12,7 +12,8 @@
  *     freed inside; outputs / workspaces are caller-allocated.
  *   - layout: channels-first (N, C, S0, S1[, S2]); `ndim` = 2 or 3 spatial dims, `dims` has
  *     `ndim` entries in tensor order (slowest first).  Sampling grids are PLANAR (N, ndim, ...)
- *     with channel 0 = x <-> last spatial dim, 1 = y, 2 = z (F.grid_sample convention).
+ *     with channel 0 = x <-> last spatial dim, 1 = y, 2 = z (F.grid_sample convention).  The sampler entry
+ *     points (grid_sample, compose_self, expo_chain, affine_warp) take volumes of at least two voxels.
  *   - align_corners=True everywhere (the reference never uses False for samplers).
  *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); kernels are
  *     enqueued asynchronously on it; the call never synchronises.

@@ -600,7 +600,8 @@ def test_window_scatter_3d(dims, amp_vox, halo):
             assert none is None and maxdiff(gin2.cpu(), a.grad) < 5e-5 * max(1.0, float(a.grad.abs().max()))
 
 
-@pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32), (10, 12, 80), (9, 10, 132)])
+@pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32), (10, 12, 80), (9, 10, 132),
+                                  (32, 64, 64)])   # (16 workgroups of the 16-byte form: the XCD-contiguous tile map is on)
 @pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4), (5.4, 6), (7.5, 8)])
 def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
     """3D sampler backward with an EXACT displacement bound of 2..4 voxels (negative halo): the owner-computes z-march of
@@ -1169,7 +1170,8 @@ def test_kl_term_in_every_kernel_variant(dims, K):
     assert abs(float(v) - float(O.consistency_loss(pred, ref, ["kl"], [1.0]))) < 1e-7 + 2e-5 * abs(float(v))
 
 
-@pytest.mark.parametrize("dims,amp", [((24, 21, 44), 0.4), ((24, 21, 44), 2.6), ((16, 32, 64), 0.6), ((16, 32, 64), 3.4)])
+@pytest.mark.parametrize("dims,amp", [((24, 21, 44), 0.4), ((24, 21, 44), 2.6), ((16, 32, 64), 0.6), ((16, 32, 64), 3.4),
+                                      ((32, 64, 64), 1.7)])   # (32 workgroups of the ring forward: XCD-contiguous tile map on)
 def test_forward_results_do_not_depend_on_the_displacement_hint(dims, amp):
     """The displacement hint (bits 8..15 of clamp_grid / final_mode) only selects the 3D forward kernel -- z-marching ring
     or LDS tiles, include/advchain_hip.h -- and comes from asynchronous read-backs and the history of earlier calls
