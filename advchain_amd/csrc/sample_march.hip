@@ -205,7 +205,7 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
         Taps<3, PAD> t;
         t.build(gx, gy, gz, d);
 #pragma unroll
-        for (int c = 0; c < C; ++c) res[c][o] = sample_linear<3, PAD>(inn + (size_t)c * V, t, d);
+        for (int c = 0; c < C; ++c) res[c][o] = sample_linear<3, PAD, false>(inn + (size_t)c * V, t, d);
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) res[c][o] = 0.f;
@@ -279,7 +279,7 @@ __device__ __forceinline__ void fuse2_phi1_global(const float* __restrict__ phin
   Taps<3, PAD_BORDER> t;
   t.build(phin[s], phin[(size_t)V + s], phin[(size_t)2 * V + s], d);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) v[c] = sample_linear<3, PAD_BORDER>(phin + (size_t)c * V, t, d);
+  for (int c = 0; c < 3; ++c) v[c] = sample_linear<3, PAD_BORDER, false>(phin + (size_t)c * V, t, d);
 }
 
 template <int NW_, int RPW_>
@@ -381,7 +381,7 @@ k_compose2_march(const float* __restrict__ in, float* __restrict__ mid, float* _
           Taps<3, PAD_BORDER> t;
           t.build(gx, gy, gz, d);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) res[c] = sample_linear<3, PAD_BORDER>(inn + (size_t)c * V, t, d);
+          for (int c = 0; c < 3; ++c) res[c] = sample_linear<3, PAD_BORDER, false>(inn + (size_t)c * V, t, d);
         }
         if (!xowned) { res[0] = res[1] = res[2] = 0.f; }
         // the owned rows of the chunk's own planes are the field phi' the backward will ask for

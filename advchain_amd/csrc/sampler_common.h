@@ -43,7 +43,9 @@ struct Taps {
 // memory, which needs a volume of at least two voxels (the C entries check it).
 struct __attribute__((packed, aligned(4))) FloatPair { float lo, hi; };
 
-template <int DIM, int PAD>
+// PAIRED = false keeps the dword form: the fallback lanes of the marching forward kernels (sample_march.hip), where the
+// gathers are rare and the extra bookkeeping cost the main path 6-12 % (16.4 -> 17.8 us at 4 x 1 x 128 x 128 x 64).
+template <int DIM, int PAD, bool PAIRED = true>
 struct CornerOffsets {
   int x[2], y[2], z[2];   // x index, y index * S2, z index * S1 * S2
   int base[2][2];         // first element of the x pair of row (cz, cy)
@@ -60,14 +62,16 @@ struct CornerOffsets {
     } else {
       z[0] = z[1] = 0;
     }
+    if constexpr (PAIRED) {
 #pragma unroll
-    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+      for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
-      for (int cy = 0; cy < 2; ++cy) {
-        base[cz][cy] = max(z[cz] + y[cy] + xa, 0);
+        for (int cy = 0; cy < 2; ++cy) {
+          base[cz][cy] = max(z[cz] + y[cy] + xa, 0);
 #pragma unroll
-        for (int cx = 0; cx < 2; ++cx) second[cz][cy][cx] = z[cz] + y[cy] + x[cx] != base[cz][cy];
-      }
+          for (int cx = 0; cx < 2; ++cx) second[cz][cy][cx] = z[cz] + y[cy] + x[cx] != base[cz][cy];
+        }
+    }
   }
   __device__ __forceinline__ int at(int cz, int cy, int cx) const { return z[cz] + y[cy] + x[cx]; }
   // all corner values, v[(cz * 2 + cy) * 2 + cx], loaded unconditionally and back to back
@@ -76,9 +80,14 @@ struct CornerOffsets {
     for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) {
-        const FloatPair p = *reinterpret_cast<const FloatPair*>(in + base[cz][cy]);
-        v[(cz * 2 + cy) * 2 + 0] = second[cz][cy][0] ? p.hi : p.lo;
-        v[(cz * 2 + cy) * 2 + 1] = second[cz][cy][1] ? p.hi : p.lo;
+        if constexpr (PAIRED) {
+          const FloatPair p = *reinterpret_cast<const FloatPair*>(in + base[cz][cy]);
+          v[(cz * 2 + cy) * 2 + 0] = second[cz][cy][0] ? p.hi : p.lo;
+          v[(cz * 2 + cy) * 2 + 1] = second[cz][cy][1] ? p.hi : p.lo;
+        } else {
+          v[(cz * 2 + cy) * 2 + 0] = in[at(cz, cy, 0)];
+          v[(cz * 2 + cy) * 2 + 1] = in[at(cz, cy, 1)];
+        }
       }
   }
 };
@@ -94,9 +103,9 @@ __device__ __forceinline__ float tap_acc(float acc, float v, float w) {
   return DIM == 3 ? acc + mul_nc(v, w) : fmaf(v, w, acc);
 }
 
-template <int DIM, int PAD>
+template <int DIM, int PAD, bool PAIRED = true>
 __device__ __forceinline__ float sample_linear(const float* __restrict__ in, const Taps<DIM, PAD>& t, const Dims& d) {
-  const CornerOffsets<DIM, PAD> o(t, d);
+  const CornerOffsets<DIM, PAD, PAIRED> o(t, d);
   float v[8];
   o.load(in, v);
   float acc = 0.f;

@@ -1212,6 +1212,16 @@ def test_owner_computes_scatters_propagate_non_finite_gradients(dims, amp, bound
         g = ops.raw_compose_self_bwd(wp, phi, ws, chain=False, halo=-bound)
         assert not torch.isfinite(g[0]).all(), poison          # it surfaces ...
         assert torch.isfinite(g[1]).all() and torch.equal(g[1], clean[1])      # ... and the other sample is untouched
+    if d == 3 and bound <= 4:      # the image warp's own kernel (the 16-byte form of the march scatter, one channel)
+        x, w1 = rand((2, 1) + dims, 63).to(DEV), rand((2, 1) + dims, 64).to(DEV)
+        clean1, cleang = ops.raw_grid_sample_bwd(w1, x, phi, 0, 0, True, True, True, -bound)
+        assert torch.isfinite(clean1).all() and torch.isfinite(cleang).all()
+        for poison in (float("nan"), float("inf")):
+            wp = w1.clone()
+            wp[(0, 0) + tuple(s // 2 for s in dims)] = poison
+            g1, gg = ops.raw_grid_sample_bwd(wp, x, phi, 0, 0, True, True, True, -bound)
+            assert not torch.isfinite(g1[0]).all(), poison
+            assert torch.isfinite(g1[1]).all() and torch.equal(g1[1], clean1[1]) and torch.equal(gg[1], cleang[1])
 
 
 @pytest.mark.parametrize("dims", [(9, 11), (5, 6, 7)])
