@@ -39,12 +39,24 @@ constexpr int kDbgNoA = 16, kDbgNoB = 32, kDbgNoStore = 64, kDbgNoStage = 128;
 constexpr int kSegOwn = 56;       // owned lanes of an x segment (rows longer than 64 voxels)
 constexpr int kMarchXcd = 256;    // workgroup -> tile map that keeps halo-sharing tiles on one XCD (one L2)
 
-template <int C, bool SELF, bool GG, int NW, int RPW>
+// WIDE (rows of 68 .. 80 voxels, cfg-5's 160 x 160 x 80): the x fold through whole-wave DPP shifts ties a lane to an x,
+// so a row cannot be cut into flat items as in the forward sampler.  Instead three A waves own RPW rows each, lanes <-> x
+// 0 .. 63 (outputs 0 .. 59), and ONE B wave takes the tails of all 3 * RPW rows: three sub-rows of 21 lanes <-> x
+// 59 .. 79 (outputs 60 .. 79; the lane at x = 59 is a halo sample whose deposit on x - 1 is dropped, so the DPP shift
+// that crosses into the previous sub-row carries a zero).  Four wave-passes per 3 rows of 80 voxels instead of the six
+// of two x segments with 56 owned lanes.
+constexpr int kWideSplit = 60;    // first output x of the B wave (a multiple of 4: 16-byte stores)
+constexpr int kWideSub = 21;      // lanes per sub-row of the B wave: x = 59 .. 79
+constexpr int kWidePW = 80;       // longest row of the wide form
+
+template <int C, bool SELF, bool GG, int NW, int RPW, bool WIDE = false>
 struct MarchCfg {
-  static constexpr int TY = NW * RPW;
+  static constexpr int TY = WIDE ? 3 * RPW : NW * RPW;
   static constexpr int R = TY + 2;                              // staged rows per plane (one halo row each side)
   static constexpr int NT = NW * 64;
-  static constexpr int PITCH = 72;                              // 4 zeros | 64 voxels | 4 zeros
+  static constexpr int PITCH = WIDE ? kWidePW + 8 : 72;         // 4 zeros | 64 (80) voxels | 4 zeros
+  static constexpr int QPR = (PITCH - 8) / 4;                   // 16-byte staging items per row
+  static_assert(!WIDE || NW == 4, "wide form: three A waves and one B wave");
   static constexpr bool HAS_IMG = GG && !SELF;
   static constexpr int RING_CH = SELF ? 3 : (HAS_IMG ? C : 0);  // planes z-1..z+1 are needed: 4-slot ring
   static constexpr int LATE_CH = SELF ? 3 : 3 + C;              // only the current plane is needed: 2 slots
@@ -55,18 +67,18 @@ struct MarchCfg {
   static constexpr int TRW = NA_ROUND * RPW * 64;               // transposition scratch per wave (floats)
   static constexpr size_t LDS = (size_t)(4 * PS + 2 * LS + NW * TRW) * sizeof(float);
   static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF && RPW == 1 ? (NW == 8 ? 4 : 3) : 2);   // per SIMD: 128 / 168 / 256 VGPRs (512-thread blocks: 2 waves per SIMD each)
-  static_assert(R * 16 <= NT, "one staging item (4 voxels of one row, all channels) per thread");
+  static_assert(R * QPR <= NT, "one staging item (4 voxels of one row, all channels) per thread");
   static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
 };
 
 __device__ __forceinline__ float march_unnormalize(float g, int S) { return ((g + 1.f) * 0.5f) * (float)(S - 1); }
 
-template <int C, bool SELF, bool GG, int MODE, int NW, int RPW>
-__global__ void __launch_bounds__(NW * 64, (MarchCfg<C, SELF, GG, NW, RPW>::MIN_WAVES))
+template <int C, bool SELF, bool GG, int MODE, int NW, int RPW, bool WIDE = false>
+__global__ void __launch_bounds__(NW * 64, (MarchCfg<C, SELF, GG, NW, RPW, WIDE>::MIN_WAVES))
 k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                 float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int zc, int flags,
                 int32_t* __restrict__ untracked, int nseg) {
-  using G = MarchCfg<C, SELF, GG, NW, RPW>;
+  using G = MarchCfg<C, SELF, GG, NW, RPW, WIDE>;
   constexpr int R = G::R, TY = G::TY, RC = G::RING_CH, LC = G::LATE_CH, P = G::PITCH, PS = G::PS, LS = G::LS;
   constexpr bool CLIP = MODE != kMarchFree, BORDER = MODE == kMarchBorder;
   if (untracked && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) untracked[3] = -1;   // see adjoint_gather.hip
@@ -101,12 +113,12 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   // ---- the zero columns of every staged row (never written again)
   for (int e = threadIdx.x; e < (4 * RC + 2 * LC) * R * 2; e += G::NT) {
     const int row = e >> 1, side = e & 1;
-    *reinterpret_cast<float4*>(lds + row * P + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(lds + row * P + (side ? P - 4 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
-  const bool has_item = threadIdx.x < R * 16;
-  const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
+  const bool has_item = threadIdx.x < R * G::QPR;
+  const int r_st = (int)threadIdx.x / G::QPR, q_st = (int)threadIdx.x % G::QPR;
   const int sy_st = y0 - 1 + r_st, x_st = xbase + 4 * q_st;
   const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st >= 0 && x_st < d.s2;
   const int lds_item = r_st * P + 4 + 4 * q_st;
@@ -204,11 +216,20 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
   for (int o = 0; o < RPW; ++o) gg_hold[o][0] = gg_hold[o][1] = gg_hold[o][2] = 0.f;
 
-  const int xl = xbase + lane;                 // x of this lane
+  // x and first owned output row (within the tile) of this lane.  Narrow rows / x segments / A waves: lane <-> x, the
+  // wave's own rows.  B wave of the wide form: sub-row sb of 21 lanes <-> x = 59 .. 79 of rows sb * RPW ..; lane 63 idles
+  // on the zero column at x = 80.
+  const bool bwave = WIDE && wave == 3;
+  const int sb = bwave ? min(lane / kWideSub, 2) : 0;
+  const int xl = bwave ? kWideSplit - 1 + lane - kWideSub * sb : xbase + lane;
+  const int own_row0 = bwave ? sb * RPW : wave * RPW;
+  const bool kill_left = bwave && xl == kWideSplit - 1;      // its deposit on x - 1 belongs to an A wave
+  const int lbase = own_row0 * P + 4 + (xl - xbase);         // this lane in a staged channel plane: + (ch * R + row) * P
+  // where the lane puts a result in the wave's transposition scratch: the 20 owned voxels of sub-row sb at 20 * sb
+  const int tr_pos = bwave ? ((xl >= kWideSplit && xl < kWidePW) ? 20 * sb + xl - kWideSplit : 60 + (lane == 63 ? 3 : sb)) : lane;
   const float xlo = -(float)xl, xhi = (float)(d.s2 - 1 - xl);
   const float half_top[3] = {0.5f * (float)(d.s2 - 1), 0.5f * (float)(d.s1 - 1), 0.5f * (float)(d.s0 - 1)};
   float* const tr = trbuf + wave * G::TRW;
-  const int own_row0 = wave * RPW;              // first owned output row of this wave within the tile
 
   // results of one step: `vals[a][o]` (array a, owned row o) go out 4 voxels per lane through the wave's LDS scratch.
   // Array a of the step starts at dst[a] + row_base[a] (floats), row o at + o * S2; `ok[a]` says whether the array is
@@ -222,7 +243,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
       for (int a = 0; a < NR; ++a)
 #pragma unroll
         for (int o = 0; o < RPW; ++o)
-          if (a0 + a < G::NA) tr[(a * RPW + o) * 64 + lane] = vals[a0 + a][o];
+          if (a0 + a < G::NA) tr[(a * RPW + o) * 64 + tr_pos] = vals[a0 + a][o];
       lds_order();
       // items of this round: (array, row, quad); 16 quads per row
       constexpr int ITEMS = NR * RPW * 16;
@@ -231,15 +252,22 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
         const int j = i0 + lane;
         const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
         const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
-        const int xq = xbase + 4 * q;
-        const bool inside = j < ITEMS && xq < d.s2 && (nseg == 1 || (q >= 1 && q <= 14)) && (y0 + own_row0 + o) < d.s1;
+        // the quad's x and owned row: lane <-> x (x segments: quads 1 .. 14 are owned) | A wave: outputs 0 .. 59 | B wave:
+        // quad q is quad q % 5 of sub-row q / 5
+        int xq = xbase + 4 * q, rq = wave * RPW + o;
+        bool inside = j < ITEMS && (nseg == 1 || (q >= 1 && q <= 14));
+        if (WIDE) {
+          inside = j < ITEMS && q <= 14;
+          if (wave == 3) { xq = kWideSplit + 4 * (q % 5); rq = (q / 5) * RPW + o; }
+        }
+        inside = inside && xq < d.s2 && (y0 + rq) < d.s1;
         bool valid = false;
         float* p = nullptr;
 #pragma unroll
         for (int aa = 0; aa < NR; ++aa)
           if (a0 + aa < G::NA && a == aa) {
             valid = inside && ok[a0 + aa];
-            p = dst[a0 + aa] + (uint32_t)(row_base[a0 + aa] + o * d.s2 + xq);
+            p = dst[a0 + aa] + (uint32_t)(row_base[a0 + aa] + rq * d.s2 + xq);
           }
         if (valid) *reinterpret_cast<float4*>(p) = v4;
       }
@@ -257,8 +285,9 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     }
 
     const float* lslot = late + (zp & 1) * LS;
-    const float* fbase = (SELF ? ring + (zp & 3) * PS : lslot) + 4 + lane;     // field offsets, 3 ch; [ch * R * P + row * P]
-    const float* gobase = (SELF ? lslot : lslot + 3 * R * P) + 4 + lane;       // grad_out, C ch
+    // (rows below are relative to the lane's first owned row: lbase carries own_row0)
+    const float* fbase = (SELF ? ring + (zp & 3) * PS : lslot) + lbase;        // field offsets, 3 ch; [ch * R * P + row * P]
+    const float* gobase = (SELF ? lslot : lslot + 3 * R * P) + lbase;          // grad_out, C ch
     const float fzp = (float)zp;
     const float zlo = -fzp, zhi = (float)(d.s0 - 1) - fzp;
 
@@ -266,7 +295,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     if (zp >= 0 && zp < d.s0 && !(flags & kDbgNoB)) {
 #pragma unroll
       for (int i = 0; i < RPW + 2; ++i) {
-        const int r = own_row0 + i;             // staged row of the sample; sample y = y0 - 1 + r
+        const int r = i;                        // staged row of the sample past the lane's own_row0; sample y = y0 - 1 + own_row0 + r
         float fx = fbase[(0 * R + r) * P];
         float fy = fbase[(1 * R + r) * P];
         float fz = fbase[(2 * R + r) * P];
@@ -274,13 +303,14 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
         for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
         if (CLIP) {
-          const float ys = (float)(y0 - 1 + r);
+          const float ys = (float)(y0 - 1 + own_row0 + r);
           fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
           fy = __builtin_amdgcn_fmed3f(fy, -ys, (float)(d.s1 - 1) - ys);
           fz = __builtin_amdgcn_fmed3f(fz, zlo, zhi);
         }
         float tx[3], tyv[3], tzv[3];
         tx[0] = fmaxf(0.f, -fx); tx[2] = fmaxf(0.f, fx); tx[1] = (1.f - tx[0]) - tx[2];
+        if (WIDE) tx[0] = kill_left ? 0.f : tx[0];
         tyv[0] = fmaxf(0.f, -fy); tyv[2] = fmaxf(0.f, fy); tyv[1] = (1.f - tyv[0]) - tyv[2];
         tzv[0] = fmaxf(0.f, -fz); tzv[2] = fmaxf(0.f, fz); tzv[1] = (1.f - tzv[0]) - tzv[2];
 #pragma unroll
@@ -313,7 +343,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     for (int c = 0; c < C; ++c) {
       const int a = (SELF || !GG) ? c : 3 + c;
       dst[a] = ginn + (size_t)c * V;
-      row_base[a] = (zt * d.s1 + y0 + own_row0) * d.s2;
+      row_base[a] = (zt * d.s1 + y0) * d.s2;
       ok[a] = fin;
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
@@ -339,7 +369,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         dst[a] = ggn + (size_t)a * V;
-        row_base[a] = (zp * d.s1 + y0 + own_row0) * d.s2;
+        row_base[a] = (zp * d.s1 + y0) * d.s2;
         ok[a] = do_a;
 #pragma unroll
         for (int o = 0; o < RPW; ++o) vals[a][o] = 0.f;
@@ -348,8 +378,8 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     if (do_a) {
 #pragma unroll
       for (int o = 0; o < RPW; ++o) {
-        const int r = own_row0 + o + 1;
-        const float ys = (float)(y0 - 1 + r);
+        const int r = o + 1;                    // (past the lane's own_row0, as above)
+        const float ys = (float)(y0 - 1 + own_row0 + r);
         const float lo[3] = {xlo, -ys, zlo};
         const float hi[3] = {xhi, (float)(d.s1 - 1) - ys, zhi};
         float w1[3], mult[3];
@@ -373,8 +403,8 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
         for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
         // corner (0,0,0) of this sample in the ring: plane zp + fl_z, staged row r + fl_y, x = lane + fl_x (the zero
         // columns, rows and planes make a corner outside the volume read 0)
-        const float* q0 = ring + ((zp + fl[2]) & 3) * PS + (r + fl[1]) * P + 4 + lane + fl[0];
-        const float* q1 = ring + ((zp + fl[2] + 1) & 3) * PS + (r + fl[1]) * P + 4 + lane + fl[0];
+        const float* q0 = ring + ((zp + fl[2]) & 3) * PS + (r + fl[1]) * P + lbase + fl[0];
+        const float* q1 = ring + ((zp + fl[2] + 1) & 3) * PS + (r + fl[1]) * P + lbase + fl[0];
         const float wx1 = w1[0], wy1 = w1[1], wz1 = w1[2];
         float acc3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -440,11 +470,11 @@ static int march_zc(const Dims& d, int64_t N, int ty) {
   return zc;
 }
 
-template <int C, bool SELF, bool GG, int MODE, int NW, int RPW>
+template <int C, bool SELF, bool GG, int MODE, int NW, int RPW, bool WIDE = false>
 static void launch_march(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
                          Dims d, int32_t* ws, hipStream_t st) {
-  using G = MarchCfg<C, SELF, GG, NW, RPW>;
-  auto kern = k_adjoint_march<C, SELF, GG, MODE, NW, RPW>;
+  using G = MarchCfg<C, SELF, GG, NW, RPW, WIDE>;
+  auto kern = k_adjoint_march<C, SELF, GG, MODE, NW, RPW, WIDE>;
   static bool attr_set = false;
   if (G::LDS > 65536 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
@@ -453,11 +483,17 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
   static const int dbg = (getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0) |
                          (getenv("ADVCHAIN_NO_XCD_MAP") ? 0 : kMarchXcd);
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
-  const int nseg = d.s2 <= 64 ? 1 : (d.s2 + kSegOwn - 1) / kSegOwn;
+  const int nseg = (WIDE || d.s2 <= 64) ? 1 : (d.s2 + kSegOwn - 1) / kSegOwn;
   const int zc = march_zc(d, N * nseg, G::TY);
   const int n0 = (d.s0 + zc - 1) / zc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
                      n1, zc, dbg, SELF ? ws : (int32_t*)nullptr, nseg);
+}
+
+// rows of 68 .. 80 voxels: the A / B wave form (MarchCfg, WIDE)
+static bool march_wide(const Dims& d) {
+  static const bool off = getenv("ADVCHAIN_NO_WIDE_ADJOINT") != nullptr;   // A/B knob
+  return !off && d.s2 > 64 && d.s2 <= kWidePW;
 }
 
 static bool march_shape_ok(const Dims& d, const void* a, const void* b, const void* c, const void* e, const void* f) {
@@ -473,7 +509,8 @@ int advchain_self_adjoint_march_launch(const float* gout, const float* phi, floa
                                        int32_t* workspace, hipStream_t st) {
   if (!march_shape_ok(d, gout, phi, gphi, nullptr, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
   static const int rpw = getenv("ADVCHAIN_MARCH_SELF_RPW") ? atoi(getenv("ADVCHAIN_MARCH_SELF_RPW")) : 2;   // tuning knob
-  if (rpw == 2) launch_march<3, true, false, kMarchBorder, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
+  if (march_wide(d)) launch_march<3, true, false, kMarchBorder, 4, 2, true>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
+  else if (rpw == 2) launch_march<3, true, false, kMarchBorder, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   else if (rpw == 8) launch_march<3, true, false, kMarchBorder, 8, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   else launch_march<3, true, false, kMarchBorder, 4, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   ADVCHAIN_LAUNCH_CHECK();
@@ -483,7 +520,10 @@ int advchain_self_adjoint_march_launch(const float* gout, const float* phi, floa
 template <int MODE>
 static void launch_warp_march(const float* gout, const float* in, const float* grid, float* gin, float* ggrid, int64_t N,
                               int64_t C, Dims d, hipStream_t st) {
-  if (C == 1) {
+  if (C == 1 && march_wide(d)) {
+    if (ggrid) launch_march<1, false, true, MODE, 4, 2, true>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+    else launch_march<1, false, false, MODE, 4, 2, true>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
+  } else if (C == 1) {
     if (ggrid) launch_march<1, false, true, MODE, 4, 2>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
     else launch_march<1, false, false, MODE, 4, 2>(gout, in, grid, gin, ggrid, N, d, nullptr, st);
   } else {

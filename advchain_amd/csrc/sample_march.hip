@@ -253,6 +253,229 @@ k_sample_march(const float* __restrict__ in, const float* __restrict__ grid, flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows of 68 .. PW voxels (cfg-5: 160 x 160 x 80): the same march with lane <-> FLAT voxel of the tile's TY x W plane.
+// The taps of a lane read LDS at addresses it computes itself, so nothing ties a lane to an x: a workgroup owns TY = 8
+// whole rows, its TY * W voxels of a plane are cut into items of 64 consecutive voxels (whole rows are contiguous in
+// memory: the grid loads and the 16-byte result stores of an item are one coalesced run) and wave w takes items
+// w * IPW .. w * IPW + IPW - 1 -- every lane of every wave has a voxel (80 = 1.25 x 64: the x segments of the kernel above
+// leave 48 of 128 lanes idle and the tile kernel, 164 us per squaring at 8 x 3 x 160 x 160 x 80, was the faster choice).
+// Staged rows are W voxels between 4 zero floats; arithmetic, fallback and results are those of k_sample_march.
+// ---------------------------------------------------------------------------------------------
+template <int C, bool SELF, int PW, int IPW>
+struct FlatMarchCfg {
+  static constexpr int TY = 8;
+  static constexpr int R = TY + 2;
+  static constexpr int P = PW + 8;                           // 4 zeros | up to PW voxels | 4 zeros
+  static constexpr int PS = C * R * P;
+  static constexpr int NWMAX = (TY * PW + 64 * IPW - 1) / (64 * IPW);
+  static constexpr int NA_ROUND = C > 2 ? 2 : C;
+  static constexpr int TRW = NA_ROUND * IPW * 64;
+  static size_t lds_bytes(int nw) { return (size_t)(4 * PS + nw * TRW) * sizeof(float); }
+  static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
+};
+
+template <int C, bool SELF, int MODE, int PW, int IPW>
+__global__ void __launch_bounds__((FlatMarchCfg<C, SELF, PW, IPW>::NWMAX) * 64)
+k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out,
+                    const float* __restrict__ phi0, Dims d, int n1, int zc, int final_mode, float* __restrict__ disp_out,
+                    int xcd) {
+  using G = FlatMarchCfg<C, SELF, PW, IPW>;
+  constexpr int R = G::R, TY = G::TY, P = G::P, PS = G::PS;
+  constexpr int PAD = MODE == kFwdBorder ? PAD_BORDER : PAD_ZEROS;
+  extern __shared__ float lds[];
+  float* const ring = lds;                  // [slot 4][C][R][P]
+  float* const trbuf = lds + 4 * PS;        // [wave][TRW]
+  const int V = (int)d.voxels();
+  const int W = d.s2, W4 = d.s2 >> 2;
+  const int NT = (int)blockDim.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tile = blockIdx.x + gridDim.x * blockIdx.y;
+  const int tiles = gridDim.x * gridDim.y;
+  if (xcd && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);   // XCD-contiguous tiles (see above)
+  const int n = tile / (int)gridDim.x;
+  const int rem = tile - n * (int)gridDim.x;
+  const int ty = rem % n1, tz = rem / n1;
+  const int y0 = ty * TY;
+  const int za = tz * zc, zb = min(za + zc, d.s0);
+  const float* inn = in + (int64_t)n * C * V;
+  const float* gn = SELF ? nullptr : grid + (int64_t)n * 3 * V;
+  const float* p0n = (SELF && final_mode == 1) ? phi0 + (int64_t)n * 3 * V : nullptr;
+  float* outn = out + (int64_t)n * C * V;
+  const int plane_stride = d.s1 * d.s2;
+  const int flat_n = min(TY, d.s1 - y0) * W;       // voxels of this tile in a plane
+
+  // ---- the zero columns of every staged row (never written again)
+  for (int e = threadIdx.x; e < 4 * C * R * 2; e += NT) {
+    const int row = e >> 1, side = e & 1;
+    *reinterpret_cast<float4*>(lds + row * P + (side ? 4 + W : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
+  const bool has_item = (int)threadIdx.x < R * W4;
+  const int r_st = (int)threadIdx.x / W4, q_st = (int)threadIdx.x - r_st * W4;
+  const int sy_st = y0 - 1 + r_st;
+  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1;
+  const int row_off = min(max(sy_st, 0), d.s1 - 1) * W + (has_item ? 4 * q_st : 0);
+  const int lds_item = r_st * P + 4 + 4 * q_st;
+  auto fetch = [&](int p, float (*v)[4]) {
+    const uint32_t s = (uint32_t)(min(max(p, 0), d.s0 - 1) * plane_stride + row_off);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 t = *reinterpret_cast<const float4*>(inn + (size_t)c * V + s);
+      v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+    }
+  };
+  auto commit = [&](int p, float (*v)[4]) {
+    const bool ok = row_ok && p >= 0 && p < d.s0;
+    float* slot = ring + (p & 3) * PS + lds_item;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      *reinterpret_cast<float4*>(slot + c * R * P) = make_float4(ok ? v[c][0] : 0.f, ok ? v[c][1] : 0.f, ok ? v[c][2] : 0.f,
+                                                                 ok ? v[c][3] : 0.f);
+  };
+
+  float pr[C][4];
+  if (has_item) {
+    float pa[C][4], pb[C][4];
+    fetch(za - 1, pa);
+    fetch(za, pb);
+    fetch(za + 1, pr);
+    commit(za - 1, pa);
+    commit(za, pb);
+    commit(za + 1, pr);
+  }
+  __syncthreads();
+
+  // ---- the voxels of this lane: item i of the wave -> flat voxel fc[i] = staged row orow[i] + 1, column ox[i]
+  int fc[IPW], orow[IPW], ox[IPW];
+  bool valid[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int f = (wave * IPW + i) * 64 + lane;
+    valid[i] = f < flat_n;
+    fc[i] = min(f, flat_n - 1);
+    orow[i] = fc[i] / W;
+    ox[i] = fc[i] - orow[i] * W;
+  }
+
+  float* const tr = trbuf + wave * G::TRW;
+  float dmax = 0.f;
+  const float topx = (float)(d.s2 - 1), topy = (float)(d.s1 - 1), topz = (float)(d.s0 - 1);
+
+  for (int z = za; z < zb; ++z) {
+    const bool more = z + 2 <= zb;
+    if (has_item) fetch(z + 2, pr);
+    const uint32_t tile_off = (uint32_t)((z * d.s1 + y0) * W);
+    float g[IPW][3], p0v[IPW][3];
+    if constexpr (!SELF) {
+#pragma unroll
+      for (int i = 0; i < IPW; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[i][a] = gn[(size_t)a * V + tile_off + fc[i]];
+    } else if (p0n) {
+#pragma unroll
+      for (int i = 0; i < IPW; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p0v[i][a] = p0n[(size_t)a * V + tile_off + fc[i]];
+    }
+
+    float res[C][IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int r = orow[i] + 1;            // staged row of this voxel
+      const int uy = y0 + orow[i];
+      const int xl = ox[i];
+      float gx, gy, gz;
+      if constexpr (SELF) {
+        const float* c0 = ring + (z & 3) * PS + r * P + 4 + xl;
+        gx = c0[0]; gy = c0[R * P]; gz = c0[2 * R * P];
+      } else {
+        gx = g[i][0]; gy = g[i][1]; gz = g[i][2];
+        if (MODE == kFwdClamp) { gx = clamp_unit(gx); gy = clamp_unit(gy); gz = clamp_unit(gz); }
+      }
+      float xs = ((gx + 1.f) * 0.5f) * topx, ys = ((gy + 1.f) * 0.5f) * topy, zs = ((gz + 1.f) * 0.5f) * topz;
+      if (PAD == PAD_BORDER) {
+        xs = fminf(fmaxf(xs, 0.f), topx); ys = fminf(fmaxf(ys, 0.f), topy); zs = fminf(fmaxf(zs, 0.f), topz);
+      }
+      xs = __builtin_amdgcn_fmed3f(xs, -16.f, 1.0e9f);
+      ys = __builtin_amdgcn_fmed3f(ys, -16.f, 1.0e9f);
+      zs = __builtin_amdgcn_fmed3f(zs, -16.f, 1.0e9f);
+      const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
+      const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+      const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs;
+      const float wy1 = ys - fy, wy0 = (fy + 1.f) - ys;
+      const float wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
+      const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)W;
+      if (staged) {
+        float w[8];
+        w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
+        w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
+        const int oxy = (r + (iy - uy)) * P + 4 + ix;
+        const float* q0 = ring + (iz & 3) * PS + oxy;
+        const float* q1 = ring + ((iz + 1) & 3) * PS + oxy;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float acc = 0.f;
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+              for (int cx = 0; cx < 2; ++cx)     // product then sum, never contracted: see tap_acc() (sampler_common.h)
+                acc = tap_acc<3>(acc, ((cz ? q1 : q0) + (c * R + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
+          res[c][i] = acc;
+        }
+      } else if (valid[i]) {
+        Taps<3, PAD> t;
+        t.build(gx, gy, gz, d);
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][i] = sample_linear<3, PAD, false>(inn + (size_t)c * V, t, d);
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][i] = 0.f;
+      }
+      if constexpr (SELF) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float v = res[c][i];
+          const int sc = c == 0 ? xl : (c == 1 ? uy : z), Sc = c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0);
+          if (final_mode == 1) v = (v - p0v[i][c]) + lin_coord(sc, Sc);
+          res[c][i] = v;
+          if (disp_out && valid[i]) dmax = fmaxf(dmax, voxel_displacement(v, Sc, sc));
+        }
+      }
+    }
+
+    // ---- results leave 4 voxels per lane through the wave's LDS scratch (an item is 64 consecutive voxels in memory)
+    constexpr int NR = G::NA_ROUND;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += NR) {
+#pragma unroll
+      for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+          if (c0 + a < C) tr[(a * IPW + i) * 64 + lane] = res[c0 + a][i];
+      lds_order();
+      constexpr int ITEMS = NR * IPW * 16;
+#pragma unroll
+      for (int i0 = 0; i0 < ITEMS; i0 += 64) {
+        const int j = i0 + lane;
+        const int a = j / (IPW * 16), i = (j / 16) % IPW, q = j & 15;
+        const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * IPW + i) * 64 + 4 * q);
+        const int f4 = (wave * IPW + i) * 64 + 4 * q;
+        if (j < ITEMS && c0 + a < C && f4 < flat_n)
+          *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + tile_off + (uint32_t)f4) = v4;
+      }
+      lds_order();
+    }
+
+    if (has_item && more) commit(z + 2, pr);
+    __syncthreads();
+  }
+  if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // f1 experiment: TWO squarings per launch.  phi -> phi' = phi o phi is computed on
 // the owned rows plus one halo row either side and kept in a second LDS ring; phi'' = phi' o phi' of the owned rows is
 // taken from that ring.  phi' is still written (the backward wants every field); what the fusion saves is the second
@@ -543,6 +766,36 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
                      final_mode, disp_out, no_xcd ? -nseg : nseg);
 }
 
+// rows of 68 .. 80 voxels: lane <-> flat voxel (k_sample_march_flat)
+constexpr int kFlatPW = 80;
+template <int C, bool SELF, int MODE>
+static void launch_fwd_flat(const float* in, const float* grid, float* out, const float* phi0, int64_t N, Dims d,
+                            int final_mode, float* disp_out, hipStream_t st) {
+  constexpr int IPW = 2;
+  using G = FlatMarchCfg<C, SELF, kFlatPW, IPW>;
+  auto kern = k_sample_march_flat<C, SELF, MODE, kFlatPW, IPW>;
+  const int nw = (G::TY * d.s2 + 64 * IPW - 1) / (64 * IPW);
+  const size_t lds = G::lds_bytes(G::NWMAX);
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int n1 = (d.s1 + G::TY - 1) / G::TY;
+  const int zc = fwd_march_zc(d, N, G::TY, C);
+  const int n0 = (d.s0 + zc - 1) / zc;
+  static const bool no_xcd = getenv("ADVCHAIN_NO_XCD_MAP") != nullptr;   // A/B knob
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(nw * 64), G::lds_bytes(nw), st, in, grid, out, phi0, d, n1,
+                     zc, final_mode, disp_out, no_xcd ? 0 : 1);
+}
+
+template <int C>
+static void launch_fwd_flat_mode(int mode, const float* in, const float* grid, float* out, int64_t N, Dims d, hipStream_t st) {
+  if (mode == kFwdBorder) launch_fwd_flat<C, false, kFwdBorder>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+  else if (mode == kFwdClamp) launch_fwd_flat<C, false, kFwdClamp>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+  else launch_fwd_flat<C, false, kFwdFree>(in, grid, out, nullptr, N, d, 0, nullptr, st);
+}
+
 template <int C>
 static void launch_fwd_march_mode(int mode, const float* in, const float* grid, float* out, int64_t N, Dims d, hipStream_t st) {
   if (mode == kFwdBorder) launch_fwd_march<C, false, kFwdBorder, 4, 2>(in, grid, out, nullptr, N, d, 0, nullptr, st);
@@ -559,14 +812,17 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
   const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out);
   if (d.s2 < 8 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
     return ADVCHAIN_ERR_UNSUPPORTED;
+  static const bool no_flat = getenv("ADVCHAIN_NO_FLAT_FWD") != nullptr;   // A/B knob
+  const bool flat = !no_flat && d.s2 > 64 && d.s2 <= kFlatPW;
   if (self) {
     if (C != 3) return ADVCHAIN_ERR_UNSUPPORTED;
-    launch_fwd_march<3, true, kFwdBorder, 4, 2>(in, nullptr, out, phi0, N, d, final_mode, disp_out, st);
+    if (flat) launch_fwd_flat<3, true, kFwdBorder>(in, nullptr, out, phi0, N, d, final_mode, disp_out, st);
+    else launch_fwd_march<3, true, kFwdBorder, 4, 2>(in, nullptr, out, phi0, N, d, final_mode, disp_out, st);
   } else {
     const int mode = padding == PAD_BORDER ? kFwdBorder : (clamp_grid ? kFwdClamp : kFwdFree);
     // (border padding with clamp_grid: the clamp is implied by the clip of the source coordinate)
-    if (C == 1) launch_fwd_march_mode<1>(mode, in, grid, out, N, d, st);
-    else if (C == 4) launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
+    if (C == 1) flat ? launch_fwd_flat_mode<1>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<1>(mode, in, grid, out, N, d, st);
+    else if (C == 4) flat ? launch_fwd_flat_mode<4>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
     else return ADVCHAIN_ERR_UNSUPPORTED;
   }
   ADVCHAIN_LAUNCH_CHECK();

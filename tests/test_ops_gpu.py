@@ -502,12 +502,13 @@ def test_demons_field_pair_is_the_two_single_fields(dims, vs, scale):
     assert maxdiff(a.grad, b.grad) <= 2e-6 * float(b.grad.abs().max()), (dims, scale)
 
 
-@pytest.mark.parametrize("dims", [(6, 10, 72), (5, 9, 80), (4, 6, 132), (10, 12, 64), (5, 7, 16)])
+@pytest.mark.parametrize("dims", [(6, 10, 72), (5, 9, 80), (4, 6, 132), (10, 12, 64), (5, 7, 16), (6, 19, 68), (11, 16, 76),
+                                  (12, 17, 80), (4, 6, 84)])
 @pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
 def test_march_kernels_rows_of_any_length(dims, pad, clamp):
     """The z-marching forward sampler and exact-bound adjoint (sample_march.hip / adjoint_march.hip) on rows longer than
-    64 voxels (x segments of 56 owned lanes + 4 halo lanes), on short rows and on the 64-voxel rows they were written
-    for: sub-voxel fields (everything from the LDS ring) and a field with a few samples beyond a voxel (per-lane
+    64 voxels (68 .. 80: lane <-> flat voxel in the forward, three A waves + one B wave of row tails in the adjoint; beyond:
+    x segments of 56 owned lanes + 4 halo lanes), on short rows and on the 64-voxel rows they were written for: sub-voxel fields (everything from the LDS ring) and a field with a few samples beyond a voxel (per-lane
     fallback to global gathers in the forward), against ATen / the oracle."""
     from oracle import advchain_oracle as O
     ops = _ops()
@@ -1171,6 +1172,7 @@ def test_kl_term_in_every_kernel_variant(dims, K):
 
 
 @pytest.mark.parametrize("dims,amp", [((24, 21, 44), 0.4), ((24, 21, 44), 2.6), ((16, 32, 64), 0.6), ((16, 32, 64), 3.4),
+                                      ((20, 27, 80), 0.5), ((20, 27, 80), 2.6), ((12, 17, 72), 0.7),   # (rows of 68 .. 80: flat march)
                                       ((32, 64, 64), 1.7)])   # (32 workgroups of the ring forward: XCD-contiguous tile map on)
 def test_forward_results_do_not_depend_on_the_displacement_hint(dims, amp):
     """The displacement hint (bits 8..15 of clamp_grid / final_mode) only selects the 3D forward kernel -- z-marching ring
