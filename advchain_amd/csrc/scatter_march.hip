@@ -465,6 +465,235 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The self-composition on rows of 68 .. 80 voxels (cfg-5: 160 x 160 x 80) with lane <-> FLAT sample.  k_scatter_march3d cuts
+// such rows into x segments of 64 - 2H owned lanes: two 64-lane visits per sample row, the second one a quarter full, and
+// the halo lanes of a segment visited twice.  Nothing in a deposit ties a lane to an x -- the cell is an address the lane
+// computes -- so here the accumulator rows are W cells wide (no x halo at all), the (TY + 2H) x W samples of a plane are cut
+// into items of 64 consecutive samples (whole rows are contiguous in memory: an item is one coalesced run) and wave w takes
+// items w, w + NWV, ...; the TY x W outputs of the finished plane leave the same way.  Arithmetic, fixed-point scale and
+// summation are those of k_scatter_march3d<PAD_BORDER, 3, true, false, 8>.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NWV, int MAXR>
+__global__ void __launch_bounds__(NWV * 64)
+k_scatter_march3d_flat(const float* __restrict__ gout, const float* __restrict__ phi, float* __restrict__ gin, Dims d, int n1,
+                       int zc, int TY, int H, int NS, int32_t* __restrict__ ws) {
+  constexpr int C = 3, PAD = PAD_BORDER;
+  constexpr int MAXF = 2;                        // output items per wave and step: TY * W <= 2 * NWV * 64
+  extern __shared__ int acc[];                   // [slot NS][C][TY][W]
+  const int V = (int)d.voxels(), W = d.s2;
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
+  const int y0 = ty * TY;
+  const int za = tz * zc, zb = min(za + zc, d.s0);
+  const int chan_cells = TY * W, plane_cells = C * chan_cells;
+  const float* gn = phi + (int64_t)n * 3 * V;
+  const float* gon = gout + (int64_t)n * C * V;
+  float* ginn = gin + (int64_t)n * C * V;
+  __shared__ float wmax[NWV];
+  {
+    const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s0 * d.s1;
+    const int ya = max(y0 - H, 0), yn = min(y0 + TY + H, d.s1) - ya;
+    const int zlo = max(za - H, 0), zn = min(zb + H, d.s0) - zlo;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < yn * zn; i += NWV * 64) m = fmaxf(m, rowmax[(zlo + i / yn) * d.s1 + ya + i % yn]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) wmax[wave] = m;
+  }
+  for (int i = threadIdx.x; i < NS * plane_cells; i += NWV * 64) acc[i] = 0;
+  __syncthreads();
+  float gmax = wmax[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) gmax = fmaxf(gmax, wmax[w]);
+  const float fix = march_fix_scale(H);
+  const float scale = gmax > 0.f ? fix / gmax : 0.f, inv = gmax / fix;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
+  const int yend = min(y0 + TY, d.s1);
+  const int nrows = TY + 2 * H;
+  const int nsamp = nrows * W, nitems = (nsamp + 63) >> 6;
+  const int nout = TY * W, oitems = (nout + 63) >> 6;
+  const unsigned plane_bytes = (unsigned)(d.s1 * W) * 4u;
+
+  // ---- the samples / outputs of this lane (the same in every step)
+  int sx[MAXR];
+  bool sval[MAXR];
+  unsigned soff[MAXR];                           // byte offset of the sample within its plane (row clamped into the volume)
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int f = (wave + k * NWV) * 64 + lane;
+    const int fcl = min(f, nsamp - 1);
+    const int r = fcl / W;
+    const int ys = y0 - H + r;
+    sval[k] = f < nsamp && ys >= 0 && ys < d.s1;
+    // (a lane past the last sample deposits its zeros into a column of its own: same-address LDS atomics serialise)
+    sx[k] = f < nsamp ? fcl - r * W : lane;
+    soff[k] = (unsigned)(min(max(ys, 0), d.s1 - 1) * W + sx[k]) * 4u;
+  }
+  int ocell[MAXF];
+  bool oval[MAXF], ocells[MAXF];
+  unsigned ooff[MAXF];
+#pragma unroll
+  for (int k = 0; k < MAXF; ++k) {
+    const int f = (wave + k * NWV) * 64 + lane;
+    const int fcl = min(f, nout - 1);
+    const int r = fcl / W, x = fcl - r * W;
+    ocells[k] = f < nout;
+    oval[k] = f < nout && y0 + r < d.s1;
+    ocell[k] = r * W + x;
+    ooff[k] = (unsigned)(min(y0 + r, d.s1 - 1) * W + x) * 4u;
+  }
+
+  auto load_samples = [&](int zp, float (&g)[MAXR][3], float (&go)[MAXR][C]) {
+    const unsigned base = (unsigned)min(max(zp, 0), d.s0 - 1) * plane_bytes;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      if (wave + k * NWV >= nitems) continue;                        // wave-uniform
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = ld_off(gn + (int64_t)a * V, base + soff[k]);
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = ld_off(gon + (int64_t)c * V, base + soff[k]);
+    }
+  };
+  auto load_own = [&](int zt, float (&g)[MAXF][3], float (&go)[MAXF][C]) {
+    const unsigned base = (unsigned)min(max(zt, 0), d.s0 - 1) * plane_bytes;
+#pragma unroll
+    for (int k = 0; k < MAXF; ++k) {
+      if (wave + k * NWV >= oitems) continue;                        // wave-uniform
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = ld_off(gn + (int64_t)a * V, base + ooff[k]);
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = ld_off(gon + (int64_t)c * V, base + ooff[k]);
+    }
+  };
+  float g[MAXR][3], go[MAXR][C], fg[MAXF][3], fgo[MAXF][C];
+  load_samples(za - H, g, go);
+  load_own(za - 2 * H, fg, fgo);
+  for (int zp = za - H; zp < zb + H; ++zp) {
+    float g1[MAXR][3], go1[MAXR][C], fg1[MAXF][3], fgo1[MAXF][C];
+    load_samples(zp + 1, g1, go1);
+    load_own(zp + 1 - H, fg1, fgo1);
+    // ---- deposits of sample plane zp: only what lands in the owned rows and planes is kept
+    if (zp >= 0 && zp < d.s0) {
+      const int sz = ((zp % NS) + NS) % NS;
+      const int zlo = max(za, zp - H), zhi = min(zb, zp + H + 2);
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k) {
+        if (wave + k * NWV >= nitems) continue;                      // wave-uniform
+        Taps<3, PAD> t;
+        t.y = make_tap<PAD>(g[k][1], d.s1);
+        t.z = make_tap<PAD>(g[k][2], d.s0);
+        const bool reach = sval[k] && t.y.i0 + 1 >= y0 && t.y.i0 < yend && t.z.i0 + 1 >= zlo && t.z.i0 < zhi;
+        if (__ballot(reach) == 0) continue;
+        t.x = make_tap<PAD>(g[k][0], d.s2);
+        float wxm[2], wym[2], wzm[2];
+        int colx[2], rowy[2], slotz[2];
+        bool anyy[2], anyz[2];
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const int pxx = t.x.i0 + cx;
+          const bool okx = sval[k] && pxx >= 0 && pxx < W;           // (masked lanes: own column, see k_scatter_march3d)
+          wxm[cx] = okx ? t.wx(cx) : 0.f;
+          colx[cx] = okx ? pxx : sx[k];
+        }
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+          const int py = t.y.i0 + cy;
+          anyy[cy] = py >= y0 && py < yend;
+          wym[cy] = anyy[cy] ? t.wy(cy) : 0.f;
+          rowy[cy] = min(max(py - y0, 0), TY - 1) * W;
+        }
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz) {
+          const int pz = t.z.i0 + cz;
+          anyz[cz] = pz >= zlo && pz < zhi;
+          wzm[cz] = anyz[cz] ? t.wz(cz) : 0.f;
+          int slot = sz + min(max(pz - zp, -H), H + 1);
+          slot += slot < 0 ? NS : 0;
+          slot -= slot >= NS ? NS : 0;
+          slotz[cz] = slot * plane_cells;
+        }
+        float a[C][2];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float gsc = go[k][c] * scale;
+          a[c][0] = wxm[0] * gsc;
+          a[c][1] = wxm[1] * gsc;
+        }
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            if (__ballot(anyz[cz] && anyy[cy]) == 0) continue;       // wave-uniform
+            const float wzy = wzm[cz] * wym[cy];
+            int* cell = acc + slotz[cz] + rowy[cy];
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx)
+#pragma unroll
+              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * chan_cells, __float2int_rn(wzy * a[c][cx]));
+          }
+      }
+    }
+    // ---- coordinate path of the outputs this wave finishes below (independent of the accumulator: before the barrier)
+    const int zt = zp - H;
+    const bool fin = zt >= za && zt < zb;
+    float gg[MAXF][3];
+    if (fin) {
+#pragma unroll
+      for (int k = 0; k < MAXF; ++k) {
+        if (wave + k * NWV >= oitems) continue;                      // wave-uniform
+        Taps<3, PAD> t;
+        t.build(fg[k][0], fg[k][1], fg[k][2], d);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) coord_path_diff<3, PAD>(gn + (int64_t)c * V, fgo[k][c], t, d, ax, ay, az);
+        gg[k][0] = t.x.mult * ax;
+        gg[k][1] = t.y.mult * ay;
+        gg[k][2] = t.z.mult * az;
+      }
+    }
+    __syncthreads();
+    // ---- output plane zp-H has seen every sample that can reach it: convert, add the coordinate path, store
+    if (fin) {
+      const int slot = ((zt % NS) + NS) % NS;
+      const unsigned base = (unsigned)zt * plane_bytes;
+#pragma unroll
+      for (int k = 0; k < MAXF; ++k) {
+        if (wave + k * NWV >= oitems) continue;                      // wave-uniform
+        if (ocells[k]) {
+          int* cell = acc + slot * plane_cells + ocell[k];
+          float v[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            v[c] = (float)cell[c * chan_cells] * inv;
+            cell[c * chan_cells] = 0;
+          }
+          if (oval[k]) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) st_off(ginn + (int64_t)c * V, base + ooff[k], v[c] + gg[k][c]);
+          }
+        }
+      }
+    }
+    if (NS == 2 * H + 2) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[k][a] = g1[k][a];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[k][c] = go1[k][c];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXF; ++k) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) fg[k][a] = fg1[k][a];
+#pragma unroll
+      for (int c = 0; c < C; ++c) fgo[k][c] = fgo1[k][c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same march for an image warp (C == 1, rows of at most 64 voxels) with everything that crosses the memory pipeline
 // 16 bytes wide.  k_scatter_march3d is bound by vector-memory ISSUE, not by bytes or VALU (lesson 4: a CU retires one
 // vector-memory wave-instruction per ~26 clk whatever it carries): per step and CU it issues 4 dword loads per visited
@@ -993,6 +1222,33 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     }
 #undef GOB_PAD
 #undef GOB
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
+  // self-composition on rows of 68 .. 80 voxels: lane <-> flat sample (k_scatter_march3d_flat)
+  static const bool no_flat = getenv("ADVCHAIN_NO_SCATTER_MARCH_FLAT") != nullptr;   // A/B knob
+  if (!no_flat && self && H <= 4 && d.s2 > 64 && d.s2 <= 80) {
+    const int TYf = 8, W = (int)d.s2;
+    int NSf = 2 * H + 3;
+    if ((size_t)NSf * 3 * TYf * W * 4 > 80 * 1024) NSf = 2 * H + 2;       // two workgroups a CU
+    const size_t ldsf = (size_t)NSf * 3 * TYf * W * sizeof(int);
+    const int n1f = (int)((d.s1 + TYf - 1) / TYf);
+    int zcf = (int)d.s0;
+    while (zcf > 8 && N * n1f * ((d.s0 + zcf - 1) / zcf) < 512) zcf = (zcf + 1) / 2;
+    static const int zcf_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+    if (zcf_forced > 0) zcf = zcf_forced;
+    const int n0f = (int)((d.s0 + zcf - 1) / zcf);
+    const int rows = (int)(d.s0 * d.s1);
+    launch_rowmax<3>(gout, reinterpret_cast<float*>(workspace + 4), d, rows, N, 3, st);
+    const int nitems = ((TYf + 2 * H) * W + 63) / 64;
+    dim3 gf((unsigned)(n1f * n0f), (unsigned)N);
+#define GOF(MAXR_) do { \
+      auto kern = k_scatter_march3d_flat<8, MAXR_>; \
+      static bool attr_set = false; \
+      if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+      hipLaunchKernelGGL(kern, gf, dim3(512), ldsf, st, gout, grid, gin, d, n1f, zcf, TYf, H, NSf, workspace); } while (0)
+    if (nitems <= 16) GOF(2); else GOF(3);
+#undef GOF
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
   }

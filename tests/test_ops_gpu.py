@@ -602,6 +602,7 @@ def test_window_scatter_3d(dims, amp_vox, halo):
 
 
 @pytest.mark.parametrize("dims", [(12, 20, 16), (9, 18, 64), (24, 21, 44), (40, 33, 32), (10, 12, 80), (9, 10, 132),
+                                  (20, 19, 72), (24, 21, 80),      # (rows of 68 .. 80: the flat form for the self-composition)
                                   (32, 64, 64)])   # (16 workgroups of the 16-byte form: the XCD-contiguous tile map is on)
 @pytest.mark.parametrize("amp_vox,bound", [(1.6, 2), (2.7, 3), (3.6, 4), (5.4, 6), (7.5, 8)])
 def test_scatter_march_3d_exact_bounds(dims, amp_vox, bound):
