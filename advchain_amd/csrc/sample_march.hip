@@ -766,14 +766,17 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
                      final_mode, disp_out, no_xcd ? -nseg : nseg);
 }
 
-// rows of 68 .. 80 voxels: lane <-> flat voxel (k_sample_march_flat)
-constexpr int kFlatPW = 80;
-template <int C, bool SELF, int MODE>
+// rows of 68 .. 80 (PW = 80) and 84 .. 128 (PW = 128) voxels: lane <-> flat voxel (k_sample_march_flat)
+constexpr int kFlatPW = 80, kFlatPW2 = 128;
+template <int C, bool SELF, int MODE, int PW = kFlatPW>
 static void launch_fwd_flat(const float* in, const float* grid, float* out, const float* phi0, int64_t N, Dims d,
                             int final_mode, float* disp_out, hipStream_t st) {
   constexpr int IPW = 2;
-  using G = FlatMarchCfg<C, SELF, kFlatPW, IPW>;
-  auto kern = k_sample_march_flat<C, SELF, MODE, kFlatPW, IPW>;
+  if constexpr (PW == kFlatPW) {
+    if (d.s2 > kFlatPW) return launch_fwd_flat<C, SELF, MODE, kFlatPW2>(in, grid, out, phi0, N, d, final_mode, disp_out, st);
+  }
+  using G = FlatMarchCfg<C, SELF, PW, IPW>;
+  auto kern = k_sample_march_flat<C, SELF, MODE, PW, IPW>;
   const int nw = (G::TY * d.s2 + 64 * IPW - 1) / (64 * IPW);
   const size_t lds = G::lds_bytes(G::NWMAX);
   static bool attr_set = false;
@@ -813,7 +816,7 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
   if (d.s2 < 8 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
     return ADVCHAIN_ERR_UNSUPPORTED;
   static const bool no_flat = getenv("ADVCHAIN_NO_FLAT_FWD") != nullptr;   // A/B knob
-  const bool flat = !no_flat && d.s2 > 64 && d.s2 <= kFlatPW;
+  const bool flat = !no_flat && d.s2 > 64 && d.s2 <= kFlatPW2;
   if (self) {
     if (C != 3) return ADVCHAIN_ERR_UNSUPPORTED;
     if (flat) launch_fwd_flat<3, true, kFwdBorder>(in, nullptr, out, phi0, N, d, final_mode, disp_out, st);
@@ -822,7 +825,9 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
     const int mode = padding == PAD_BORDER ? kFwdBorder : (clamp_grid ? kFwdClamp : kFwdFree);
     // (border padding with clamp_grid: the clamp is implied by the clip of the source coordinate)
     if (C == 1) flat ? launch_fwd_flat_mode<1>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<1>(mode, in, grid, out, N, d, st);
-    else if (C == 4) flat ? launch_fwd_flat_mode<4>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
+    // (four channels of rows beyond 80 voxels: the ring of the flat form takes 87 KiB, one workgroup a CU -- the x segments win,
+    // 81 against 105 us at 8 x 4 x 96 x 96 x 96)
+    else if (C == 4) (flat && d.s2 <= kFlatPW) ? launch_fwd_flat_mode<4>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
     else return ADVCHAIN_ERR_UNSUPPORTED;
   }
   ADVCHAIN_LAUNCH_CHECK();

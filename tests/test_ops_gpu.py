@@ -503,7 +503,7 @@ def test_demons_field_pair_is_the_two_single_fields(dims, vs, scale):
 
 
 @pytest.mark.parametrize("dims", [(6, 10, 72), (5, 9, 80), (4, 6, 132), (10, 12, 64), (5, 7, 16), (6, 19, 68), (11, 16, 76),
-                                  (12, 17, 80), (4, 6, 84)])
+                                  (12, 17, 80), (4, 6, 84), (5, 11, 128), (6, 9, 100)])
 @pytest.mark.parametrize("pad,clamp", [("zeros", True), ("zeros", False), ("border", False)])
 def test_march_kernels_rows_of_any_length(dims, pad, clamp):
     """The z-marching forward sampler and exact-bound adjoint (sample_march.hip / adjoint_march.hip) on rows longer than

@@ -48,6 +48,8 @@ def main():
         N, dims, vs = args.batch or 4, (128, 128, 64), [8, 8, 32]
     elif args.shape == "3d5":   # cfg-5's volume (rows of 80 voxels: x segments), the paired batch of its 4 volumes
         N, dims, vs = args.batch or 8, (160, 160, 80), [20, 20, 10]
+    elif args.shape == "3d96":  # rows of 96 voxels (flat forward march with PW = 128)
+        N, dims, vs = args.batch or 8, (96, 96, 96), [12, 12, 12]
     else:
         N, dims, vs = args.batch or 32, (256, 256), [16, 16]
     d = len(dims)
