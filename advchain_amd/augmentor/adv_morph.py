@@ -106,6 +106,20 @@ class AdvMorph(AdvTransformBase):
             return t
         return red
 
+    def _chain_opts(self, positions_only=False):
+        """The attributes DemonsCompose reads (adv_morph.py:236-242,461-471) as the operator's options; None = the
+        reference defaults (num_steps=8, smooth_iter=1, sigma=1, scaling and squaring)."""
+        if self.integration_type != 'ss':
+            raise NotImplementedError('integration_type=%r: only scaling and squaring ("ss", the reference default, '
+                                      'adv_morph.py:241) is implemented; the reference\'s Euler branch does not run in 3D '
+                                      '(adv_morph.py:171: range() of a float)' % (self.integration_type,))
+        n, it = int(self.num_steps), int(self.smooth_iter)
+        if n < 1 or it < 1:
+            raise NotImplementedError('num_steps and smooth_iter must be at least 1 (got %d, %d)' % (n, it))
+        if (n, it, float(self.sigma)) == (8, 1, 1.0) and not positions_only:
+            return None
+        return (n, it, float(self.sigma), bool(positions_only))
+
     def _field(self, sign):
         """Un-clamped sampling grid for sign*scale*param, shared between the data / prediction / mask paths of
         one solver step (the reference recomputes the identical field 4x per step)."""
@@ -114,9 +128,10 @@ class AdvMorph(AdvTransformBase):
         p = self.param
         scale = sign * self._scale()
         want_grad = torch.is_grad_enabled() and p.requires_grad
+        opts = self._chain_opts()
         if not self._share_fields:
-            return ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
-        key = (scale,)
+            return ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), opts)
+        key = (scale, opts)
         hit = self._field_cache.get(key)
         if hit is not None and hit[0] is p and hit[1] == p._version and (hit[3] or not want_grad):
             q = hit[2]
@@ -124,11 +139,11 @@ class AdvMorph(AdvTransformBase):
         if ops.PAIR_FIELDS:
             # a solver step warps forward with field(+s) and back with field(-s): integrate both as one batch
             s = self._scale()
-            qp, qm = ops.demons_field_pair(p, s, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
-            self._field_cache[(s,)] = (p, p._version, qp, want_grad)
-            self._field_cache[(-s,)] = (p, p._version, qm, want_grad)
+            qp, qm = ops.demons_field_pair(p, s, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), opts)
+            self._field_cache[(s, opts)] = (p, p._version, qp, want_grad)
+            self._field_cache[(-s, opts)] = (p, p._version, qm, want_grad)
             return self._field_cache[key][2]
-        q = ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
+        q = ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), opts)
         self._field_cache[key] = (p, p._version, q, want_grad)
         return q
 
@@ -145,27 +160,33 @@ class AdvMorph(AdvTransformBase):
         """Clamped sampling grid (N,d,...) for an explicit low-res velocity (adv_morph.py:454-491).
 
         The reference's own (and only) call is ``DemonsCompose(duv=duv, init_deformation_dxy=self.base_grid,
-        smooth=True)`` (adv_morph.py:299-303,322-324,342-343): composition with the IDENTITY grid, which is what the HIP
-        chain implements.  ``init_deformation_dxy`` may therefore be None or the identity grid (``self.base_grid`` itself
-        or a tensor equal to it); a genuinely different initial deformation raises."""
-        if init_deformation_dxy is not None and init_deformation_dxy is not self._base_grid:
-            base = self.base_grid
-            if (tuple(init_deformation_dxy.shape) != tuple(base.shape)
-                    or not torch.equal(init_deformation_dxy.to(base.device), base)):
-                raise NotImplementedError('DemonsCompose: init_deformation_dxy must be the identity grid '
-                                          '(self.base_grid, as in every call of the reference: adv_morph.py:299-303,'
-                                          '322-324,342-343) or None; composing with another initial deformation is not '
-                                          'implemented by the HIP chain')
-        if not smooth:
-            raise NotImplementedError('DemonsCompose: smooth=False is not implemented (every call of the reference passes '
-                                      'smooth=True; adv_morph.py:299-303,322-324,342-343)')
-        if (self.sigma, self.num_steps, self.smooth_iter, self.integration_type) != (1, 8, 1, 'ss'):
-            raise NotImplementedError('DemonsCompose: the HIP chain implements the reference defaults only '
-                                      '(sigma=1, num_steps=8, smooth_iter=1, integration_type="ss"; adv_morph.py:236-242)')
+        smooth=True)`` (adv_morph.py:299-303,322-324,342-343): composition with the IDENTITY grid followed by the
+        smoothing -- the fused HIP chain (``ops.demons_field``), taken whenever ``init_deformation_dxy`` is None, the
+        identity grid itself or a tensor equal to it, and ``smooth`` is true.  Any other initial deformation and
+        ``smooth=False`` take the same chain up to the sampling positions and then the reference's own steps on them
+        (adv_morph.py:474-490), each a HIP operator: ``grid_sample(init, positions, border)``, ``G * (. - id) + id``.
+        ``num_steps``, ``smooth_iter`` and ``sigma`` are honoured on both routes (sigma within the 9-tap window of the
+        kernels, 0.875 <= sigma < 1.125)."""
         if self._tables is None:
             self._tables = bands.upsample_tables(list(self.vector_size), list(self.data_size[2:]), self.device)
-        q = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq())
-        return torch.clamp(q, -1, 1)
+        identity = init_deformation_dxy is None or init_deformation_dxy is self._base_grid
+        if not identity:
+            base = self.base_grid
+            if tuple(init_deformation_dxy.shape) != tuple(base.shape):
+                raise ValueError('DemonsCompose: init_deformation_dxy must have the shape of the sampling grid %s, got %s'
+                                 % (tuple(base.shape), tuple(init_deformation_dxy.shape)))
+            identity = (not init_deformation_dxy.requires_grad) and torch.equal(init_deformation_dxy.to(base.device), base)
+        if identity and smooth:
+            q = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), self._chain_opts())
+            return torch.clamp(q, -1, 1)
+        # general route: positions = integrated offsets + identity (adv_morph.py:464-472), then adv_morph.py:474-490
+        pos = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(),
+                               self._chain_opts(positions_only=True))
+        init = self.base_grid if init_deformation_dxy is None else init_deformation_dxy.to(self.device)
+        comp = ops.grid_sample(init.contiguous(), pos, 'bilinear', 'border')          # applyComposition{2,3}D
+        if smooth:
+            comp = ops.axpy(ops.gauss_smooth(ops.axpy(comp, self.base_grid, -1.0), self.sigma), self.base_grid, 1.0)
+        return torch.clamp(comp, -1, 1)
 
     def get_deformation_displacement_field(self, duv=None):
         # adv_morph.py:339-347

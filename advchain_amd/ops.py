@@ -16,6 +16,25 @@ from .bands import gaussian_weights_1d
 _INTERP = {"bilinear": 0, "trilinear": 0, "linear": 0, "nearest": 1, "bicubic": 2}
 _PAD = {"zeros": 0, "border": 1, "reflection": 2}
 _GAUSS9 = _lib.float_array(gaussian_weights_1d(1.0))
+_GAUSS9_CACHE = {}
+
+
+def gauss9(sigma):
+    """The 9 tap weights of the Gaussian for `sigma` (ctypes array).  The kernels are 9-tap: the reference sizes its
+    window as 2 * int(4 sigma + 0.5) + 1 (adv_morph.py:393-398), which is 9 for 0.875 <= sigma < 1.125 only."""
+    sigma = float(sigma)
+    if sigma == 1.0:
+        return _GAUSS9
+    w = _GAUSS9_CACHE.get(sigma)
+    if w is None:
+        taps = gaussian_weights_1d(sigma)
+        if len(taps) != 9:
+            raise NotImplementedError("Gaussian smoothing with sigma=%g needs a %d-tap window; the HIP kernels are 9-tap "
+                                      "(0.875 <= sigma < 1.125; the reference uses sigma=1, adv_morph.py:236)" % (sigma, len(taps)))
+        if len(_GAUSS9_CACHE) > 16:
+            _GAUSS9_CACHE.clear()
+        w = _GAUSS9_CACHE[sigma] = _lib.float_array(taps)
+    return w
 
 
 def _ptr(t):
@@ -194,7 +213,7 @@ def _persistent_zeros(tag, shape, device):
     return buf
 
 
-def raw_gauss_small_pair(x, scale, adjoint=False):
+def raw_gauss_small_pair(x, scale, adjoint=False, weights=None):
     """Gaussian of the low-resolution planes of a paired field: forward (N,d,..) -> (2N,d,..) = [G(s x); G(-s x)], adjoint
     (2N,d,..) -> (N,d,..) = G(s x[:N]) - G(s x[N:]).  None when the planes are too large for the one-launch kernel."""
     if x[0, 0].numel() > 4096 or not x.is_contiguous():
@@ -204,8 +223,9 @@ def raw_gauss_small_pair(x, scale, adjoint=False):
     n_out = n_in // 2 if adjoint else 2 * n_in
     out = torch.empty((n_out,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
     planes = (n_out if adjoint else n_in) * x.shape[1]
-    _lib.check(_lib.load().advchain_gauss_small_pair(_ptr(x), _ptr(out), planes, nd, _lib.dims_array(x.shape[2:]), _GAUSS9,
-                                                     float(scale), int(bool(adjoint)), _stream()), "gauss_small_pair")
+    _lib.check(_lib.load().advchain_gauss_small_pair(_ptr(x), _ptr(out), planes, nd, _lib.dims_array(x.shape[2:]),
+                                                     weights or _GAUSS9, float(scale), int(bool(adjoint)), _stream()),
+               "gauss_small_pair")
     return out
 
 
@@ -279,10 +299,11 @@ def _halo_2d(disp):
     return 16
 
 
-def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
+def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None, weights=None):
     """Separable 9-tap Gaussian over all spatial axes of x (planes = x.shape[0]*x.shape[1]).  `x` may be a pair of
     tensors (the two halves of a batch, e.g. the gradients of a paired field): the fused x+y launch reads both in place,
-    any other route concatenates them first."""
+    any other route concatenates them first.  `weights`: gauss9(sigma), default sigma = 1."""
+    w9 = weights or _GAUSS9
     x_hi = None
     if isinstance(x, (tuple, list)):
         x, x_hi = x
@@ -298,13 +319,13 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
         x, x_hi = torch.cat([x, x_hi], 0), None
     if post == 0 and pre in (0, 1) and x[0, 0].numel() <= 4096:     # low-resolution grids: all axes in one launch
         out = torch.empty_like(x)
-        _lib.check(lib.advchain_gauss_small(_ptr(x), _ptr(out), planes, nd, dims, _GAUSS9, pre, float(scale), _stream()),
+        _lib.check(lib.advchain_gauss_small(_ptr(x), _ptr(out), planes, nd, dims, w9, pre, float(scale), _stream()),
                    "gauss_small")
         return out
     cur = x
     # x and y in one launch where the shape allows (advchain_gauss_xy); post belongs to the last axis
     out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    rc = lib.advchain_gauss_xy(_ptr(x), _ptr(out), _ptr(aux) if (post == 2 and nd == 2) else None, planes, C, nd, dims, _GAUSS9,
+    rc = lib.advchain_gauss_xy(_ptr(x), _ptr(out), _ptr(aux) if (post == 2 and nd == 2) else None, planes, C, nd, dims, w9,
                                pre, post if nd == 2 else 0, float(scale) if pre == 1 else 1.0, _stream(), _ptr(x_hi),
                                x.shape[0] * x.shape[1])
     if rc == 0:
@@ -312,7 +333,7 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
             return out
         out2 = torch.empty_like(out)
         _lib.check(lib.advchain_gauss_axis(_ptr(out), _ptr(out2), _ptr(aux) if post == 2 else None, planes, C, nd, dims, 0,
-                                           _GAUSS9, 0, post, 1.0, _stream()), "gauss_axis")
+                                           w9, 0, post, 1.0, _stream()), "gauss_axis")
         return out2
     if rc != -2:
         _lib.check(rc, "gauss_xy")
@@ -323,7 +344,7 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None):
         p = pre if i == 0 else 0
         q = post if i == len(axes) - 1 else 0
         _lib.check(lib.advchain_gauss_axis(_ptr(cur), _ptr(out), _ptr(aux) if q == 2 else None, planes, C, nd, dims, ax,
-                                           _GAUSS9, p, q, float(scale) if p == 1 else 1.0, _stream()), "gauss_axis")
+                                           w9, p, q, float(scale) if p == 1 else 1.0, _stream()), "gauss_axis")
         cur = out
     return cur
 
@@ -751,22 +772,31 @@ class _DemonsField(torch.autograd.Function):
     forward:  gauss(scale*v) -> linear upsample -> phi0 = id + u/2^n -> n x (phi <- phi o phi)
               -> pos = (phi_n - phi0) + id -> gauss(border_identity(pos) - id) + id
     The final clamp(-1,1) (adv_morph.py:490, 304-305) is applied by the sampler on load.
-    backward: the hand-written adjoint of the same chain (saved: phi_0..phi_{n-1}, pos)."""
+    backward: the hand-written adjoint of the same chain (saved: phi_0..phi_{n-1}, pos).
+
+    opts = (num_steps, smooth_iter, sigma, positions_only) -- the attributes of AdvMorph the reference reads in
+    DemonsCompose (adv_morph.py:236-242,461-471): defaults (8, 1, 1.0, False).  positions_only returns `pos` itself (the
+    caller composes it with an initial deformation other than the identity and / or skips the final smoothing)."""
 
     @staticmethod
-    def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False):
+    def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False, opts=None):
         vel = _dev(vel, "velocity")
         ctx.pair = bool(pair)
+        n_base, smooth_iter, sigma, pos_only = opts if opts is not None else (8, 1, 1.0, False)
+        w9 = gauss9(sigma)
+        ctx.opts = (int(smooth_iter), w9, bool(pos_only))
         s1 = None
         if pair:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))
-            s1 = raw_gauss_small_pair(vel, scale)         # the negated copy is never materialised
+            s1 = raw_gauss_small_pair(vel, scale, weights=w9)         # the negated copy is never materialised
             if s1 is None:
                 vel = torch.cat([vel, -vel], 0)
         d = vel.shape[1]
         if s1 is None:
-            s1 = raw_gauss(vel, d, pre=1, scale=scale)
+            s1 = raw_gauss(vel, d, pre=1, scale=scale, weights=w9)
+        for _ in range(int(smooth_iter) - 1):      # smooth_iter > 1 (adv_morph.py:386-387): the same window again
+            s1 = raw_gauss(s1, d, weights=w9)
         N = s1.shape[0]
-        n = 8
+        n = int(n_base)
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
             slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
             # pair: the batch is [v; -v] -- the rule is the reference's, over ONE field's batch (both halves agree)
@@ -795,7 +825,7 @@ class _DemonsField(torch.autograd.Function):
         _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
                                                        _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr, _stream()),
                    "expo_chain_fwd")
-        q = raw_gauss(pos, d, pre=2, post=1)
+        q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
         ctx.save_for_backward(pos, phi0, fields)
         ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp, reset=True))
         global _LAST_FIELD_BOUND
@@ -813,8 +843,12 @@ class _DemonsField(torch.autograd.Function):
         scale, tables, inv, d = ctx.cfg
         # pair: one contiguous gradient for the batch [v; -v] (autograd's own route -- two slice_backward zero-fills of
         # the whole batch, two copies and an add per chain -- cost more than the concatenation)
+        smooth_iter, w9, pos_only = ctx.opts
         gq = tuple(_dev(g, "grad") for g in grads) if ctx.pair else _dev(grads[0], "grad")
-        gpos = raw_gauss(gq, d, post=2, aux=pos)          # adjoint of gauss(border_identity(.) - id) + id
+        if pos_only:
+            gpos = torch.cat(gq, 0) if ctx.pair else gq.contiguous()
+        else:
+            gpos = raw_gauss(gq, d, post=2, aux=pos, weights=w9)          # adjoint of gauss(border_identity(.) - id) + id
         g = gpos                                          # d/d phi_n
         ws = _scatter_workspace(gpos.shape[0], gpos.shape[2:], gpos.device) if TILED_SCATTER else None
         # squaring m composes a field whose displacement is ~2^(m-n) of the total: the early steps are sub-voxel and
@@ -840,13 +874,15 @@ class _DemonsField(torch.autograd.Function):
                                                            _lib.dims_array(gpos.shape[2:]), n, _stream()), "expo_chain_bwd")
         # phi0 also enters through '- phi0' (Q1 aliasing): total = g - gpos ; u = (phi0 - id) * 2^n
         gs1 = raw_tp_adjoint(g, tables, gfull2=gpos, scale=inv)
-        gvel = raw_gauss_small_pair(gs1, scale, adjoint=True) if ctx.pair else None
+        for _ in range(smooth_iter - 1):           # (the zero-padded symmetric window is its own adjoint)
+            gs1 = raw_gauss(gs1, d, weights=w9)
+        gvel = raw_gauss_small_pair(gs1, scale, adjoint=True, weights=w9) if ctx.pair else None
         if gvel is None:
-            gvel = raw_gauss(gs1, d, pre=1, scale=scale)
+            gvel = raw_gauss(gs1, d, pre=1, scale=scale, weights=w9)
             if ctx.pair:
                 h = gvel.shape[0] // 2
                 gvel = gvel[:h] - gvel[h:]
-        return gvel, None, None, None, None, None
+        return gvel, None, None, None, None, None, None
 
 
 _LAST_FIELD_BOUND = None
@@ -865,10 +901,13 @@ _WARP_HINTS = _HintCache()      # (device, spatial dims) -> displacement of the 
 
 
 @_on_tensor_device
-def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
-    q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, False)
+    q = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, False, opts)
+    if opts is not None and opts[3]:       # positions only: no bound rides on them (the caller composes them further)
+        _LAST_FIELD_BOUND = None
+        return q
     if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
         rb, idx = _LAST_FIELD_BOUND
         q._advchain_disp = [rb, None, q._version, idx, (str(q.device),) + tuple(q.shape[2:])]
@@ -876,15 +915,36 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
     return q
 
 
+class _GaussSmooth(torch.autograd.Function):
+    """x -> G * x, the zero-padded separable 9-tap Gaussian of every (n, c) plane (depthwise conv of adv_morph.py:377-452);
+    the symmetric window is its own adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, sigma):
+        x = _dev(x, "field")
+        ctx.w9 = gauss9(sigma)
+        return raw_gauss(x, x.shape[1], weights=ctx.w9)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dev(g, "grad")
+        return raw_gauss(g, g.shape[1], weights=ctx.w9), None
+
+
 @_on_tensor_device
-def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None):
+def gauss_smooth(x, sigma=1.0):
+    return _GaussSmooth.apply(x, float(sigma))
+
+
+@_on_tensor_device
+def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     """(field(+scale * vel), field(-scale * vel)): the deformation and its approximate inverse, which one solver step
     always needs together (adv_morph.py:285-331), integrated as ONE batch [v; -v] -- half the launches, each twice the
     size (the 2D kernels of a 32-image batch are too small to fill 256 CUs).  Per sample the arithmetic is that of two
     separate calls: -(s*v) == (-s)*v exactly, so the results are bit-identical to demons_field(vel, +-scale)."""
     global _LAST_FIELD_BOUND
     _LAST_FIELD_BOUND = None
-    qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True)
+    qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True, opts)
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
         qp._advchain_disp = [rb, None, qp._version, idx, (str(qp.device),) + tuple(qp.shape[2:])]

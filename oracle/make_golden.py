@@ -892,6 +892,62 @@ def g9_utils(aug):
     save("g9_utils", out)
 
 
+# ----------------------------------------------------------------------------- G10
+def g10_demons_args(aug):
+    """AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults
+    (adv_morph.py:236-242,454-491): num_steps, smooth_iter, sigma (within the 9-tap window), smooth=False and an initial
+    deformation other than the identity.  Per case: the velocity, the returned grid, d(sum(grid * w))/d(velocity) and, for
+    the initial deformation, d/d(init)."""
+    out, meta = {}, {}
+    shapes = {
+        "2d": dict(spatial_dims=2, data_size=[2, 1, 24, 40], vector_size=[3, 5]),
+        "3d": dict(spatial_dims=3, data_size=[1, 1, 12, 10, 14], vector_size=[3, 2, 4]),
+    }
+    variants = {
+        "default": dict(),
+        "steps6": dict(num_steps=6),
+        "steps3": dict(num_steps=3),
+        "iter2": dict(smooth_iter=2),
+        "sigma09": dict(sigma=0.9),
+        "sigma11_iter2_steps7": dict(sigma=1.1, smooth_iter=2, num_steps=7),
+        "nosmooth": dict(smooth=False),
+        "init": dict(init=True),
+        "init_nosmooth_steps5": dict(init=True, smooth=False, num_steps=5),
+    }
+    i = 0
+    for stag, c in shapes.items():
+        for vtag, v in variants.items():
+            i += 1
+            cfg = dict(epsilon=1.5, data_size=c["data_size"], vector_size=c["vector_size"])
+            t = aug.AdvMorph(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
+            torch.manual_seed(4100 + i)
+            t.init_parameters()
+            for a in ("num_steps", "smooth_iter", "sigma"):
+                if a in v:
+                    setattr(t, a, v[a])
+            p = t.unit_normalize(rand(tuple(t.param.shape), 4200 + i)).detach().requires_grad_(True)
+            base = t.base_grid.detach().clone()
+            if v.get("init"):      # a smooth deformation of the identity that stays inside [-1, 1]
+                d = c["spatial_dims"]
+                low = rand((c["data_size"][0], d) + tuple([4] * d), 4300 + i)
+                bump = F.interpolate(low, size=tuple(c["data_size"][2:]), mode="bilinear" if d == 2 else "trilinear",
+                                     align_corners=True)
+                init = (0.9 * base + 0.08 * bump).contiguous().requires_grad_(True)
+            else:
+                init = base
+            w = rand(tuple(base.shape), 4400 + i)
+            dxy = t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=init, smooth=v.get("smooth", True))
+            (dxy * w).sum().backward()
+            key = "%s_%s_" % (stag, vtag)
+            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, attrs={a: v[a] for a in ("num_steps", "smooth_iter", "sigma") if a in v},
+                             smooth=v.get("smooth", True), init=bool(v.get("init")))
+            out.update({key + "param": p.detach(), key + "w": w, key + "dxy": dxy.detach(), key + "grad_param": p.grad.clone()})
+            if v.get("init"):
+                out.update({key + "init": init.detach(), key + "grad_init": init.grad.clone()})
+    out["meta"] = meta
+    save("g10_demons_args", out)
+
+
 ONLY = []
 
 
@@ -927,6 +983,8 @@ def main():
         save("g6s_sensitivity", dict(meta=merged))
     if want("g7"):
         g7_misc(aug)
+    if want("g10"):
+        g10_demons_args(aug)
     if want("g8"):
         g8_kinks(aug)
     if want("g9"):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import advchain_oracle as O
 from tests import cpu_backend
 from tests.helpers import Fixture, counted_torch_seed, fixture_model, make_model, maxdiff, rand, smooth_data
 
@@ -84,10 +85,19 @@ def test_morph_and_affine_host_classes(cpu_ops):
         # the reference's own call form (adv_morph.py:342-343): the identity grid as initial deformation, positional
         assert maxdiff(t.DemonsCompose(t.epsilon * p, t.base_grid, smooth=True), dxy) == 0
         assert maxdiff(t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=t.base_grid.clone()), dxy) == 0
+        # another initial deformation / no final smoothing: the general route (adv_morph.py:474-490 on the chain's positions)
+        dims = m["config"]["data_size"][2:]
+        other = 0.5 * t.base_grid
+        assert maxdiff(t.DemonsCompose(t.epsilon * p, other, smooth=True),
+                       O.demons_compose(t.epsilon * p, dims, init=other)) < 2e-6
+        assert maxdiff(t.DemonsCompose(t.epsilon * p, t.base_grid, smooth=False),
+                       O.demons_compose(t.epsilon * p, dims, smooth=False)) < 2e-6
+        with pytest.raises(ValueError):
+            t.DemonsCompose(t.epsilon * p, t.base_grid[:, :1])
+        t.integration_type = 'euler'
         with pytest.raises(NotImplementedError):
-            t.DemonsCompose(t.epsilon * p, 0.5 * t.base_grid, smooth=True)
-        with pytest.raises(NotImplementedError):
-            t.DemonsCompose(t.epsilon * p, t.base_grid, smooth=False)
+            t.DemonsCompose(t.epsilon * p, t.base_grid)
+        t.integration_type = 'ss'
         o = t.forward(data)
         (o * w).sum().backward()
         assert maxdiff(o, fx.t(key + "forward")) < 2e-6

@@ -919,6 +919,42 @@ def test_demons_field_golden():
             assert err < (3e-3 if big else 1e-4), (key, sgn, err)
 
 
+def test_demons_compose_arguments_golden():
+    """G10: AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults --
+    num_steps, smooth_iter, sigma (9-tap window), smooth=False, an initial deformation other than the identity
+    (adv_morph.py:236-242,454-491) -- against the reference's grids and gradients; forward() / _field honour the same
+    attributes; what the kernels cannot do (another window size, Euler integration) raises."""
+    from advchain_amd.augmentor import AdvMorph
+    fx = Fixture("g10_demons_args")
+    for key, m in fx.json().items():
+        t = AdvMorph(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
+        t.init_parameters()
+        for a, v in m["attrs"].items():
+            setattr(t, a, v)
+        p = fx.t(key + "param", DEV).requires_grad_(True)
+        t.param = p
+        init = fx.t(key + "init", DEV).requires_grad_(True) if m["init"] else t.base_grid
+        dxy = t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=init, smooth=m["smooth"])
+        assert maxdiff(dxy.cpu(), fx.t(key + "dxy")) < TOL, key
+        (dxy * fx.t(key + "w", DEV)).sum().backward()
+        ref = fx.t(key + "grad_param")
+        assert maxdiff(p.grad.cpu(), ref) < 2e-4 * max(1.0, float(ref.abs().max())), key
+        if m["init"]:
+            assert maxdiff(init.grad.cpu(), fx.t(key + "grad_init")) < 5e-5, key
+        elif m["smooth"]:      # the fused route of forward(): same attributes, same grid
+            with torch.no_grad():
+                q = torch.clamp(t._field(1.0), -1, 1)
+            assert maxdiff(q.cpu(), fx.t(key + "dxy")) < TOL, key
+    t = AdvMorph(spatial_dims=2, config_dict=dict(epsilon=1.5, data_size=[2, 1, 24, 40], vector_size=[3, 5]), device=torch.device(DEV))
+    t.init_parameters()
+    t.sigma = 2.0
+    with pytest.raises(NotImplementedError):
+        t.DemonsCompose(duv=t.param)
+    t.sigma, t.integration_type = 1, 'euler'
+    with pytest.raises(NotImplementedError):
+        t.DemonsCompose(duv=t.param)
+
+
 def test_affine_golden():
     from advchain_amd.augmentor import AdvAffine
     fx = Fixture("g4_affine")
