@@ -63,10 +63,19 @@ ENTRIES["advchain_affine_warp_fwd"] = ([r"k_affine_warp_fwd", r"k_affine_box_fwd
 # the theta kernel (every backward call launches exactly one k_reduce_partials)
 ENTRIES["advchain_affine_warp_bwd"] = ([r"k_affine_warp_bwd<", r"k_affine_gather_bwd<", r"k_affine_geometry<", r"k_reduce_partials",
                                         r"k_affine_box_gtheta<", r"k_affine_box_gin<"], r"k_reduce_partials")
-WIDE = re.compile(r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
+# round 3, second half: rows of 68 .. 128 voxels -- flat forward march, flat march scatter of the self-composition (the wide
+# adjoint march keeps the name k_adjoint_march, with a seventh template argument)
+ENTRIES["advchain_compose_self_fwd"] = (ENTRIES["advchain_compose_self_fwd"][0] + [r"k_sample_march_flat<3, true"],
+                                        ENTRIES["advchain_compose_self_fwd"][1] + r"|k_sample_march_flat<3, true")
+ENTRIES["advchain_grid_sample_fwd"] = (ENTRIES["advchain_grid_sample_fwd"][0] + [r"k_sample_march_flat<\d, false"],
+                                       ENTRIES["advchain_grid_sample_fwd"][1] + r"|k_sample_march_flat<\d, false")
+ENTRIES["advchain_compose_self_bwd"] = (ENTRIES["advchain_compose_self_bwd"][0] + [r"k_scatter_march3d_flat<"],
+                                        ENTRIES["advchain_compose_self_bwd"][1] + r"|k_scatter_march3d_flat<")
+WIDE = re.compile(r"k_sample_march_flat<3, true|"r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
                   r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4|k_affine_box_fwd|k_affine_box_gtheta|"
                   r"k_scatter_march3d_wide|k_march_rowmax64|k_sample_ring")   # 16 B / lane
-MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
+MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7,
+         r"k_sample_march_flat<1, false": 1.41, r"k_sample_march_flat<4, false": 1.7}   # image 16 B/lane + 3 grid channels 4 B/lane
 
 
 def read_factor(kernel):
