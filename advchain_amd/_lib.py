@@ -31,6 +31,7 @@ PROTOTYPES = {
     "advchain_bias_field_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _F, _I, _F, _P]),
     "advchain_bias_field_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _F, _I, _F, _P]),
     "advchain_gauss_axis": (_I, [_P, _P, _P, _L, _L, _I, _P, _I, _P, _I, _I, _F, _P]),
+    "advchain_gauss_axis_generic": (_I, [_P, _P, _L, _I, _P, _I, _P, _I, _F, _P]),
     "advchain_max_displacement": (_I, [_P, _P, _L, _I, _P, _P]),
     "advchain_grid_sample_bicubic2d_fwd": (_I, [_P, _P, _P, _L, _L, _P, _P, _I, _P]),
     "advchain_grid_sample_bicubic2d_bwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P]),

@@ -120,6 +120,10 @@ class AdvMorph(AdvTransformBase):
             return None
         return (n, it, float(self.sigma), bool(positions_only))
 
+    def _nine_taps(self):
+        """The reference's window rule (adv_morph.py:393-398) gives the 9 taps of the fused kernels for this sigma."""
+        return 2 * int(4 * float(self.sigma) + 0.5) + 1 == 9
+
     def _field(self, sign):
         """Un-clamped sampling grid for sign*scale*param, shared between the data / prediction / mask paths of
         one solver step (the reference recomputes the identical field 4x per step)."""
@@ -129,6 +133,8 @@ class AdvMorph(AdvTransformBase):
         scale = sign * self._scale()
         want_grad = torch.is_grad_enabled() and p.requires_grad
         opts = self._chain_opts()
+        if not self._nine_taps():      # another Gaussian window: the general route of DemonsCompose (no pairing, no bound)
+            return self.DemonsCompose(duv=scale * p) if want_grad else self.DemonsCompose(duv=scale * p.detach()).detach()
         if not self._share_fields:
             return ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), opts)
         key = (scale, opts)
@@ -165,8 +171,8 @@ class AdvMorph(AdvTransformBase):
         identity grid itself or a tensor equal to it, and ``smooth`` is true.  Any other initial deformation and
         ``smooth=False`` take the same chain up to the sampling positions and then the reference's own steps on them
         (adv_morph.py:474-490), each a HIP operator: ``grid_sample(init, positions, border)``, ``G * (. - id) + id``.
-        ``num_steps``, ``smooth_iter`` and ``sigma`` are honoured on both routes (sigma within the 9-tap window of the
-        kernels, 0.875 <= sigma < 1.125)."""
+        ``num_steps``, ``smooth_iter`` and ``sigma`` are honoured on both routes; a sigma whose window is not 9 taps
+        (outside 0.875 <= sigma < 1.125, adv_morph.py:393-398) takes the general route with the plain K-tap Gaussian."""
         if self._tables is None:
             self._tables = bands.upsample_tables(list(self.vector_size), list(self.data_size[2:]), self.device)
         identity = init_deformation_dxy is None or init_deformation_dxy is self._base_grid
@@ -176,7 +182,7 @@ class AdvMorph(AdvTransformBase):
                 raise ValueError('DemonsCompose: init_deformation_dxy must have the shape of the sampling grid %s, got %s'
                                  % (tuple(base.shape), tuple(init_deformation_dxy.shape)))
             identity = (not init_deformation_dxy.requires_grad) and torch.equal(init_deformation_dxy.to(base.device), base)
-        if identity and smooth:
+        if identity and smooth and self._nine_taps():
             q = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), self._chain_opts())
             return torch.clamp(q, -1, 1)
         # general route: positions = integrated offsets + identity (adv_morph.py:464-472), then adv_morph.py:474-490

@@ -1044,6 +1044,54 @@ int advchain_bias_field_bwd(const float* cp, const float* data, const float* gra
   return ADVCHAIN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Any odd window (sigma outside the 9-tap range of the kernels above: adv_morph.py:393-398 sizes the window as
+// 2 * int(4 sigma + 0.5) + 1).  The reference never leaves sigma = 1; this is the plain per-voxel form -- one output per
+// thread, taps in ascending order, zero padding -- for the callers that do.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGenericMaxTaps = 129;
+struct GaussWN { float w[kGenericMaxTaps]; };
+
+namespace advchain {
+__global__ void __launch_bounds__(kBlock) k_gauss_axis_generic(const float* __restrict__ in, float* __restrict__ out, int64_t total,
+                                                               Dims d, int axis, GaussWN gw, int ntaps, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= total) return;
+  const int V = (int)d.voxels();
+  const int v = (int)(i % V);
+  const int x = v % d.s2, y = (v / d.s2) % d.s1, z = v / (d.s2 * d.s1);
+  const int S = axis == 2 ? d.s2 : (axis == 1 ? d.s1 : d.s0);
+  const int c = axis == 2 ? x : (axis == 1 ? y : z);
+  const int stride = axis == 2 ? 1 : (axis == 1 ? d.s2 : d.s1 * d.s2);
+  const int R = ntaps / 2;
+  const float* p = in + (i - (int64_t)c * stride);
+  float acc = 0.f;
+  for (int t = 0; t < ntaps; ++t) {
+    const int q = c + t - R;
+    if (q >= 0 && q < S) acc = fmaf(gw.w[t], p[(int64_t)q * stride] * scale, acc);
+  }
+  out[i] = acc;
+}
+}  // namespace advchain
+
+int advchain_gauss_axis_generic(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims, int axis,
+                                const float* weights, int ntaps, float scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && in != out && weights, "gauss_axis_generic: null/aliased pointer");
+  ADVCHAIN_CHECK_ARG(fdims_ok(ndim, dims), "gauss_axis_generic: bad dims");
+  ADVCHAIN_CHECK_ARG(axis >= 0 && axis < 3, "gauss_axis_generic: bad axis");
+  ADVCHAIN_CHECK_ARG(ntaps >= 1 && ntaps <= kGenericMaxTaps && (ntaps & 1) == 1, "gauss_axis_generic: the window must have 1..129 taps, odd");
+  const Dims d = fmake_dims(ndim, dims);
+  ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "gauss_axis_generic: volume too large");
+  const int64_t total = planes * d.voxels();
+  if (total == 0) return ADVCHAIN_OK;
+  GaussWN gw;
+  for (int k = 0; k < ntaps; ++k) gw.w[k] = weights[k];
+  hipLaunchKernelGGL(advchain::k_gauss_axis_generic, dim3(advchain_blocks(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, in, out,
+                     total, d, axis, gw, ntaps, scale);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
 // weights: 9 taps (sigma = 1 -> radius 4).  axis is 0..2 of the (s0,s1,s2) view (2D: s0 == 1).
 int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t planes, int64_t C, int ndim,
                         const int64_t* dims, int axis, const float* weights9, int pre, int post, float scale,

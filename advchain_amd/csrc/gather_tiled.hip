@@ -273,7 +273,8 @@ static bool march_forward_pays(bool self, int64_t C, const Dims& d, int hint) {
   static const bool always = getenv("ADVCHAIN_FWD_MARCH_ALWAYS") != nullptr;   // A/B knob: the round-2 policy before the hint
   if (always) return true;
   static const bool no_flat = getenv("ADVCHAIN_NO_FLAT_FWD") != nullptr;   // A/B knob
-  if (d.s2 > 64 && d.s2 <= 128 && !no_flat) return hint <= 1;   // lane <-> flat voxel (k_sample_march_flat): no idle lanes
+  static const int flat_hint_max = getenv("ADVCHAIN_FLAT_FWD_HINT_MAX") ? atoi(getenv("ADVCHAIN_FLAT_FWD_HINT_MAX")) : 1;   // tuning knob
+  if (d.s2 > 64 && d.s2 <= 128 && !no_flat) return hint <= flat_hint_max;   // lane <-> flat voxel (k_sample_march_flat): no idle lanes
   if (d.s2 > 64) return !self && C == 4 && hint <= 1;
   return hint <= 1;
 }

@@ -19,18 +19,24 @@ _GAUSS9 = _lib.float_array(gaussian_weights_1d(1.0))
 _GAUSS9_CACHE = {}
 
 
+GENERIC_MAX_TAPS = 129
+
+
 def gauss9(sigma):
-    """The 9 tap weights of the Gaussian for `sigma` (ctypes array).  The kernels are 9-tap: the reference sizes its
-    window as 2 * int(4 sigma + 0.5) + 1 (adv_morph.py:393-398), which is 9 for 0.875 <= sigma < 1.125 only."""
+    """The tap weights of the Gaussian for `sigma` (ctypes array).  The reference sizes its window as
+    2 * int(4 sigma + 0.5) + 1 taps (adv_morph.py:393-398): 9 for 0.875 <= sigma < 1.125 -- the fast kernels; any other
+    window runs advchain_gauss_axis_generic (raw_gauss; no fused prologue / epilogue there)."""
     sigma = float(sigma)
     if sigma == 1.0:
         return _GAUSS9
     w = _GAUSS9_CACHE.get(sigma)
     if w is None:
+        if not sigma > 0.0:
+            raise ValueError("Gaussian smoothing needs sigma > 0, got %r" % (sigma,))
         taps = gaussian_weights_1d(sigma)
-        if len(taps) != 9:
-            raise NotImplementedError("Gaussian smoothing with sigma=%g needs a %d-tap window; the HIP kernels are 9-tap "
-                                      "(0.875 <= sigma < 1.125; the reference uses sigma=1, adv_morph.py:236)" % (sigma, len(taps)))
+        if len(taps) > GENERIC_MAX_TAPS:
+            raise NotImplementedError("Gaussian smoothing with sigma=%g needs a %d-tap window (at most %d)"
+                                      % (sigma, len(taps), GENERIC_MAX_TAPS))
         if len(_GAUSS9_CACHE) > 16:
             _GAUSS9_CACHE.clear()
         w = _GAUSS9_CACHE[sigma] = _lib.float_array(taps)
@@ -216,7 +222,7 @@ def _persistent_zeros(tag, shape, device):
 def raw_gauss_small_pair(x, scale, adjoint=False, weights=None):
     """Gaussian of the low-resolution planes of a paired field: forward (N,d,..) -> (2N,d,..) = [G(s x); G(-s x)], adjoint
     (2N,d,..) -> (N,d,..) = G(s x[:N]) - G(s x[N:]).  None when the planes are too large for the one-launch kernel."""
-    if x[0, 0].numel() > 4096 or not x.is_contiguous():
+    if x[0, 0].numel() > 4096 or not x.is_contiguous() or (weights is not None and len(weights) != 9):
         return None
     nd = x.dim() - 2
     n_in = x.shape[0]
@@ -315,6 +321,18 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None, weights=None):
     dims = _lib.dims_array(x.shape[2:])
     axes = [2, 1, 0][:nd]  # innermost first (padded 3-axis numbering)
     lib = _lib.load()
+    if len(w9) != 9:      # another window: the plain per-axis kernel (adv_morph.py:393-398 with sigma outside [0.875, 1.125))
+        if post != 0 or pre not in (0, 1):
+            raise NotImplementedError("the fused prologue / epilogue of the Gaussian exists for the 9-tap window only")
+        cur = torch.cat([x, x_hi], 0) if x_hi is not None else x
+        cur = cur if cur.is_contiguous() else cur.contiguous()
+        for i, ax in enumerate(axes):
+            out = torch.empty_like(cur)
+            _lib.check(lib.advchain_gauss_axis_generic(_ptr(cur), _ptr(out), planes, nd, dims, ax, w9, len(w9),
+                                                       float(scale) if (pre == 1 and i == 0) else 1.0, _stream()),
+                       "gauss_axis_generic")
+            cur = out
+        return cur
     if x_hi is not None and (x[0, 0].numel() <= 4096 or not (x.is_contiguous() and x_hi.is_contiguous())):
         x, x_hi = torch.cat([x, x_hi], 0), None
     if post == 0 and pre in (0, 1) and x[0, 0].numel() <= 4096:     # low-resolution grids: all axes in one launch
@@ -784,6 +802,8 @@ class _DemonsField(torch.autograd.Function):
         ctx.pair = bool(pair)
         n_base, smooth_iter, sigma, pos_only = opts if opts is not None else (8, 1, 1.0, False)
         w9 = gauss9(sigma)
+        if len(w9) != 9 and not pos_only:
+            raise NotImplementedError("the fused final smoothing exists for the 9-tap window only: ask for the positions")
         ctx.opts = (int(smooth_iter), w9, bool(pos_only))
         s1 = None
         if pair:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))

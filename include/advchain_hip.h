@@ -222,6 +222,12 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
                         const int64_t* dims, int axis, const float* weights9_host, int pre, int post, float scale,
                         void* stream);
 
+/* The same convolution with ANY odd window (host pointer weights[ntaps], 1 <= ntaps <= 129): the reference sizes its window
+ * as 2 * int(4 sigma + 0.5) + 1 taps (adv_morph.py:393-398), 9 only for 0.875 <= sigma < 1.125; out = G_axis * (scale * in),
+ * zero padding, no prologue / epilogue.  Plain per-voxel form (the reference never leaves sigma = 1).                       */
+int advchain_gauss_axis_generic(const float* in, float* out, int64_t planes, int ndim, const int64_t* dims, int axis,
+                                const float* weights_host, int ntaps, float scale, void* stream);
+
 /* x and y passes of the Gaussian above in ONE launch (LDS tile of whole rows): one read and one write of the tensor
  * instead of two each; the same sums in the same tap order as the two per-axis calls (results agree to a few ulp).  post != 0 only when y is the last axis (ndim == 2).
  * Returns -2 (unsupported, no error text) for shapes it does not take (rows not a multiple of 4 or longer than 512, unaligned

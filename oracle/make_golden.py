@@ -895,7 +895,7 @@ def g9_utils(aug):
 # ----------------------------------------------------------------------------- G10
 def g10_demons_args(aug):
     """AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults
-    (adv_morph.py:236-242,454-491): num_steps, smooth_iter, sigma (within the 9-tap window), smooth=False and an initial
+    (adv_morph.py:236-242,454-491): num_steps, smooth_iter, sigma (9-tap and other windows), smooth=False and an initial
     deformation other than the identity.  Per case: the velocity, the returned grid, d(sum(grid * w))/d(velocity) and, for
     the initial deformation, d/d(init)."""
     out, meta = {}, {}
@@ -913,6 +913,9 @@ def g10_demons_args(aug):
         "nosmooth": dict(smooth=False),
         "init": dict(init=True),
         "init_nosmooth_steps5": dict(init=True, smooth=False, num_steps=5),
+        # windows other than 9 taps (adv_morph.py:393-398: 2 * int(4 sigma + 0.5) + 1 = 17 / 5)
+        "sigma2": dict(sigma=2.0),
+        "sigma05_init": dict(sigma=0.5, init=True),
     }
     i = 0
     for stag, c in shapes.items():

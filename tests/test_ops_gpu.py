@@ -921,9 +921,10 @@ def test_demons_field_golden():
 
 def test_demons_compose_arguments_golden():
     """G10: AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults --
-    num_steps, smooth_iter, sigma (9-tap window), smooth=False, an initial deformation other than the identity
-    (adv_morph.py:236-242,454-491) -- against the reference's grids and gradients; forward() / _field honour the same
-    attributes; what the kernels cannot do (another window size, Euler integration) raises."""
+    num_steps, smooth_iter, sigma (the 9-tap window of the fused kernels and others: 5 / 17 taps through the plain K-tap
+    Gaussian), smooth=False, an initial deformation other than the identity (adv_morph.py:236-242,454-491) -- against the
+    reference's grids and gradients; forward() / _field honour the same attributes; what is not implemented (Euler
+    integration, windows beyond 129 taps) raises."""
     from advchain_amd.augmentor import AdvMorph
     fx = Fixture("g10_demons_args")
     for key, m in fx.json().items():
@@ -940,14 +941,15 @@ def test_demons_compose_arguments_golden():
         ref = fx.t(key + "grad_param")
         assert maxdiff(p.grad.cpu(), ref) < 2e-4 * max(1.0, float(ref.abs().max())), key
         if m["init"]:
-            assert maxdiff(init.grad.cpu(), fx.t(key + "grad_init")) < 5e-5, key
+            gi = fx.t(key + "grad_init")       # (a scatter of the upstream gradient: border cells collect many deposits)
+            assert maxdiff(init.grad.cpu(), gi) < 5e-5 * max(1.0, float(gi.abs().max())), key
         elif m["smooth"]:      # the fused route of forward(): same attributes, same grid
             with torch.no_grad():
                 q = torch.clamp(t._field(1.0), -1, 1)
             assert maxdiff(q.cpu(), fx.t(key + "dxy")) < TOL, key
     t = AdvMorph(spatial_dims=2, config_dict=dict(epsilon=1.5, data_size=[2, 1, 24, 40], vector_size=[3, 5]), device=torch.device(DEV))
     t.init_parameters()
-    t.sigma = 2.0
+    t.sigma = 40.0                      # a 321-tap window: beyond the generic kernel's 129
     with pytest.raises(NotImplementedError):
         t.DemonsCompose(duv=t.param)
     t.sigma, t.integration_type = 1, 'euler'
