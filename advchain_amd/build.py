@@ -17,6 +17,20 @@ LIB_PATH = os.path.join(CSRC, "libadvchain_hip.so")
 ARCH = "gfx950"
 
 
+# Per-source compiler flags (measured, DESIGN.md lesson 42).  clang's SLP vectoriser packs pairs of independent fp32 operations
+# into v_pk_fma / v_pk_mul / v_pk_add: no faster per flop on gfx950 (tools/microbench/valubench: 4.85 clk against 2 x 2.6),
+# but the operands must sit in adjacent register pairs -- v_mov / v_pk_mov shuffles and, in the marching adjoint, 228 instead
+# of 152 VGPRs.  Off where the A/B says so (3D marching adjoint -5..-16 %, 2D gather form -3..-8 %, Gaussian passes -7 %);
+# the forward samplers and the scatters keep it (2D squaring forward +49 % without).
+PER_FILE_FLAGS = {
+    "adjoint_march.hip": ["-fno-slp-vectorize"],
+    "adjoint_gather.hip": ["-fno-slp-vectorize"],
+    "fields.hip": ["-fno-slp-vectorize"],
+}
+if os.environ.get("ADVCHAIN_BUILD_SLP_EVERYWHERE"):     # A/B knob: the compiler default for every source
+    PER_FILE_FLAGS = {}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
@@ -62,7 +76,7 @@ def build_library(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            jobs.append((hipcc, src, obj, flags, verbose))
+            jobs.append((hipcc, src, obj, flags + PER_FILE_FLAGS.get(os.path.basename(src), []), verbose))
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
         for src, rc, log in pool.map(_compile_one, jobs):
             if rc != 0:

@@ -27,6 +27,7 @@
 // measure it in the forward).  Shapes outside the fast form (rows longer than 64 voxels, rows not a multiple of 4,
 // misaligned bases) return ADVCHAIN_ERR_UNSUPPORTED and the caller keeps the tile kernel of adjoint_gather.hip.
 #include <stdlib.h>
+#include <type_traits>
 #include "sampler_common.h"
 
 namespace advchain {
@@ -54,8 +55,15 @@ struct MarchCfg {
   static constexpr int TY = WIDE ? 3 * RPW : NW * RPW;
   static constexpr int R = TY + 2;                              // staged rows per plane (one halo row each side)
   static constexpr int NT = NW * 64;
-  static constexpr int PITCH = WIDE ? kWidePW + 8 : 72;         // 4 zeros | 64 (80) voxels | 4 zeros
-  static constexpr int QPR = (PITCH - 8) / 4;                   // 16-byte staging items per row
+  // 4 zeros | 64 (80) voxels; the 4 zeros to the RIGHT of a row are the left zeros of the next row in memory (every staged
+  // row of every slot is followed by another one; the last one by a 4-float pad): 68 instead of 72 floats per row is what lets
+  // three workgroups of the self-composition share a CU's 160 KiB (53 KiB each)
+#ifdef ADVCHAIN_MARCH_PAD8      // A/B build: rows with their own right zeros (72 / 88 floats)
+  static constexpr int PITCH = WIDE ? kWidePW + 8 : 72;
+#else
+  static constexpr int PITCH = WIDE ? kWidePW + 4 : 68;
+#endif
+  static constexpr int QPR = WIDE ? kWidePW / 4 : 16;           // 16-byte staging items per row
   static_assert(!WIDE || NW == 4, "wide form: three A waves and one B wave");
   static constexpr bool HAS_IMG = GG && !SELF;
   static constexpr int RING_CH = SELF ? 3 : (HAS_IMG ? C : 0);  // planes z-1..z+1 are needed: 4-slot ring
@@ -65,8 +73,11 @@ struct MarchCfg {
   static constexpr int NA = SELF ? 3 : C + (GG ? 3 : 0);        // arrays written per step (grad_in channels, grad_grid)
   static constexpr int NA_ROUND = NA > 2 ? 2 : NA;              // arrays transposed per round
   static constexpr int TRW = NA_ROUND * RPW * 64;               // transposition scratch per wave (floats)
-  static constexpr size_t LDS = (size_t)(4 * PS + 2 * LS + NW * TRW) * sizeof(float);
-  static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF && RPW == 1 ? (NW == 8 ? 4 : 3) : 2);   // per SIMD: 128 / 168 / 256 VGPRs (512-thread blocks: 2 waves per SIMD each)
+  static constexpr int ROWS_END = 4 * PS + 2 * LS + 4;          // staged rows, then the right zeros of the last one
+  static constexpr size_t LDS = (size_t)(ROWS_END + NW * TRW) * sizeof(float);
+  // per SIMD: 128 / 168 / 256 VGPRs (512-thread blocks: 2 waves per SIMD each).  Without the SLP vectoriser (build.py) the
+  // self-composition needs 152: three workgroups a CU
+  static constexpr int MIN_WAVES = (C == 1) ? 4 : (SELF ? (RPW == 1 && NW == 8 ? 4 : 3) : 2);
   static_assert(R * QPR <= NT, "one staging item (4 voxels of one row, all channels) per thread");
   static_assert(!SELF || C == 3, "the self-composition carries 3 channels");
 };
@@ -85,7 +96,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   extern __shared__ float lds[];
   float* const ring = lds;                       // [slot 4][RC][R][P]
   float* const late = lds + 4 * PS;              // [slot 2][LC][R][P]
-  float* const trbuf = lds + 4 * PS + 2 * LS;    // [wave][TRW]
+  float* const trbuf = lds + G::ROWS_END;        // [wave][TRW]
   const int V = (int)d.voxels();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // workgroup L runs on XCD L % 8 (observed dispatch order; speed only): give every XCD a contiguous run of tiles, so
@@ -111,10 +122,8 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   const int plane_stride = d.s1 * d.s2;
 
   // ---- the zero columns of every staged row (never written again)
-  for (int e = threadIdx.x; e < (4 * RC + 2 * LC) * R * 2; e += G::NT) {
-    const int row = e >> 1, side = e & 1;
-    *reinterpret_cast<float4*>(lds + row * P + (side ? P - 4 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int row = threadIdx.x; row <= (4 * RC + 2 * LC) * R; row += G::NT)      // (the last one: the pad behind the rows)
+    *reinterpret_cast<float4*>(lds + row * P) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- staging item of this thread: 4 consecutive x of staged row r_st, every channel
   const bool has_item = threadIdx.x < R * G::QPR;
@@ -275,7 +284,13 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     }
   };
 
-  for (int zp = za - 1; zp <= zb; ++zp) {
+  // One marching step.  The three planes of partial sums ROTATE through their register sets instead of shifting down one slot
+  // per step (the shift was 36 moves + 18 zero-fills per step, copied through temporaries by the register allocator: 125
+  // v_mov of the 858 VALU instructions of a step): plane p lives in slot (p - (za - 1)) mod 3, and the loop below runs
+  // three copies of the step whose slot indices are compile-time constants (ROT = (zp - (za - 1)) mod 3).
+  auto step = [&](const int zp, auto rot_tag) {
+    constexpr int ROT = decltype(rot_tag)::value;
+    constexpr int SL[3] = {(ROT + 2) % 3, ROT, (ROT + 1) % 3};      // slots of the target planes zp-1, zp, zp+1
     // ---- loads of the next planes go out first: they land while this plane is being worked on
     const bool more_ring = zp + 2 <= zb && !(flags & kDbgNoStage), more_late = zp + 1 <= zb && !(flags & kDbgNoStage);
     if (has_item) {
@@ -291,77 +306,70 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     const float fzp = (float)zp;
     const float zlo = -fzp, zhi = (float)(d.s0 - 1) - fzp;
 
-    // ---- phase B: deposits of sample plane zp on the target planes zp-1, zp, zp+1
-    if (zp >= 0 && zp < d.s0 && !(flags & kDbgNoB)) {
-#pragma unroll
-      for (int i = 0; i < RPW + 2; ++i) {
-        const int r = i;                        // staged row of the sample past the lane's own_row0; sample y = y0 - 1 + own_row0 + r
-        float fx = fbase[(0 * R + r) * P];
-        float fy = fbase[(1 * R + r) * P];
-        float fz = fbase[(2 * R + r) * P];
-        float go[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
-        if (CLIP) {
-          const float ys = (float)(y0 - 1 + own_row0 + r);
-          fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
-          fy = __builtin_amdgcn_fmed3f(fy, -ys, (float)(d.s1 - 1) - ys);
-          fz = __builtin_amdgcn_fmed3f(fz, zlo, zhi);
-        }
-        float tx[3], tyv[3], tzv[3];
-        tx[0] = fmaxf(0.f, -fx); tx[2] = fmaxf(0.f, fx); tx[1] = (1.f - tx[0]) - tx[2];
-        if (WIDE) tx[0] = kill_left ? 0.f : tx[0];
-        tyv[0] = fmaxf(0.f, -fy); tyv[2] = fmaxf(0.f, fy); tyv[1] = (1.f - tyv[0]) - tyv[2];
-        tzv[0] = fmaxf(0.f, -fz); tzv[2] = fmaxf(0.f, fz); tzv[1] = (1.f - tzv[0]) - tzv[2];
-#pragma unroll
-        for (int o = 0; o < RPW; ++o) {
-          const int k = o + 1 - i;              // output row minus sample row (compile time)
-          if (k < -1 || k > 1) continue;
-          const float wy = tyv[k + 1];
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const float a = go[c] * wy;
-#pragma unroll
-            for (int kz = 0; kz < 3; ++kz) {
-              const float b = a * tzv[kz];
-#pragma unroll
-              for (int kx = 0; kx < 3; ++kx) acc[o][kz][c][kx] = fmaf(b, tx[kx], acc[o][kz][c][kx]);
-            }
-          }
-        }
-      }
-    }
-
     float vals[G::NA][RPW];
     float* dst[G::NA];
     int row_base[G::NA];
     bool ok[G::NA];
-    // ---- target plane zp-1 has now seen its three sample planes: fold over x
     const int zt = zp - 1;
     const bool fin = zt >= za && zt < zb;
+    {
+      // ---- phase B: deposits of sample plane zp on the target planes zp-1, zp, zp+1
+      if (zp >= 0 && zp < d.s0 && !(flags & kDbgNoB)) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int a = (SELF || !GG) ? c : 3 + c;
-      dst[a] = ginn + (size_t)c * V;
-      row_base[a] = (zt * d.s1 + y0) * d.s2;
-      ok[a] = fin;
+        for (int i = 0; i < RPW + 2; ++i) {
+          const int r = i;                        // staged row of the sample past the lane's own_row0; sample y = y0 - 1 + own_row0 + r
+          float fx = fbase[(0 * R + r) * P];
+          float fy = fbase[(1 * R + r) * P];
+          float fz = fbase[(2 * R + r) * P];
+          float go[C];
 #pragma unroll
-      for (int o = 0; o < RPW; ++o) {
-        float v = lane_prev_f(acc[o][0][c][2]) + acc[o][0][c][1] + lane_next_f(acc[o][0][c][0]);
-        if (SELF) v += gg_hold[o][c < 3 ? c : 0];
-        vals[a][o] = v;
+          for (int c = 0; c < C; ++c) go[c] = gobase[(c * R + r) * P];
+          if (CLIP) {
+            const float ys = (float)(y0 - 1 + own_row0 + r);
+            fx = __builtin_amdgcn_fmed3f(fx, xlo, xhi);
+            fy = __builtin_amdgcn_fmed3f(fy, -ys, (float)(d.s1 - 1) - ys);
+            fz = __builtin_amdgcn_fmed3f(fz, zlo, zhi);
+          }
+          float tx[3], tyv[3], tzv[3];
+          tx[0] = fmaxf(0.f, -fx); tx[2] = fmaxf(0.f, fx); tx[1] = (1.f - tx[0]) - tx[2];
+          if (WIDE) tx[0] = kill_left ? 0.f : tx[0];
+          tyv[0] = fmaxf(0.f, -fy); tyv[2] = fmaxf(0.f, fy); tyv[1] = (1.f - tyv[0]) - tyv[2];
+          tzv[0] = fmaxf(0.f, -fz); tzv[2] = fmaxf(0.f, fz); tzv[1] = (1.f - tzv[0]) - tzv[2];
+#pragma unroll
+          for (int o = 0; o < RPW; ++o) {
+            const int k = o + 1 - i;              // output row minus sample row (compile time)
+            if (k < -1 || k > 1) continue;
+            const float wy = tyv[k + 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              const float a = go[c] * wy;
+#pragma unroll
+              for (int kz = 0; kz < 3; ++kz) {
+                const float b = a * tzv[kz];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[o][SL[kz]][c][kx] = fmaf(b, tx[kx], acc[o][SL[kz]][c][kx]);
+              }
+            }
+          }
+        }
+      }
+      // ---- target plane zp-1 has now seen its three sample planes: fold over x; its slot starts over as plane zp+2
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int a = (SELF || !GG) ? c : 3 + c;
+        dst[a] = ginn + (size_t)c * V;
+        row_base[a] = (zt * d.s1 + y0) * d.s2;
+        ok[a] = fin;
+#pragma unroll
+        for (int o = 0; o < RPW; ++o) {
+          float v = lane_prev_f(acc[o][SL[0]][c][2]) + acc[o][SL[0]][c][1] + lane_next_f(acc[o][SL[0]][c][0]);
+          if (SELF) v += gg_hold[o][c < 3 ? c : 0];
+          vals[a][o] = v;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc[o][SL[0]][c][kx] = 0.f;
+        }
       }
     }
-#pragma unroll
-    for (int o = 0; o < RPW; ++o)
-#pragma unroll
-      for (int c = 0; c < C; ++c)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          acc[o][0][c][kx] = acc[o][1][c][kx];
-          acc[o][1][c][kx] = acc[o][2][c][kx];
-          acc[o][2][c][kx] = 0.f;
-        }
 
     // ---- phase A: coordinate-path gradient of the owned samples of plane zp (corner values from the ring)
     const bool do_a = (SELF || GG) && zp >= za && zp < zb && !(flags & kDbgNoA);
@@ -453,6 +461,13 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
       if (more_late) commit_late(zp + 1, pl);
     }
     __syncthreads();
+  };
+  for (int zp = za - 1; zp <= zb; zp += 3) {
+    step(zp, std::integral_constant<int, 0>{});
+    if (zp + 1 > zb) break;
+    step(zp + 1, std::integral_constant<int, 1>{});
+    if (zp + 2 > zb) break;
+    step(zp + 2, std::integral_constant<int, 2>{});
   }
 }
 
