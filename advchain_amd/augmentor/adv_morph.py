@@ -109,10 +109,6 @@ class AdvMorph(AdvTransformBase):
     def _chain_opts(self, positions_only=False):
         """The attributes DemonsCompose reads (adv_morph.py:236-242,461-471) as the operator's options; None = the
         reference defaults (num_steps=8, smooth_iter=1, sigma=1, scaling and squaring)."""
-        if self.integration_type != 'ss':
-            raise NotImplementedError('integration_type=%r: only scaling and squaring ("ss", the reference default, '
-                                      'adv_morph.py:241) is implemented; the reference\'s Euler branch does not run in 3D '
-                                      '(adv_morph.py:171: range() of a float)' % (self.integration_type,))
         n, it = int(self.num_steps), int(self.smooth_iter)
         if n < 1 or it < 1:
             raise NotImplementedError('num_steps and smooth_iter must be at least 1 (got %d, %d)' % (n, it))
@@ -133,7 +129,7 @@ class AdvMorph(AdvTransformBase):
         scale = sign * self._scale()
         want_grad = torch.is_grad_enabled() and p.requires_grad
         opts = self._chain_opts()
-        if not self._nine_taps():      # another Gaussian window: the general route of DemonsCompose (no pairing, no bound)
+        if not self._nine_taps() or self.integration_type != 'ss':      # another Gaussian window / Euler steps: the general route of DemonsCompose (no pairing, no bound)
             return self.DemonsCompose(duv=scale * p) if want_grad else self.DemonsCompose(duv=scale * p.detach()).detach()
         if not self._share_fields:
             return ops.demons_field(p, scale, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), opts)
@@ -182,17 +178,37 @@ class AdvMorph(AdvTransformBase):
                 raise ValueError('DemonsCompose: init_deformation_dxy must have the shape of the sampling grid %s, got %s'
                                  % (tuple(base.shape), tuple(init_deformation_dxy.shape)))
             identity = (not init_deformation_dxy.requires_grad) and torch.equal(init_deformation_dxy.to(base.device), base)
-        if identity and smooth and self._nine_taps():
+        if identity and smooth and self._nine_taps() and self.integration_type == 'ss':
             q = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(), self._chain_opts())
             return torch.clamp(q, -1, 1)
         # general route: positions = integrated offsets + identity (adv_morph.py:464-472), then adv_morph.py:474-490
-        pos = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(),
-                               self._chain_opts(positions_only=True))
+        if self.integration_type != 'ss':
+            pos = self._euler_positions(duv)
+        else:
+            pos = ops.demons_field(duv, 1.0, self._tables, self.spatial_dims == 3, self._reduce_sumsq(),
+                                   self._chain_opts(positions_only=True))
         init = self.base_grid if init_deformation_dxy is None else init_deformation_dxy.to(self.device)
         comp = ops.grid_sample(init.contiguous(), pos, 'bilinear', 'border')          # applyComposition{2,3}D
         if smooth:
             comp = ops.axpy(ops.gauss_smooth(ops.axpy(comp, self.base_grid, -1.0), self.sigma), self.base_grid, 1.0)
         return torch.clamp(comp, -1, 1)
+
+    def _euler_positions(self, duv):
+        """The `else` branch of vectorFieldExponentiation2D (adv_morph.py:136-141; any integration_type other than 'ss'):
+        phi_0 = id + u / 2^n composed n times with the running field, returned as (phi_n - phi_0) + id.  Every step is the
+        general HIP sampler (the field as a 2-channel image, border padding).  3D: the reference's own loop cannot run
+        (adv_morph.py:171 calls range() on a float) -- the same TypeError is raised here."""
+        if self.spatial_dims == 3:
+            raise TypeError("'float' object cannot be interpreted as an integer")    # range(2.0 ** nb_steps), adv_morph.py:171
+        n, it = int(self.num_steps), int(self.smooth_iter)
+        u = duv
+        for _ in range(it):
+            u = ops.gauss_smooth(u, self.sigma)
+        phi0 = ops.upsample_field(u, self._tables, 1.0 / (2.0 ** n))
+        phi = phi0
+        for _ in range(n):
+            phi = ops.grid_sample(phi0, phi, 'bilinear', 'border')                  # applyComposition2D(interval_phi, phi)
+        return ops.axpy(ops.axpy(phi, phi0, -1.0), self.base_grid, 1.0)
 
     def get_deformation_displacement_field(self, duv=None):
         # adv_morph.py:339-347

@@ -956,6 +956,27 @@ def gauss_smooth(x, sigma=1.0):
     return _GaussSmooth.apply(x, float(sigma))
 
 
+class _UpsampleField(torch.autograd.Function):
+    """Low-resolution velocity (N,d,g...) -> id + scale * F.interpolate(v, size, linear, align_corners=False)
+    (adv_morph.py:464 + 111): the banded tensor-product kernel and its adjoint as one differentiable operator (the fused
+    chain calls the same kernels directly)."""
+
+    @staticmethod
+    def forward(ctx, coef, tables, scale):
+        coef = _dev(coef, "velocity")
+        ctx.tables, ctx.scale = tables, float(scale)
+        return raw_tp_interp(coef, tables, coef.shape[1], add_identity=True, scale=float(scale))
+
+    @staticmethod
+    def backward(ctx, g):
+        return raw_tp_adjoint(_dev(g, "grad").contiguous(), ctx.tables, scale=ctx.scale), None, None
+
+
+@_on_tensor_device
+def upsample_field(coef, tables, scale):
+    return _UpsampleField.apply(coef, tables, float(scale))
+
+
 @_on_tensor_device
 def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     """(field(+scale * vel), field(-scale * vel)): the deformation and its approximate inverse, which one solver step

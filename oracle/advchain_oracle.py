@@ -95,8 +95,9 @@ def compose_fields(flow1, flow2):
     return F.grid_sample(flow1, _to_sampler_layout(flow2), padding_mode="border", align_corners=True)
 
 
-def field_exponentiation(u, nb_steps=8):
-    """Scaling and squaring.  adv_morph.py:116-177.
+def field_exponentiation(u, nb_steps=8, integration_type="ss"):
+    """Scaling and squaring ('ss'), or nb_steps Euler compositions with phi_0 for any other type (2D only in the
+    reference: adv_morph.py:136-141; its 3D loop, :171, calls range() on a float).  adv_morph.py:116-177.
 
     Q1: the start grid is aliased with phi_0 = id + u/2^n (in-place add at adv_morph.py:111), so
     the function returns phi_n - phi_0, not phi_n - id.  Q2: 3D only -- n grows while the
@@ -109,12 +110,19 @@ def field_exponentiation(u, nb_steps=8):
             step = u / (2.0 ** nb_steps)
     phi0 = identity_grid(u.shape[0], u.shape[2:], u.device) + step
     phi = phi0
-    for _ in range(nb_steps):
-        phi = compose_fields(phi, phi)
+    if integration_type == "ss":
+        for _ in range(nb_steps):
+            phi = compose_fields(phi, phi)
+    else:
+        if d == 3:
+            raise TypeError("'float' object cannot be interpreted as an integer")    # adv_morph.py:171
+        for _ in range(nb_steps):
+            phi = compose_fields(phi0, phi)
     return phi - phi0, nb_steps
 
 
-def demons_compose(duv, dims, final_clamp=True, num_steps=8, smooth_iter=1, sigma=1, smooth=True, init=None):
+def demons_compose(duv, dims, final_clamp=True, num_steps=8, smooth_iter=1, sigma=1, smooth=True, init=None,
+                   integration_type="ss"):
     """Low-res velocity (N,d,v...) -> clamped sampling grid (N,d,*dims).  adv_morph.py:454-491 (Q4).
     ``final_clamp=False`` (test aid) stops before the last torch.clamp of adv_morph.py:490.  num_steps / smooth_iter /
     sigma: the attributes of adv_morph.py:236-240; ``smooth`` and ``init`` (None = the identity grid, what every call of
@@ -125,7 +133,7 @@ def demons_compose(duv, dims, final_clamp=True, num_steps=8, smooth_iter=1, sigm
         duv = gaussian_smooth(duv, sigma=sigma)
     duv = F.interpolate(duv, size=tuple(dims), mode="bilinear" if d == 2 else "trilinear",
                         align_corners=False)
-    offsets, _ = field_exponentiation(duv, num_steps)
+    offsets, _ = field_exponentiation(duv, num_steps, integration_type)
     composed = compose_fields(base if init is None else init, offsets + base)
     if smooth:
         composed = gaussian_smooth(composed - base, sigma=sigma) + base

@@ -916,16 +916,21 @@ def g10_demons_args(aug):
         # windows other than 9 taps (adv_morph.py:393-398: 2 * int(4 sigma + 0.5) + 1 = 17 / 5)
         "sigma2": dict(sigma=2.0),
         "sigma05_init": dict(sigma=0.5, init=True),
+        # Euler steps instead of scaling and squaring (adv_morph.py:136-141; the reference's 3D loop cannot run)
+        "euler": dict(integration_type="euler", only=2),
+        "euler_steps5_nosmooth": dict(integration_type="euler", num_steps=5, smooth=False, only=2),
     }
     i = 0
     for stag, c in shapes.items():
         for vtag, v in variants.items():
             i += 1
+            if v.get("only", c["spatial_dims"]) != c["spatial_dims"]:
+                continue
             cfg = dict(epsilon=1.5, data_size=c["data_size"], vector_size=c["vector_size"])
             t = aug.AdvMorph(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
             torch.manual_seed(4100 + i)
             t.init_parameters()
-            for a in ("num_steps", "smooth_iter", "sigma"):
+            for a in ("num_steps", "smooth_iter", "sigma", "integration_type"):
                 if a in v:
                     setattr(t, a, v[a])
             p = t.unit_normalize(rand(tuple(t.param.shape), 4200 + i)).detach().requires_grad_(True)
@@ -942,7 +947,7 @@ def g10_demons_args(aug):
             dxy = t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=init, smooth=v.get("smooth", True))
             (dxy * w).sum().backward()
             key = "%s_%s_" % (stag, vtag)
-            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, attrs={a: v[a] for a in ("num_steps", "smooth_iter", "sigma") if a in v},
+            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, attrs={a: v[a] for a in ("num_steps", "smooth_iter", "sigma", "integration_type") if a in v},
                              smooth=v.get("smooth", True), init=bool(v.get("init")))
             out.update({key + "param": p.detach(), key + "w": w, key + "dxy": dxy.detach(), key + "grad_param": p.grad.clone()})
             if v.get("init"):

@@ -112,6 +112,13 @@ def gauss_smooth(x, sigma=1.0):
     return O.gaussian_smooth(x, sigma=sigma)
 
 
+def upsample_field(coef, tables, scale):
+    dims = tuple(tables.full_dims)
+    d = len(dims)
+    return O.identity_grid(coef.shape[0], dims) + scale * F.interpolate(coef, size=dims, mode="bilinear" if d == 2 else "trilinear",
+                                                                         align_corners=False)
+
+
 def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
     """[S_mse, S_edgeA, S_edgeB, S_kl] raw sums as the HIP kernels define them (advchain_amd/csrc/loss.hip)."""
     K = pred.shape[1]
@@ -149,7 +156,7 @@ def consistency_sums(pred, ref, mask, coef, ref_is_prob=False, want_edges=True):
 
 
 PATCHED = ["grid_sample", "affine_warp", "affine_theta", "axpy", "normalized_axpy", "sign_axpy", "nonzero_mask", "bias_apply", "bias_field_only",
-           "demons_field", "demons_field_pair", "gauss_smooth", "consistency_sums"]
+           "demons_field", "demons_field_pair", "gauss_smooth", "upsample_field", "consistency_sums"]
 
 
 def install(monkeypatch):

@@ -94,9 +94,13 @@ def test_morph_and_affine_host_classes(cpu_ops):
                        O.demons_compose(t.epsilon * p, dims, smooth=False)) < 2e-6
         with pytest.raises(ValueError):
             t.DemonsCompose(t.epsilon * p, t.base_grid[:, :1])
-        t.integration_type = 'euler'
-        with pytest.raises(NotImplementedError):
-            t.DemonsCompose(t.epsilon * p, t.base_grid)
+        t.integration_type = 'euler'          # adv_morph.py:136-141 (2D); the reference's 3D loop raises (adv_morph.py:171)
+        if m["spatial_dims"] == 2:
+            assert maxdiff(t.DemonsCompose(t.epsilon * p, t.base_grid),
+                           O.demons_compose(t.epsilon * p, dims, integration_type='euler')) < 2e-6
+        else:
+            with pytest.raises(TypeError):
+                t.DemonsCompose(t.epsilon * p, t.base_grid)
         t.integration_type = 'ss'
         o = t.forward(data)
         (o * w).sum().backward()
