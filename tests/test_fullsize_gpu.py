@@ -1,4 +1,4 @@
-"""Full BASELINE sizes (cfg-2: 32x1x256x256, cfg-3: 4x1x128x128x64) on the GPU, checked through size-independent
+"""Full BASELINE sizes (cfg-2: 32x1x256x256, cfg-3: 4x1x128x128x64, cfg-5: 4x1x160x160x80) on the GPU, checked through size-independent
 properties, since the CPU oracle needs minutes there: adjointness <A x, y> = <x, A^T y> of every forward/backward
 kernel pair, linearity, identity warps, agreement of the two independent scatter implementations, bitwise
 run-to-run determinism of the fixed-point scatter (3D), and one whole solver call (finite, ascent does not lower the
@@ -9,7 +9,9 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
 
-SHAPES = {"cfg2": dict(N=32, dims=(256, 256), vs=[16, 16]), "cfg3": dict(N=4, dims=(128, 128, 64), vs=[8, 8, 32])}
+SHAPES = {"cfg2": dict(N=32, dims=(256, 256), vs=[16, 16]), "cfg3": dict(N=4, dims=(128, 128, 64), vs=[8, 8, 32]),
+          # cfg-5's volume: rows of 80 voxels -- the flat forward march, the A / B-wave adjoint, the flat march scatter
+          "cfg5": dict(N=4, dims=(160, 160, 80), vs=[20, 20, 10])}
 
 
 def _morph(shape, eps=1.5, seed=0):
@@ -26,7 +28,7 @@ def dot(a, b):
     return float((a.double() * b.double()).sum())
 
 
-@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3", "cfg5"])
 def test_warp_adjoint_linearity_and_paths(shape):
     from advchain_amd import ops
     t, s = _morph(shape)
@@ -62,7 +64,7 @@ def test_warp_adjoint_linearity_and_paths(shape):
         assert float((gq - gq_atomic).abs().max()) < 1e-4 * float(gq_atomic.abs().max())
 
 
-@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3", "cfg5"])
 def test_identity_field_is_identity_warp(shape):
     from advchain_amd import ops
     t, s = _morph(shape)
@@ -76,7 +78,7 @@ def test_identity_field_is_identity_warp(shape):
     assert float((out - x).abs().mean()) < 1e-3
 
 
-@pytest.mark.parametrize("shape", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("shape", ["cfg2", "cfg3", "cfg5"])
 def test_compose_self_jvp_matches_vjp(shape):
     """<J dphi, g> == <dphi, J^T g> with J dphi from a central difference of the forward kernel."""
     from advchain_amd import ops
@@ -123,6 +125,38 @@ def test_linear_kernels_are_adjoint_pairs(shape):
     (gx,) = torch.autograd.grad(Ax, x, y)
     lhs, rhs = dot(Ax.detach(), y), dot(x.detach(), gx)
     assert abs(lhs - rhs) < 1e-5 * abs(lhs)
+
+
+@pytest.mark.parametrize("shape", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("amp,bound", [(1.5, 2), (3.5, 4)])
+def test_march_scatter_agrees_with_the_window_scatter_at_full_size(shape, amp, bound):
+    """The self-composition backward on a smooth field of 1.5 / 3.5 voxels at the full 3D volumes: the owner-computes march
+    scatter with the exact bound (LDS int32 accumulators; lane <-> flat sample on cfg-5's rows of 80) against the
+    source-tiled window scatter (LDS windows flushed with float atomics) -- two independent implementations of the same
+    sum -- plus the march scatter's bitwise run-to-run determinism and the forward kernels' agreement under any hint."""
+    import torch.nn.functional as F
+    from advchain_amd import ops
+    s = SHAPES[shape]
+    N, dims = s["N"], s["dims"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    low = torch.rand(N, 3, *[max(2, v // 8) for v in dims], generator=g) * 2 - 1
+    up = F.interpolate(low, size=dims, mode="trilinear", align_corners=True)
+    up = (up / up.abs().max()).to(DEV)
+    lin = [torch.linspace(-1, 1, v, device=DEV) for v in dims]
+    mesh = torch.meshgrid(*lin, indexing="ij")
+    ident = torch.stack(list(reversed(mesh)), 0).unsqueeze(0)
+    sc = torch.tensor([2.0 * amp / (dims[2 - a] - 1) for a in range(3)], device=DEV).view(1, 3, 1, 1, 1)
+    phi = (ident + up * sc).contiguous()
+    assert bound - 1 <= float(ops.raw_max_displacement(phi).item()) < bound - 0.001
+    gq = torch.randn(N, 3, *dims, device=DEV)
+    ws = ops._scatter_workspace(N, dims, DEV)
+    a = ops.raw_compose_self_bwd(gq, phi, ws, False, -bound)
+    assert torch.equal(a, ops.raw_compose_self_bwd(gq, phi, ws, False, -bound))
+    b = ops.raw_compose_self_bwd(gq, phi, ws, False, 8)
+    assert float((a - b).abs().max()) < 3e-5 * float(b.abs().max())
+    outs = [ops.raw_compose_self_fwd(phi, disp_hint=h) for h in (None, 0.5, 2.5, 9.0)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
