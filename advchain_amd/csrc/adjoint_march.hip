@@ -74,6 +74,7 @@ struct MarchCfg {
   static constexpr int NA_ROUND = NA > 2 ? 2 : NA;              // arrays transposed per round
   static constexpr int TRW = NA_ROUND * RPW * 64;               // transposition scratch per wave (floats)
   static constexpr int ROWS_END = 4 * PS + 2 * LS + 4;          // staged rows, then the right zeros of the last one
+  static constexpr bool LATE_FETCH = SELF || (GG && C > 1);     // order of requests / commit / stores at the end of a step (see there)
   static constexpr size_t LDS = (size_t)(ROWS_END + NW * TRW) * sizeof(float);
   // per SIMD: 128 / 168 / 256 VGPRs (512-thread blocks: 2 waves per SIMD each).  Without the SLP vectoriser (build.py) the
   // self-composition needs 152: three workgroups a CU
@@ -208,6 +209,10 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
     commit_ring(za - 1, pr0);
     commit_ring(za, pr);
     commit_late(za - 1, pl);
+    if constexpr (G::LATE_FETCH) {     // the planes the FIRST step commits at its end: requested now (see the end of a step)
+      fetch_ring(za + 1, pr);
+      fetch_late(za, pl);
+    }
   }
   __syncthreads();
 
@@ -291,12 +296,13 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
   auto step = [&](const int zp, auto rot_tag) {
     constexpr int ROT = decltype(rot_tag)::value;
     constexpr int SL[3] = {(ROT + 2) % 3, ROT, (ROT + 1) % 3};      // slots of the target planes zp-1, zp, zp+1
-    // ---- loads of the next planes go out first: they land while this plane is being worked on
-    const bool more_ring = zp + 2 <= zb && !(flags & kDbgNoStage), more_late = zp + 1 <= zb && !(flags & kDbgNoStage);
-    if (has_item) {
-      // (a plane beyond the chunk is loaded from a clamped address and never committed: no branch around the loads)
-      fetch_ring(zp + 2, pr);
-      fetch_late(zp + 1, pl);
+    // (LATE_FETCH: the planes this step commits at its end -- ring zp+2, late zp+1 -- were requested at the END of the
+    // previous step: see below)
+    if constexpr (!G::LATE_FETCH) {
+      if (has_item) {
+        fetch_ring(zp + 2, pr);
+        fetch_late(zp + 1, pl);
+      }
     }
 
     const float* lslot = late + (zp & 1) * LS;
@@ -452,13 +458,37 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
         }
       }
     }
-    if (!(flags & kDbgNoStore)) store_rows(vals, dst, row_base, ok);
-
     // ---- the prefetched planes go to LDS; nobody reads these slots in this step (ring: zp+2 = zp-2 mod 4, last read
-    // in step zp-1; late: zp+1 = zp-1 mod 2, last read in step zp-1)
-    if (has_item) {
-      if (more_ring) commit_ring(zp + 2, pr);
-      if (more_late) commit_late(zp + 1, pl);
+    // in step zp-1; late: zp+1 = zp-1 mod 2, last read in step zp-1).  Order of the memory traffic at the end of a step:
+    // commit (wait for the planes requested a step ago), request the next planes, THEN this step's stores.  vmcnt counts in
+    // order and the stores sit behind (wave-uniform and per-lane) branches, so a wait for loads that are older than such
+    // stores has to be vmcnt(0): with the stores issued just before the commit every step waited for their acknowledgements
+    // (measured with the stores switched off: 21 of 119 us at 8 x 3 x 128 x 128 x 64).  Now everything a commit waits for
+    // was issued a whole step earlier.  (Stores before the requests does not work either: the register allocator reuses
+    // the stores' data registers as load destinations and guards them with the same wait.)
+    // (Committed unconditionally, also the planes beyond the chunk that nobody will read -- their slots hold dead planes:
+    // a request that is never waited for leaves the compiler guarding its registers at the next request, with a count that
+    // includes the stores.)
+    // Commit and request share ONE block: a request whose wait does not dominate the next write of its registers leaves
+    // the compiler guarding them there, with a count that includes the stores.
+    // Same-box A/B per kernel: the self-composition -7..-12 % (109 -> 97-101 us at 8 x 3 x 128 x 128 x 64), C = 4 with
+    // grad_grid -3..-7 %; the warps without grad_grid (no phase A: short steps) +16-21 % on rows of 64 (84.6 -> 98.2 us) and
+    // the one-channel warp +3-5 % (31.9 -> 33.5 us): those keep requests at the top and stores before the commit.
+    if constexpr (G::LATE_FETCH) {
+      if (has_item) {
+        commit_ring(zp + 2, pr);
+        commit_late(zp + 1, pl);
+        // (a plane beyond the chunk is loaded from a clamped address: no branch around the loads)
+        fetch_ring(zp + 3, pr);
+        fetch_late(zp + 2, pl);
+      }
+      if (!(flags & kDbgNoStore)) store_rows(vals, dst, row_base, ok);
+    } else {
+      if (!(flags & kDbgNoStore)) store_rows(vals, dst, row_base, ok);
+      if (has_item) {
+        if (zp + 2 <= zb) commit_ring(zp + 2, pr);
+        if (zp + 1 <= zb) commit_late(zp + 1, pl);
+      }
     }
     __syncthreads();
   };
