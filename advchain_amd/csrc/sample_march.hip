@@ -282,6 +282,7 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
   using G = FlatMarchCfg<C, SELF, PW, IPW>;
   constexpr int R = G::R, TY = G::TY, P = G::P, PS = G::PS;
   constexpr int PAD = MODE == kFwdBorder ? PAD_BORDER : PAD_ZEROS;
+  constexpr bool LATE = SELF || C == 4;     // order of commit / request / stores at the end of a step (see there)
   extern __shared__ float lds[];
   float* const ring = lds;                  // [slot 4][C][R][P]
   float* const trbuf = lds + 4 * PS;        // [wave][TRW]
@@ -343,6 +344,7 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
     commit(za - 1, pa);
     commit(za, pb);
     commit(za + 1, pr);
+    if constexpr (LATE) fetch(za + 2, pr);
   }
   __syncthreads();
 
@@ -364,7 +366,9 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
 
   for (int z = za; z < zb; ++z) {
     const bool more = z + 2 <= zb;
-    if (has_item) fetch(z + 2, pr);
+    if constexpr (!LATE) {
+      if (has_item) fetch(z + 2, pr);
+    }
     const uint32_t tile_off = (uint32_t)((z * d.s1 + y0) * W);
     float g[IPW][3], p0v[IPW][3];
     if constexpr (!SELF) {
@@ -446,6 +450,14 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
       }
     }
 
+    // LATE: the plane requested a step ago goes to LDS (its slot held plane z-2: nobody reads it in this step) and the next
+    // one is requested BEFORE this step's stores: a wait for loads that are older than conditional stores has to be
+    // vmcnt(0) and would wait for the stores' acknowledgements every step (adjoint_march.hip).  Same-box A/B at
+    // 8 x . x 160 x 160 x 80: self-composition 124.8 -> 117.6 us, C = 4 184.7 -> 177 us, C = 1 unchanged (it keeps the
+    // old order; so does k_sample_march, where the late order measured 3-8 % slower).
+    if constexpr (LATE) {
+      if (has_item) { commit(z + 2, pr); fetch(z + 3, pr); }
+    }
     // ---- results leave 4 voxels per lane through the wave's LDS scratch (an item is 64 consecutive voxels in memory)
     constexpr int NR = G::NA_ROUND;
 #pragma unroll
@@ -469,7 +481,9 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
       lds_order();
     }
 
-    if (has_item && more) commit(z + 2, pr);
+    if constexpr (!LATE) {
+      if (has_item && more) commit(z + 2, pr);
+    }
     __syncthreads();
   }
   if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
