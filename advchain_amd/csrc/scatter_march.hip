@@ -35,12 +35,24 @@ __device__ __forceinline__ void st_off(float* __restrict__ base, unsigned byte_o
 // d(sample)/d(unnormalised coordinate) * go in difference form: ax = go * sum_zy wz wy (v[z][y][1] - v[z][y][0]) and so on
 // -- a third of the instructions of the signed-product form of sample_linear_bwd (these kernels are VALU bound), the same
 // value up to the rounding of the differences.
+// (the arithmetic on corner values that are already in registers: a caller with several channels / samples loads all their
+// corners first -- CornerOffsets::load -- so that their round trips overlap)
+template <int DIM, int PAD>
+__device__ __forceinline__ void coord_path_values(const float (&vl)[8], float go, const Taps<DIM, PAD>& t, float& ax, float& ay,
+                                                  float& az);
+
 template <int DIM, int PAD>
 __device__ __forceinline__ void coord_path_diff(const float* __restrict__ in, float go, const Taps<DIM, PAD>& t, const Dims& d,
                                                 float& ax, float& ay, float& az) {
   const CornerOffsets<DIM, PAD> o(t, d);
   float vl[8];
   o.load(in, vl);
+  coord_path_values<DIM, PAD>(vl, go, t, ax, ay, az);
+}
+
+template <int DIM, int PAD>
+__device__ __forceinline__ void coord_path_values(const float (&vl)[8], float go, const Taps<DIM, PAD>& t, float& ax, float& ay,
+                                                  float& az) {
   float v[2][2][2];
 #pragma unroll
   for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
@@ -371,8 +383,14 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         }
         if (own) {
           float ax = 0.f, ay = 0.f, az = 0.f;
+          {   // the corners of every channel first, then the arithmetic: one round trip instead of one per channel
+            const CornerOffsets<3, PAD> o(t, d);
+            float vl[C][8];
 #pragma unroll
-          for (int c = 0; c < C; ++c) coord_path_diff<3, PAD>(inn + (int64_t)c * V, go[k][c], t, d, ax, ay, az);
+            for (int c = 0; c < C; ++c) o.load(inn + (int64_t)c * V, vl[c]);
+#pragma unroll
+            for (int c = 0; c < C; ++c) coord_path_values<3, PAD>(vl[c], go[k][c], t, ax, ay, az);
+          }
           if (xown) {
             float* gq = ggrid + (int64_t)n * 3 * V;
             const unsigned so = (unsigned)((zp * d.s1 + ys) * d.s2 + xl) * 4u;
@@ -399,8 +417,14 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
         Taps<3, PAD> t;
         t.build(q[0], q[1], q[2], d);
         float ax = 0.f, ay = 0.f, az = 0.f;
+        if (!SL) {   // the corners of every channel first, then the arithmetic: one round trip instead of one per channel
+          const CornerOffsets<3, PAD> o(t, d);
+          float vl[C][8];
 #pragma unroll
-        for (int c = 0; c < C; ++c) if (!SL) coord_path_diff<3, PAD>(inn + (int64_t)c * V, fgo[k][c], t, d, ax, ay, az);
+          for (int c = 0; c < C; ++c) o.load(inn + (int64_t)c * V, vl[c]);
+#pragma unroll
+          for (int c = 0; c < C; ++c) coord_path_values<3, PAD>(vl[c], fgo[k][c], t, ax, ay, az);
+        }
         if (SL) {
           const int so = (min(max(zt, 0), d.s0 - 1) * d.s1 + min(y0 + wave + k * NWV, d.s1 - 1)) * d.s2 + xl;   // the own sample
 #pragma unroll
@@ -639,17 +663,23 @@ k_scatter_march3d_flat(const float* __restrict__ gout, const float* __restrict__
     const bool fin = zt >= za && zt < zb;
     float gg[MAXF][3];
     if (fin) {
+      // every corner of every channel of an output item is requested before the first one is used: per channel the gathers
+      // were a round trip each (load, wait, arithmetic, next channel)
 #pragma unroll
       for (int k = 0; k < MAXF; ++k) {
         if (wave + k * NWV >= oitems) continue;                      // wave-uniform
-        Taps<3, PAD> t;
-        t.build(fg[k][0], fg[k][1], fg[k][2], d);
+        Taps<3, PAD> tq;
+        tq.build(fg[k][0], fg[k][1], fg[k][2], d);
+        const CornerOffsets<3, PAD> o(tq, d);
+        float vl[C][8];                                              // (both items at once: 147 VGPRs, one workgroup a CU)
+#pragma unroll
+        for (int c = 0; c < C; ++c) o.load(gn + (int64_t)c * V, vl[c]);
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) coord_path_diff<3, PAD>(gn + (int64_t)c * V, fgo[k][c], t, d, ax, ay, az);
-        gg[k][0] = t.x.mult * ax;
-        gg[k][1] = t.y.mult * ay;
-        gg[k][2] = t.z.mult * az;
+        for (int c = 0; c < C; ++c) coord_path_values<3, PAD>(vl[c], fgo[k][c], tq, ax, ay, az);
+        gg[k][0] = tq.x.mult * ax;
+        gg[k][1] = tq.y.mult * ay;
+        gg[k][2] = tq.z.mult * az;
       }
     }
     __syncthreads();
