@@ -154,6 +154,30 @@ __device__ __forceinline__ void sample_linear_bwd(const float* __restrict__ in, 
       }
 }
 
+// The coordinate-path part of sample_linear_bwd on corner values that are already in registers (CornerOffsets::load): a
+// caller with several channels requests the corners of all of them first, so that their round trips overlap (per channel
+// -- load, wait, arithmetic, next channel -- they were serial: 96 loads and 33 full waits in the 3D window scatter).
+template <int DIM, int PAD>
+__device__ __forceinline__ void sample_linear_bwd_values(const float (&v)[8], float go, const Taps<DIM, PAD>& t, float& ax,
+                                                         float& ay, float& az) {
+#pragma unroll
+  for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        const float val = t.ok(cz, cy, cx) ? v[(cz * 2 + cy) * 2 + cx] : 0.f;
+        if (DIM == 3) {
+          ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * t.wz(cz) * go);
+          ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * t.wz(cz) * go);
+          az += (cz ? 1.f : -1.f) * (val * t.wx(cx) * t.wy(cy) * go);
+        } else {
+          ax += (cx ? 1.f : -1.f) * (val * t.wy(cy) * go);
+          ay += (cy ? 1.f : -1.f) * (val * t.wx(cx) * go);
+        }
+      }
+}
+
 // affine warp: grid = theta_n * (x, y[, z], 1) evaluated in registers (F.affine_grid, align_corners=True)
 template <int DIM>
 struct Theta { float m[DIM][DIM + 1]; };

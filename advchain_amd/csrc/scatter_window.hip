@@ -298,6 +298,14 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     float go[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) go[c] = gopre[j][c];
+    // the corner values of the coordinate path (every channel) are requested here and used after the deposits
+    constexpr bool CP_PATH = SELF || GG;
+    float cv[CP_PATH ? C : 1][8];
+    if (CP_PATH && c0 == 0) {
+      const CornerOffsets<DIM, PAD> co(t, d);
+#pragma unroll
+      for (int c = 0; c < C; ++c) co.load(inn + (int64_t)c * V, cv[c]);
+    }
     // window cell / voxel of corner (0,0,0) once (24-bit multiplies: a 32-bit v_mul_lo costs four VALU slots); the
     // other corners are +1, +ww, +plane away
     const int wx0 = t.x.i0 - lo[0], wy0 = t.y.i0 - lo[1], wz0 = t.z.i0 - lo[2];
@@ -329,8 +337,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     if ((SELF || GG) && c0 == 0) {
       float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-      for (int c = 0; c < C; ++c)
-        sample_linear_bwd<DIM, PAD, false, true>(inn + (int64_t)c * V, nullptr, go[c], t, d, ax, ay, az);
+      for (int c = 0; c < C; ++c) sample_linear_bwd_values<DIM, PAD>(cv[c], go[c], t, ax, ay, az);
       const float ggx = pass[0] ? t.x.mult * ax : 0.f, ggy = pass[1] ? t.y.mult * ay : 0.f,
                   ggz = pass[2] ? t.z.mult * az : 0.f;
       if (SELF) {
