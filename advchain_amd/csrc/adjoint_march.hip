@@ -9,14 +9,18 @@
 //     once and deposited on the 3 (z) x 3 (x) x RPW (y) outputs it touches.  The output-centric kernel re-reads and
 //     re-derives every sample row for each of the 9 output rows around it (x2.4 the VALU work, x3 the LDS reads).
 //   * a wave keeps 3 planes of partial sums per owned row in registers; the plane that has seen all three of its
-//     sample planes is folded over x with two whole-wave DPP shifts and stored, the others shift down one slot.
-//   * the next plane is loaded into registers at the top of a step and written to LDS at its end (one barrier per
-//     step): the loads of step k+1 are in flight under the arithmetic of step k.  The image / field planes the
-//     coordinate path needs (z-1, z, z+1 around a sample) live in a 4-slot ring, staged two steps ahead.
+//     sample planes is folded over x with two whole-wave DPP shifts and stored, and its register set starts over as the
+//     plane two steps ahead (the march loop is unrolled by three: no register moves).
+//   * the next plane is requested a step ahead and written to LDS at the end of the step (one barrier per step): the
+//     loads of step k+1 are in flight under the arithmetic of step k; where it pays (MarchCfg::LATE_FETCH) the order at
+//     the end of a step is commit -> next requests -> stores, so that no wait for loads also waits for the step's own
+//     stores.  The image / field planes the coordinate path needs (z-1, z, z+1 around a sample) live in a 4-slot ring,
+//     staged two steps ahead.
 //   * with |p - s| < 1 guaranteed the tents need no general max(0, 1 - |f - k|): t(-1) = max(0, -f), t(+1) = max(0, f),
 //     t(0) = 1 - t(-1) - t(+1); the lower corner of an axis is s + floor(f) with floor(f) in {-1, 0}.
-//   * staged rows carry 4 zero floats on either side of their 64 voxels: a corner at x = -1 or x = S2 reads the 0 that
-//     zeros padding asks for, without a select; rows and planes outside the volume are staged as zeros.
+//   * staged rows have 4 zero floats on either side of their 64 voxels (the right zeros of a row ARE the left zeros of the
+//     next row in memory: 68 floats a row): a corner at x = -1 or x = S2 reads the 0 that zeros padding asks for,
+//     without a select; rows and planes outside the volume are staged as zeros.
 //   * results leave through LDS: a wave writes its rows lane <-> x and reads them back 4 voxels per lane, so that two
 //     16-byte store instructions replace eight 4-byte ones (a vector-memory instruction costs the CU ~26 clk whether
 //     it carries 4 or 16 bytes per lane).
