@@ -292,7 +292,8 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile = blockIdx.x + gridDim.x * blockIdx.y;
   const int tiles = gridDim.x * gridDim.y;
-  if (xcd && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);   // XCD-contiguous tiles (see above)
+  if ((xcd & 1) && (tiles & 7) == 0) tile = (tile & 7) * (tiles >> 3) + (tile >> 3);   // XCD-contiguous tiles (see above)
+  const int dbg = xcd >> 4;   // timing experiments only (ADVCHAIN_FWD_MARCH_DEBUG, results are wrong): 1 no taps, 2 no stores
   const int n = tile / (int)gridDim.x;
   const int rem = tile - n * (int)gridDim.x;
   const int ty = rem % n1, tz = rem / n1;
@@ -410,7 +411,10 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
       const float wy1 = ys - fy, wy0 = (fy + 1.f) - ys;
       const float wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
       const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)W;
-      if (staged) {
+      if (dbg & 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][i] = wx1 + wy1 + wz1;
+      } else if (staged) {
         float w[8];
         w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
         w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
@@ -475,7 +479,7 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
         const int a = j / (IPW * 16), i = (j / 16) % IPW, q = j & 15;
         const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * IPW + i) * 64 + 4 * q);
         const int f4 = (wave * IPW + i) * 64 + 4 * q;
-        if (j < ITEMS && c0 + a < C && f4 < flat_n)
+        if (j < ITEMS && c0 + a < C && f4 < flat_n && !(dbg & 2))
           *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + tile_off + (uint32_t)f4) = v4;
       }
       lds_order();
@@ -802,8 +806,9 @@ static void launch_fwd_flat(const float* in, const float* grid, float* out, cons
   const int zc = fwd_march_zc(d, N, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
   static const bool no_xcd = getenv("ADVCHAIN_NO_XCD_MAP") != nullptr;   // A/B knob
+  static const int dbg = getenv("ADVCHAIN_FWD_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_FWD_MARCH_DEBUG")) : 0;   // timing experiments
   hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(nw * 64), G::lds_bytes(nw), st, in, grid, out, phi0, d, n1,
-                     zc, final_mode, disp_out, no_xcd ? 0 : 1);
+                     zc, final_mode, disp_out, (no_xcd ? 0 : 1) | (dbg << 4));
 }
 
 template <int C>
