@@ -27,6 +27,13 @@ from .adv_noise import AdvNoise
 _NATIVE = (AdvNoise, AdvBias, AdvMorph, AdvAffine)
 
 
+def _native_update(t):
+    """True when `t` steps its parameters with one of the built-in update methods -- the ones that hand `t._gate` to the
+    gated update kernels.  A subclass that overrides optimize_parameters() may never look at the gate: it gets the
+    literal host-side NaN check of the reference instead (adv_compose_solver.py:343-347)."""
+    return any(isinstance(t, cls) and type(t).optimize_parameters is cls.optimize_parameters for cls in _NATIVE)
+
+
 class ComposeAdversarialTransformSolver(object):
     """apply a chain of transformation"""
 
@@ -194,6 +201,9 @@ class ComposeAdversarialTransformSolver(object):
         whole-batch loss."""
         if self.process_group is not None and self._global_batch is None:
             self._resolve_global_batch(pred.size(0), pred.device)
+        # (the loss is differentiated w.r.t. `pred` only: a reference that carries a graph -- a caller's init_output -- is a
+        # constant here, as it is for every result of the reference's solver: adv_compose_solver.py:268-270,310,366)
+        reference = reference.detach() if isinstance(reference, torch.Tensor) else reference
         return calc_segmentation_consistency(output=pred, reference=reference, divergence_types=self.divergence_types,
                                              divergence_weights=self.divergence_weights, scales=[0], mask=mask,
                                              class_weights=self.class_weights, is_gt=self.is_gt,
@@ -307,7 +317,7 @@ class ComposeAdversarialTransformSolver(object):
                 # stalled the GPU once per step: 9.8 ms per cfg-2 call for 8.8 ms of kernels).  Third-party transforms
                 # get the literal check.
                 flagged = [t for flag, t in zip(optimize_flags, self.chain_of_transforms) if flag]
-                device_guard = (self.device_nan_guard and value.is_cuda and all(isinstance(t, _NATIVE) for t in flagged)
+                device_guard = (self.device_nan_guard and value.is_cuda and all(_native_update(t) for t in flagged)
                                 and not getattr(self, 'full_backward', False))
                 if not device_guard and not math.isfinite(float(value.detach())):     # one read-back, no launches
                     dist = 0
@@ -327,8 +337,11 @@ class ComposeAdversarialTransformSolver(object):
                                 step_size = transform.get_step_size()
                                 logging.warning(f'use default step size:{step_size}')
                             transform.optimize_parameters(step_size=step_size)
-                            transform._gate = None
             finally:
+                # (also when the backward or an update raised: a stale loss must not gate a later manual update)
+                for transform in self.chain_of_transforms:
+                    if getattr(transform, '_gate', None) is not None:
+                        transform._gate = None
                 self._shared_fields(self.chain_of_transforms, False)
             model.zero_grad()
 

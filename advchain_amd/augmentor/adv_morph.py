@@ -112,13 +112,19 @@ class AdvMorph(AdvTransformBase):
         n, it = int(self.num_steps), int(self.smooth_iter)
         if n < 1 or it < 1:
             raise NotImplementedError('num_steps and smooth_iter must be at least 1 (got %d, %d)' % (n, it))
-        if (n, it, float(self.sigma)) == (8, 1, 1.0) and not positions_only:
+        taps = self._taps()
+        if (n, it, float(self.sigma), taps) == (8, 1, 1.0, 9) and not positions_only:
             return None
-        return (n, it, float(self.sigma), bool(positions_only))
+        return (n, it, float(self.sigma), bool(positions_only), taps)
+
+    def _taps(self):
+        """Window length of the Gaussian: `gaussian_ks` unless the rule 2 * int(4 sigma + 0.5) + 1 is larger
+        (adv_morph.py:393-398; 9 with the defaults, Q3)."""
+        return bands.gaussian_taps(self.sigma, self.gaussian_ks)
 
     def _nine_taps(self):
-        """The reference's window rule (adv_morph.py:393-398) gives the 9 taps of the fused kernels for this sigma."""
-        return 2 * int(4 * float(self.sigma) + 0.5) + 1 == 9
+        """The reference's window rule (adv_morph.py:393-398) gives the 9 taps of the fused kernels."""
+        return self._taps() == 9
 
     def _field(self, sign):
         """Un-clamped sampling grid for sign*scale*param, shared between the data / prediction / mask paths of
@@ -167,8 +173,9 @@ class AdvMorph(AdvTransformBase):
         identity grid itself or a tensor equal to it, and ``smooth`` is true.  Any other initial deformation and
         ``smooth=False`` take the same chain up to the sampling positions and then the reference's own steps on them
         (adv_morph.py:474-490), each a HIP operator: ``grid_sample(init, positions, border)``, ``G * (. - id) + id``.
-        ``num_steps``, ``smooth_iter`` and ``sigma`` are honoured on both routes; a sigma whose window is not 9 taps
-        (outside 0.875 <= sigma < 1.125, adv_morph.py:393-398) takes the general route with the plain K-tap Gaussian."""
+        ``num_steps``, ``smooth_iter``, ``sigma`` and ``gaussian_ks`` are honoured on both routes; a window other than 9
+        taps (max(gaussian_ks, 2 int(4 sigma + 0.5) + 1), adv_morph.py:393-398: sigma outside [0.875, 1.125) or a
+        gaussian_ks above 9) takes the general route with the plain K-tap Gaussian."""
         if self._tables is None:
             self._tables = bands.upsample_tables(list(self.vector_size), list(self.data_size[2:]), self.device)
         identity = init_deformation_dxy is None or init_deformation_dxy is self._base_grid
@@ -190,7 +197,7 @@ class AdvMorph(AdvTransformBase):
         init = self.base_grid if init_deformation_dxy is None else init_deformation_dxy.to(self.device)
         comp = ops.grid_sample(init.contiguous(), pos, 'bilinear', 'border')          # applyComposition{2,3}D
         if smooth:
-            comp = ops.axpy(ops.gauss_smooth(ops.axpy(comp, self.base_grid, -1.0), self.sigma), self.base_grid, 1.0)
+            comp = ops.axpy(ops.gauss_smooth(ops.axpy(comp, self.base_grid, -1.0), self.sigma, self._taps()), self.base_grid, 1.0)
         return torch.clamp(comp, -1, 1)
 
     def _euler_positions(self, duv):
@@ -203,7 +210,7 @@ class AdvMorph(AdvTransformBase):
         n, it = int(self.num_steps), int(self.smooth_iter)
         u = duv
         for _ in range(it):
-            u = ops.gauss_smooth(u, self.sigma)
+            u = ops.gauss_smooth(u, self.sigma, self._taps())
         phi0 = ops.upsample_field(u, self._tables, 1.0 / (2.0 ** n))
         phi = phi0
         for _ in range(n):

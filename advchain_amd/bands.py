@@ -147,9 +147,15 @@ def _upsample_tables(low_dims, full_dims, device, scale_factors=None):
     return BandTables(mats, device)
 
 
-def gaussian_weights_1d(sigma=1.0):
-    """1-D factor of the normalised 9^d window of adv_morph.py:391-428 (sigma=1 -> 9 taps)."""
-    k = 2 * int(4 * sigma + 0.5) + 1
+def gaussian_taps(sigma=1.0, gaussian_ks=5):
+    """Window length of the reference's Gaussian (adv_morph.py:393-398): the caller's `gaussian_ks` unless the rule
+    2 * int(4 sigma + 0.5) + 1 is larger (sigma = 1, gaussian_ks = 5 -> 9 taps, Q3; sigma = 0.3 -> the 5 of gaussian_ks)."""
+    return max(int(gaussian_ks), 2 * int(4 * float(sigma) + 0.5) + 1)
+
+
+def gaussian_weights_1d(sigma=1.0, taps=None):
+    """1-D factor of the normalised k^d window of adv_morph.py:391-428 (sigma=1 -> 9 taps), centred on (k - 1) / 2."""
+    k = 2 * int(4 * sigma + 0.5) + 1 if taps is None else int(taps)
     t = np.arange(k, dtype=np.float64) - (k - 1) / 2.0
     w = np.exp(-t * t / (2.0 * sigma * sigma))
     return (w / w.sum()).tolist()

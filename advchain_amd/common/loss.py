@@ -6,9 +6,24 @@ softmax + mask + squared error + KL sum + 3^d edge stencils in two launches forw
 Batch sharding: ``global_batch`` overrides N in every normaliser -- mse ~ 1/(N^2 K V^2),
 contour ~ 1/(N V) -- so that the per-shard values SUM to the whole-batch loss and the mse:contour mix
 (hence the ascent direction) does not depend on the shard size."""
+import warnings
+
 import torch
 
 from .. import ops
+
+MAX_CLASSES = 16      # kMaxK of csrc/loss.hip: the fused kernels keep one softmax row per voxel in registers
+
+
+def _check_operands(output, reference):
+    """The restrictions of the fused kernels, stated where the user meets them (INTEGRATION.md "Known deviations"): fp32
+    ROCm tensors (no CPU path -- ops raises), at most MAX_CLASSES channels, gradient w.r.t. the prediction only."""
+    if output.size(1) > MAX_CLASSES:
+        raise NotImplementedError('the fused consistency kernels take at most %d classes, got %d'
+                                  % (MAX_CLASSES, output.size(1)))
+    if torch.is_grad_enabled() and isinstance(reference, torch.Tensor) and reference.requires_grad:
+        warnings.warn('advchain_amd: the consistency loss is differentiated w.r.t. the prediction only; the reference '
+                      'is treated as a constant (detach it to silence this warning)', stacklevel=3)
 
 
 def _pooled(x, scale):
@@ -38,6 +53,7 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
     assert spatial_dims == 2 or spatial_dims == 3, 'only support 2d or 3d segmentation'
     assert output.dim() == reference.dim(), 'output and reference must have the same rank'
     K = reference.size(1)
+    _check_operands(output, reference)
     dist = 0.
     for scale in scales:
         out_s, ref_s = (output, reference) if scale == 0 else (_pooled(output, scale), _pooled(reference, scale))
@@ -82,6 +98,7 @@ def calc_segmentation_consistency(output, reference, divergence_types=['kl', 'co
 def kl_divergence(reference, pred, mask=None, is_gt=False, global_batch=None):
     """KL(P||Q) of two logit maps (loss.py:223-249): the 'kl' term of the fused kernels on its own."""
     K = pred.size(1)
+    _check_operands(pred, reference)
     V = 1
     for s in pred.shape[2:]:
         V *= s

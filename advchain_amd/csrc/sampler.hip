@@ -807,14 +807,16 @@ static int launch_grid_sample_bwd(const float* gout, const float* in, const floa
   return ADVCHAIN_OK;
 }
 
-static inline bool dims_ok(int ndim, const int64_t* s) {
+// min_voxels = 2 for a tensor that is GATHERED from (the paired corner gathers read two neighbouring elements:
+// sampler_common.h); the output side of a resampling warp may be a single voxel
+static inline bool dims_ok(int ndim, const int64_t* s, int64_t min_voxels = 2) {
   if (ndim != 2 && ndim != 3) return false;
   int64_t v = 1;
   for (int i = 0; i < ndim; ++i) {
     if (s[i] < 1 || s[i] > (1 << 24)) return false;
     v *= s[i];
   }
-  return v >= 2;          // (the paired corner gathers read two neighbouring elements: sampler_common.h)
+  return v >= min_voxels;
 }
 static inline Dims make_dims(int ndim, const int64_t* s) {
   Dims d;
@@ -842,7 +844,7 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
   const int disp_hint = (clamp_grid >> 8) & 0xff;   // bits 8..15: displacement estimate in voxels (0 = unknown), a performance hint
   clamp_grid &= 1;
   ADVCHAIN_CHECK_ARG(in && grid && out, "grid_sample_fwd: null pointer");
-  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims, 1), "grid_sample_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "grid_sample_fwd: bad N/C");
   ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "grid_sample_fwd: interp must be 0 (linear) or 1 (nearest)");
   ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "grid_sample_fwd: padding must be 0/1/2");
@@ -864,7 +866,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
                              int halo, void* stream) {
   ADVCHAIN_CHECK_ARG(grad_out && in && grid, "grid_sample_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(grad_in || grad_grid, "grid_sample_bwd: nothing to compute");
-  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims), "grid_sample_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims, 1), "grid_sample_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && C >= 1, "grid_sample_bwd: bad N/C");
   ADVCHAIN_CHECK_ARG(interp == INTERP_LINEAR || interp == INTERP_NEAREST, "grid_sample_bwd: interp");
   ADVCHAIN_CHECK_ARG(padding >= 0 && padding <= 2, "grid_sample_bwd: padding");

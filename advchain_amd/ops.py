@@ -22,24 +22,30 @@ _GAUSS9_CACHE = {}
 GENERIC_MAX_TAPS = 129
 
 
-def gauss9(sigma):
+def gauss9(sigma, taps=None):
     """The tap weights of the Gaussian for `sigma` (ctypes array).  The reference sizes its window as
-    2 * int(4 sigma + 0.5) + 1 taps (adv_morph.py:393-398): 9 for 0.875 <= sigma < 1.125 -- the fast kernels; any other
-    window runs advchain_gauss_axis_generic (raw_gauss; no fused prologue / epilogue there)."""
+    max(gaussian_ks, 2 * int(4 sigma + 0.5) + 1) taps (adv_morph.py:393-398; `taps`, default the rule alone): 9 for
+    0.875 <= sigma < 1.125 with the default gaussian_ks = 5 -- the fast kernels; any other window runs
+    advchain_gauss_axis_generic (raw_gauss; no fused prologue / epilogue there)."""
     sigma = float(sigma)
-    if sigma == 1.0:
+    if taps is None:
+        taps = 2 * int(4 * sigma + 0.5) + 1
+    taps = int(taps)
+    if sigma == 1.0 and taps == 9:
         return _GAUSS9
-    w = _GAUSS9_CACHE.get(sigma)
+    w = _GAUSS9_CACHE.get((sigma, taps))
     if w is None:
         if not sigma > 0.0:
             raise ValueError("Gaussian smoothing needs sigma > 0, got %r" % (sigma,))
-        taps = gaussian_weights_1d(sigma)
-        if len(taps) > GENERIC_MAX_TAPS:
+        if taps % 2 == 0:
+            # (the reference's conv then pads k // 2 on both sides and returns a field one voxel larger per axis)
+            raise NotImplementedError("Gaussian smoothing with an even window (%d taps) is not implemented" % taps)
+        if taps > GENERIC_MAX_TAPS:
             raise NotImplementedError("Gaussian smoothing with sigma=%g needs a %d-tap window (at most %d)"
-                                      % (sigma, len(taps), GENERIC_MAX_TAPS))
+                                      % (sigma, taps, GENERIC_MAX_TAPS))
         if len(_GAUSS9_CACHE) > 16:
             _GAUSS9_CACHE.clear()
-        w = _GAUSS9_CACHE[sigma] = _lib.float_array(taps)
+        w = _GAUSS9_CACHE[(sigma, taps)] = _lib.float_array(gaussian_weights_1d(sigma, taps))
     return w
 
 
@@ -210,13 +216,21 @@ def _persistent_zeros(tag, shape, device):
     whose CONSUMER kernel zeroes them again (advchain_slot_rows_max / advchain_consistency_finish with reset) -- one
     torch.zeros at first use instead of a fill launch per call.  Stream order makes the reuse safe: the consumer of call
     k runs before the producers of call k + 1 on the same stream."""
-    key = (tag, tuple(shape), str(device), _raw_stream(_raw_device()) if (_raw_stream and _raw_device) else 0)
+    stream = _raw_stream(_raw_device()) if (_raw_stream and _raw_device) else torch.cuda.current_stream().cuda_stream
+    key = (tag, tuple(shape), str(device), stream)
     buf = _PERSISTENT.get(key)
     if buf is None:
         if len(_PERSISTENT) > 64:
             _PERSISTENT.clear()
         buf = _PERSISTENT[key] = torch.zeros(shape, device=device, dtype=torch.float32)
     return buf
+
+
+def _forget_persistent(buf):
+    """Drop a persistent accumulator whose producer ran but whose consumer did not (an exception in between): it may hold
+    partial sums, and the next user must start from a fresh zero-filled buffer."""
+    for k in [k for k, v in _PERSISTENT.items() if v is buf]:
+        del _PERSISTENT[k]
 
 
 def raw_gauss_small_pair(x, scale, adjoint=False, weights=None):
@@ -792,16 +806,17 @@ class _DemonsField(torch.autograd.Function):
     The final clamp(-1,1) (adv_morph.py:490, 304-305) is applied by the sampler on load.
     backward: the hand-written adjoint of the same chain (saved: phi_0..phi_{n-1}, pos).
 
-    opts = (num_steps, smooth_iter, sigma, positions_only) -- the attributes of AdvMorph the reference reads in
-    DemonsCompose (adv_morph.py:236-242,461-471): defaults (8, 1, 1.0, False).  positions_only returns `pos` itself (the
+    opts = (num_steps, smooth_iter, sigma, positions_only[, taps]) -- the attributes of AdvMorph the reference reads in
+    DemonsCompose (adv_morph.py:236-242,461-471): defaults (8, 1, 1.0, False); taps = the Gaussian window length when it
+    is not the rule's 2 * int(4 sigma + 0.5) + 1 (a gaussian_ks above it, adv_morph.py:393-398).  positions_only returns `pos` itself (the
     caller composes it with an initial deformation other than the identity and / or skips the final smoothing)."""
 
     @staticmethod
     def forward(ctx, vel, scale, tables, nsteps_rule, reduce_sumsq, pair=False, opts=None):
         vel = _dev(vel, "velocity")
         ctx.pair = bool(pair)
-        n_base, smooth_iter, sigma, pos_only = opts if opts is not None else (8, 1, 1.0, False)
-        w9 = gauss9(sigma)
+        n_base, smooth_iter, sigma, pos_only = (tuple(opts) + (None,))[:4] if opts is not None else (8, 1, 1.0, False)
+        w9 = gauss9(sigma, opts[4] if (opts is not None and len(opts) > 4) else None)
         if len(w9) != 9 and not pos_only:
             raise NotImplementedError("the fused final smoothing exists for the 9-tap window only: ask for the positions")
         ctx.opts = (int(smooth_iter), w9, bool(pos_only))
@@ -940,20 +955,20 @@ class _GaussSmooth(torch.autograd.Function):
     the symmetric window is its own adjoint."""
 
     @staticmethod
-    def forward(ctx, x, sigma):
+    def forward(ctx, x, sigma, taps=None):
         x = _dev(x, "field")
-        ctx.w9 = gauss9(sigma)
+        ctx.w9 = gauss9(sigma, taps)
         return raw_gauss(x, x.shape[1], weights=ctx.w9)
 
     @staticmethod
     def backward(ctx, g):
         g = _dev(g, "grad")
-        return raw_gauss(g, g.shape[1], weights=ctx.w9), None
+        return raw_gauss(g, g.shape[1], weights=ctx.w9), None, None
 
 
 @_on_tensor_device
-def gauss_smooth(x, sigma=1.0):
-    return _GaussSmooth.apply(x, float(sigma))
+def gauss_smooth(x, sigma=1.0, taps=None):
+    return _GaussSmooth.apply(x, float(sigma), taps)
 
 
 class _UpsampleField(torch.autograd.Function):
@@ -1014,17 +1029,23 @@ class _Consistency(torch.autograd.Function):
         R = None
         if need_grad and want_edges and K > 1:
             R = torch.empty((N, 2 * (K - 1)) + tuple(pred.shape[2:]), device=pred.device, dtype=torch.float32)
+        # every output exists before the producer runs, and a failure between producer and consumer (the finisher zeroes
+        # the slots again) evicts the shared accumulator instead of leaving partial sums for the next evaluation
+        sums = torch.empty(4, device=pred.device, dtype=torch.float32)
+        value = torch.empty((), device=pred.device, dtype=torch.float32)
         slots = _persistent_zeros("loss", (4, 64), pred.device)   # per-workgroup partials, 64 slots per sum; zeroed by the finisher
-        _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
-                                                        _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
-                                                        int(want_edges), int(want_kl), _stream()), "consistency_fwd")
+        try:
+            _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
+                                                            _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
+                                                            int(want_edges), int(want_kl), _stream()), "consistency_fwd")
+            _lib.check(_lib.load().advchain_consistency_finish(_ptr(slots), _lib.float_array(coef), _ptr(sums), _ptr(value), 1,
+                                                               _stream()), "consistency_finish")
+        except BaseException:
+            _forget_persistent(slots)
+            raise
         if need_grad:
             ctx.save_for_backward(P, D, R, mask)
         ctx.cfg = (coef, mch, int(ref_is_prob))
-        sums = torch.empty(4, device=pred.device, dtype=torch.float32)
-        value = torch.empty((), device=pred.device, dtype=torch.float32)
-        _lib.check(_lib.load().advchain_consistency_finish(_ptr(slots), _lib.float_array(coef), _ptr(sums), _ptr(value), 1,
-                                                           _stream()), "consistency_finish")
         ctx.mark_non_differentiable(sums)
         ctx.set_materialize_grads(False)      # (no zero tensor for the gradient of `sums`)
         return value, sums

@@ -122,21 +122,21 @@ def field_exponentiation(u, nb_steps=8, integration_type="ss"):
 
 
 def demons_compose(duv, dims, final_clamp=True, num_steps=8, smooth_iter=1, sigma=1, smooth=True, init=None,
-                   integration_type="ss"):
+                   integration_type="ss", gaussian_ks=5):
     """Low-res velocity (N,d,v...) -> clamped sampling grid (N,d,*dims).  adv_morph.py:454-491 (Q4).
     ``final_clamp=False`` (test aid) stops before the last torch.clamp of adv_morph.py:490.  num_steps / smooth_iter /
-    sigma: the attributes of adv_morph.py:236-240; ``smooth`` and ``init`` (None = the identity grid, what every call of
+    sigma / gaussian_ks: the attributes of adv_morph.py:236-240; ``smooth`` and ``init`` (None = the identity grid, what every call of
     the reference passes): the arguments of adv_morph.py:454."""
     d = len(dims)
     base = identity_grid(duv.shape[0], dims, duv.device)
     for _ in range(smooth_iter):                                   # adv_morph.py:386-387
-        duv = gaussian_smooth(duv, sigma=sigma)
+        duv = gaussian_smooth(duv, sigma=sigma, kernel_size=gaussian_ks)
     duv = F.interpolate(duv, size=tuple(dims), mode="bilinear" if d == 2 else "trilinear",
                         align_corners=False)
     offsets, _ = field_exponentiation(duv, num_steps, integration_type)
     composed = compose_fields(base if init is None else init, offsets + base)
     if smooth:
-        composed = gaussian_smooth(composed - base, sigma=sigma) + base
+        composed = gaussian_smooth(composed - base, sigma=sigma, kernel_size=gaussian_ks) + base
     return torch.clamp(composed, -1, 1) if final_clamp else composed
 
 

@@ -470,59 +470,119 @@ G6L_CASES = {
     "2d_full_256": dict(sd=2, N=2, dims=(256, 256), names=["noise", "bias", "morph", "affine"], seed=4100),
     "3d_full_64": dict(sd=3, N=1, dims=(64, 64, 32), names=["noise", "bias", "morph", "affine"], seed=4200),
     "3d_morph_40x40x80": dict(sd=3, N=1, dims=(40, 40, 80), names=["morph"], morph_div8=True, seed=4300),
+    # round 4 (VERDICT r3 "parity hygiene"):
+    # cfg-1 at its own size (4 x 1 x 192 x 192, control-point spacing 96, velocity 12 x 12; notebook cell 14 / 18)
+    "2d_cfg1_192": dict(sd=2, N=4, dims=(192, 192), names=["noise", "bias", "morph", "affine"], seed=4400),
+    # the 3D chain where the cfg-3 solver lives after its ascent steps: the velocity is the unit-norm draw x 4 (the norm
+    # three un-normalised ascent steps reach), so that the integrated field moves 2-4 voxels -- the march scatters and the
+    # ring forward sampler of the product, which the sub-voxel 3d_full_64 case never selects
+    "3d_full_64_multivoxel": dict(sd=3, N=1, dims=(64, 64, 32), names=["noise", "bias", "morph", "affine"], seed=4500,
+                                  param_scale={"morph": 4.0}),
+    # two ascent steps at realistic size; every parameter is small enough to be stored in full, so step 2 can be
+    # teacher-forced from the reference's theta_1
+    "2d_bma_256_n2": dict(sd=2, N=2, dims=(256, 256), names=["bias", "morph", "affine"], seed=4600, n_iter=2),
 }
 
 
-def g6l_large(aug):
-    """ONE ascent step + the final consistency pass of the reference at realistic size, from seeded inputs (data and
-    initial parameters are regenerated from the seeds by the tests: tests/helpers.py).  Large tensors are stored as a
-    strided sample plus float64 moments (tests/helpers.sampled_record) so that a fixture stays below 1 MB."""
+G6L_JITTER = [1e-6, 4e-6, 1.6e-5]      # normalised grid units (a 256-px axis: 1.3e-4 ... 2e-3 px)
+
+
+def _g6l_run(aug, c, jitter=None, trial=0):
+    """One run of a g6l case on the reference.  `jitter`: every DemonsCompose output of the morph transform is moved by
+    uniform noise in [-jitter, jitter] where it is strictly inside (-1, 1), and clamped again (the reference's OWN
+    sensitivity to a field difference of that size in front of its final clamp)."""
     import contextlib
     import io
     cls = {"noise": aug.AdvNoise, "bias": aug.AdvBias, "morph": aug.AdvMorph, "affine": aug.AdvAffine}
+    sd, N, dims = c["sd"], c["N"], c["dims"]
+    specs = notebook_configs(dims, N, c["names"], morph_div8=c.get("morph_div8", False))
+    chain = [cls[nm](spatial_dims=sd, config_dict=dict(cfg), use_gpu=False, device=CPU) for nm, cfg in specs]
+    for i, (t, (nm, cfg)) in enumerate(zip(chain, specs)):
+        t.init_parameters()
+        t.param = seeded_init_param(nm, t.param.shape, c["seed"] + 10 + i) * float(c.get("param_scale", {}).get(nm, 1.0))
+    solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
+                                                   divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
+    data = smooth_data(N, 1, dims, c["seed"])
+    model = make_model(sd)
+    steps, losses, fields = [], [], []
+    for ti, t in enumerate(chain):
+        def wrap(t=t, ti=ti, orig=t.optimize_parameters):
+            def f(step_size=None):
+                rec = dict(ti=ti, grad=t.param.grad.detach().clone())
+                r = orig(step_size=step_size)
+                rec["param_out"] = t.param.detach().clone()
+                steps.append(rec)
+                return r
+            return f
+        t.optimize_parameters = wrap()
+        if t.get_name() == "morph":
+            def demons(*a, t=t, orig=t.DemonsCompose, **k):
+                q = orig(*a, **k)
+                if not fields:
+                    fields.append(q.detach().clone())       # the first field of the run: +epsilon * theta_0
+                if jitter:
+                    g = torch.Generator().manual_seed(100000 * trial + len(fields) + 7919 * demons.calls)
+                    # DemonsCompose ends with clamp(-1, 1) (adv_morph.py:490): another implementation's field differs BEFORE
+                    # that clamp, so a coordinate pinned to exactly +-1 stays pinned (it lay beyond the border; moving it
+                    # inside by 1e-7 would flip the solver's `!= 0` validity mask on whole border faces, Q12 -- measured:
+                    # 338 voxels, 1.5 % of the loss) and the others are re-clamped
+                    noise = (torch.rand(q.shape, generator=g) * 2 - 1) * jitter
+                    q = torch.where(q.abs() < 1, torch.clamp(q + noise, -1, 1), q)
+                demons.calls += 1
+                return q
+            demons.calls = 0
+            t.DemonsCompose = demons
+    orig_loss = solver.loss_fn
+
+    def loss_rec(pred, reference, mask=None):
+        v = orig_loss(pred=pred, reference=reference, mask=mask)
+        losses.append(float(v.detach()))
+        return v
+    solver.loss_fn = loss_rec
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = solver.adversarial_training(data=data, model=model, n_iter=c.get("n_iter", 1), lazy_load=True, step_sizes=1)
+    return dict(chain=chain, specs=specs, solver=solver, steps=steps, losses=losses, loss=loss, fields=fields)
+
+
+def g6l_large(aug):
+    """ONE ascent step (n_iter of the case) + the final consistency pass of the reference at realistic size, from seeded
+    inputs (data and initial parameters are regenerated from the seeds by the tests: tests/helpers.py).  Large tensors are
+    stored as a strided sample plus float64 moments (tests/helpers.sampled_record) so that a fixture stays below 1 MB.
+    Cases with an AdvMorph also store (a) a sample of the first deformation field and (b) PER COEFFICIENT, how far the
+    reference's own first-step velocity gradient moves when its fields are jittered by G6L_JITTER (max over 3 trials):
+    the derivative of a (tri)linear interpolant jumps at grid nodes, so single coefficients of that gradient are
+    sensitive to field differences far below the 2e-5 the fields themselves are held to (tests/golden/g8_kinks.npz)."""
     for tag, c in G6L_CASES.items():
         if ONLY and not any(o in ("g6l", "g6l_" + tag) for o in ONLY):
             continue
         sd, N, dims = c["sd"], c["N"], c["dims"]
-        specs = notebook_configs(dims, N, c["names"], morph_div8=c.get("morph_div8", False))
-        chain = [cls[nm](spatial_dims=sd, config_dict=dict(cfg), use_gpu=False, device=CPU) for nm, cfg in specs]
-        for i, (t, (nm, cfg)) in enumerate(zip(chain, specs)):
-            t.init_parameters()
-            t.param = seeded_init_param(nm, t.param.shape, c["seed"] + 10 + i)
-        solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=chain, use_gpu=False, debug=False,
-                                                       divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
-        data = smooth_data(N, 1, dims, c["seed"])
-        model = make_model(sd)
-        steps, losses = [], []
-        for ti, t in enumerate(chain):
-            def wrap(t=t, ti=ti, orig=t.optimize_parameters):
-                def f(step_size=None):
-                    rec = dict(ti=ti, grad=t.param.grad.detach().clone())
-                    r = orig(step_size=step_size)
-                    rec["param_out"] = t.param.detach().clone()
-                    steps.append(rec)
-                    return r
-                return f
-            t.optimize_parameters = wrap()
-        orig_loss = solver.loss_fn
-
-        def loss_rec(pred, reference, mask=None):
-            v = orig_loss(pred=pred, reference=reference, mask=mask)
-            losses.append(float(v.detach()))
-            return v
-        solver.loss_fn = loss_rec
-        with contextlib.redirect_stdout(io.StringIO()):
-            loss = solver.adversarial_training(data=data, model=model, n_iter=1, lazy_load=True, step_sizes=1)
-        assert len(steps) == len(chain)
+        run = _g6l_run(aug, c)
+        chain, specs, solver, steps, losses, loss = (run[k] for k in ("chain", "specs", "solver", "steps", "losses", "loss"))
+        n_it = c.get("n_iter", 1)
+        assert len(steps) == n_it * len(chain)
         out = dict(meta=dict(spatial_dims=sd, batch=N, dims=list(dims), names=c["names"], morph_div8=c.get("morph_div8", False),
-                             seed=c["seed"], chain=[dict(name=nm, config=cfg) for nm, cfg in specs]),
+                             seed=c["seed"], chain=[dict(name=nm, config=cfg) for nm, cfg in specs], n_iter=n_it,
+                             param_scale=c.get("param_scale", {}), jitter_levels=G6L_JITTER),
                    loss_trace=np.array(losses, dtype=np.float64), final_loss=loss.detach().double())
         recs = dict(adv_data=solver.adv_data, init_output=solver.init_output, warped_back=solver.warped_back_adv_output)
-        for rec in steps:
-            recs["grad_%d" % rec["ti"]] = rec["grad"]
-            recs["param_out_%d" % rec["ti"]] = rec["param_out"]
+        for j, rec in enumerate(steps):      # step 0 keeps the round-3 key names; later steps carry a suffix _s<k>
+            sfx = "" if j < len(chain) else "_s%d" % (j // len(chain))
+            recs["grad_%d%s" % (rec["ti"], sfx)] = rec["grad"]
+            recs["param_out_%d%s" % (rec["ti"], sfx)] = rec["param_out"]
         for i, t in enumerate(chain):
             recs["final_param_%d" % i] = t.param
+        if "morph" in c["names"]:
+            mi = c["names"].index("morph")
+            recs["morph_field"] = run["fields"][0]
+            base = steps[mi]["grad"]
+            for lvl, amp in enumerate(G6L_JITTER):
+                spread = torch.zeros_like(base)
+                for trial in range(3):
+                    pert = _g6l_run(aug, dict(c, n_iter=1), jitter=amp, trial=trial + 1)["steps"][mi]["grad"]
+                    spread = torch.maximum(spread, (pert - base).abs())
+                out["morph_grad_spread_%d" % lvl] = spread
+                print("  %s: reference morph-gradient spread at field jitter %g: max %.2e of scale, %d of %d coefficients above 1e-4"
+                      % (tag, amp, float(spread.max() / base.abs().max()), int((spread > 1e-4 * base.abs().max()).sum()), spread.numel()))
         for k, v in recs.items():
             for kk, vv in sampled_record(v).items():
                 out[k + "__" + kk] = vv
@@ -898,11 +958,6 @@ def g10_demons_args(aug):
     (adv_morph.py:236-242,454-491): num_steps, smooth_iter, sigma (9-tap and other windows), smooth=False and an initial
     deformation other than the identity.  Per case: the velocity, the returned grid, d(sum(grid * w))/d(velocity) and, for
     the initial deformation, d/d(init)."""
-    out, meta = {}, {}
-    shapes = {
-        "2d": dict(spatial_dims=2, data_size=[2, 1, 24, 40], vector_size=[3, 5]),
-        "3d": dict(spatial_dims=3, data_size=[1, 1, 12, 10, 14], vector_size=[3, 2, 4]),
-    }
     variants = {
         "default": dict(),
         "steps6": dict(num_steps=6),
@@ -920,6 +975,30 @@ def g10_demons_args(aug):
         "euler": dict(integration_type="euler", only=2),
         "euler_steps5_nosmooth": dict(integration_type="euler", num_steps=5, smooth=False, only=2),
     }
+    _g10_cases(aug, variants, 0, "g10_demons_args")
+
+
+_G10_ATTRS = ("num_steps", "smooth_iter", "sigma", "integration_type", "gaussian_ks")
+
+
+def g10b_gauss_window(aug):
+    """The Gaussian window rule of adv_morph.py:393-398 where `gaussian_ks` (default 5) decides, not 2 int(4 sigma + 0.5) + 1:
+    sigma = 0.3 (rule: 3 taps -> the reference keeps its 5) and a user-set gaussian_ks = 11 / 7 above the rule's 9 / 5."""
+    variants = {
+        "sigma03": dict(sigma=0.3),
+        "ks11": dict(gaussian_ks=11),
+        "ks7_sigma05_iter2_nosmooth": dict(gaussian_ks=7, sigma=0.5, smooth_iter=2, smooth=False),
+        "ks9_default_window": dict(gaussian_ks=9),
+    }
+    _g10_cases(aug, variants, 5000, "g10b_gauss_window")
+
+
+def _g10_cases(aug, variants, seed, name):
+    out, meta = {}, {}
+    shapes = {
+        "2d": dict(spatial_dims=2, data_size=[2, 1, 24, 40], vector_size=[3, 5]),
+        "3d": dict(spatial_dims=3, data_size=[1, 1, 12, 10, 14], vector_size=[3, 2, 4]),
+    }
     i = 0
     for stag, c in shapes.items():
         for vtag, v in variants.items():
@@ -928,32 +1007,97 @@ def g10_demons_args(aug):
                 continue
             cfg = dict(epsilon=1.5, data_size=c["data_size"], vector_size=c["vector_size"])
             t = aug.AdvMorph(spatial_dims=c["spatial_dims"], config_dict=cfg, use_gpu=False, device=CPU)
-            torch.manual_seed(4100 + i)
+            torch.manual_seed(seed + 4100 + i)
             t.init_parameters()
-            for a in ("num_steps", "smooth_iter", "sigma", "integration_type"):
+            for a in _G10_ATTRS:
                 if a in v:
                     setattr(t, a, v[a])
-            p = t.unit_normalize(rand(tuple(t.param.shape), 4200 + i)).detach().requires_grad_(True)
+            p = t.unit_normalize(rand(tuple(t.param.shape), seed + 4200 + i)).detach().requires_grad_(True)
             base = t.base_grid.detach().clone()
             if v.get("init"):      # a smooth deformation of the identity that stays inside [-1, 1]
                 d = c["spatial_dims"]
-                low = rand((c["data_size"][0], d) + tuple([4] * d), 4300 + i)
+                low = rand((c["data_size"][0], d) + tuple([4] * d), seed + 4300 + i)
                 bump = F.interpolate(low, size=tuple(c["data_size"][2:]), mode="bilinear" if d == 2 else "trilinear",
                                      align_corners=True)
                 init = (0.9 * base + 0.08 * bump).contiguous().requires_grad_(True)
             else:
                 init = base
-            w = rand(tuple(base.shape), 4400 + i)
+            w = rand(tuple(base.shape), seed + 4400 + i)
             dxy = t.DemonsCompose(duv=t.epsilon * p, init_deformation_dxy=init, smooth=v.get("smooth", True))
             (dxy * w).sum().backward()
             key = "%s_%s_" % (stag, vtag)
-            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, attrs={a: v[a] for a in ("num_steps", "smooth_iter", "sigma", "integration_type") if a in v},
+            meta[key] = dict(spatial_dims=c["spatial_dims"], config=cfg, attrs={a: v[a] for a in _G10_ATTRS if a in v},
                              smooth=v.get("smooth", True), init=bool(v.get("init")))
             out.update({key + "param": p.detach(), key + "w": w, key + "dxy": dxy.detach(), key + "grad_param": p.grad.clone()})
             if v.get("init"):
                 out.update({key + "init": init.detach(), key + "grad_init": init.grad.clone()})
     out["meta"] = meta
-    save("g10_demons_args", out)
+    save(name, out)
+
+
+
+# ----------------------------------------------------------------------------- G11
+def g11_padding(aug):
+    """The f3 branches: image_padding_mode 'lowest' (N = 1: the reference's (N, 1) minimum only broadcasts
+    there), a number, 'border', 'reflection' x bilinear / nearest x forward / backward for AdvMorph and AdvAffine
+    (adv_morph.py:542-557, adv_affine.py:299-313), and get_adv_data(n_iter=0) with injected parameters
+    (adv_compose_solver.py:435-463).  Inputs come from seeds (the tests regenerate them: same geometry and seeds as
+    tests/test_solver_gpu.py::test_padding_modes_and_get_adv_data); the fixture stores the parameters and the outputs."""
+    out, meta = {}, {}
+    for sd in (2, 3):
+        dims = (24, 32) if sd == 2 else (8, 12, 16)
+
+        def cfgs(N):
+            ds = [N, 1] + list(dims)
+            mcfg = dict(epsilon=1.5, data_size=ds, vector_size=[max(2, s // 8) for s in dims])
+            acfg = (dict(rot=30 / 180., scale_x=0.2, scale_y=0.2, shift_x=0.1, shift_y=0.1, data_size=ds) if sd == 2 else
+                    dict(rot_x=0.05, rot_y=0.05, rot_z=0.05, scale_x=0.1, scale_y=0.1, scale_z=0.1, shift_x=0.1, shift_y=0.1,
+                         shift_z=0.1, data_size=ds))
+            return mcfg, acfg
+        for pad, N in (("lowest", 1), (0.25, 2), ("border", 2), ("reflection", 2)):
+            mcfg, acfg = cfgs(N)
+            data = smooth_data(N, 1, dims, 5) + 0.3          # minimum well above 0: 'lowest' differs from 'zeros'
+            tm = aug.AdvMorph(spatial_dims=sd, config_dict=mcfg, use_gpu=False, device=CPU, image_padding_mode=pad)
+            ta = aug.AdvAffine(spatial_dims=sd, config_dict=acfg, use_gpu=False, device=CPU, image_padding_mode=pad)
+            tm.init_parameters(); ta.init_parameters()
+            pm = tm.unit_normalize(rand((N, sd) + tuple(mcfg["vector_size"]), 6))
+            pa = 0.7 * rand((N, 5 if sd == 2 else 9), 7)
+            tag = "%dd_%s_" % (sd, str(pad).replace(".", "p"))
+            meta[tag] = dict(spatial_dims=sd, pad=pad, N=N, dims=list(dims), morph=mcfg, affine=acfg)
+            for name, t, p in (("morph", tm, pm), ("affine", ta, pa)):
+                t.param = p.clone()
+                t.train()             # the training-mode paths apply epsilon * param, as in the solver's inner loop
+                out[tag + name + "_param"] = p
+                with torch.no_grad():
+                    for interp in ("bilinear", "nearest"):
+                        out[tag + name + "_fwd_" + interp] = t.forward(data, interp=interp).clone()
+                        out[tag + name + "_bwd_" + interp] = t.backward(data, interp=interp).clone()
+        # data generation, no optimisation: init_random_transformation() is made to "draw" the stored parameters
+        mcfg, acfg = cfgs(2)
+        for pad_tag, kw in (("zeros", {}), ("lowest1", dict(image_padding_mode="lowest"))):
+            N = 1 if pad_tag == "lowest1" else 2
+            mcfg, acfg = cfgs(N)
+            data = smooth_data(N, 1, dims, 5) + (0.3 if kw else 0.0)
+            tm = aug.AdvMorph(spatial_dims=sd, config_dict=mcfg, use_gpu=False, device=CPU, **kw)
+            ta = aug.AdvAffine(spatial_dims=sd, config_dict=acfg, use_gpu=False, device=CPU, **kw)
+            tm.init_parameters(); ta.init_parameters()
+            pm = tm.unit_normalize(rand((N, sd) + tuple(mcfg["vector_size"]), 16))
+            pa = 0.7 * rand((N, 5 if sd == 2 else 9), 17)
+            for t, p in ((tm, pm), (ta, pa)):
+                def inject(t=t, p=p, orig=t.init_parameters):
+                    orig()                    # (re-reads the config, as the reference's own call does)
+                    t.param = p.clone()
+                    return t.param
+                t.init_parameters = inject
+            solver = aug.ComposeAdversarialTransformSolver(chain_of_transforms=[tm, ta], use_gpu=False, debug=False)
+            model = make_model(sd)
+            adv, lab = solver.get_adv_data(data, model, n_iter=0)
+            tag = "%dd_getadv_%s_" % (sd, pad_tag)
+            meta[tag] = dict(spatial_dims=sd, N=N, dims=list(dims), morph=mcfg, affine=acfg, kwargs=kw, data_offset=0.3 if kw else 0.0)
+            out.update({tag + "morph_param": pm, tag + "affine_param": pa, tag + "adv_data": adv.detach(),
+                        tag + "adv_label": lab.detach()})
+    out["meta"] = meta
+    save("g11_padding", out)
 
 
 ONLY = []
@@ -993,6 +1137,10 @@ def main():
         g7_misc(aug)
     if want("g10"):
         g10_demons_args(aug)
+    if want("g10b"):
+        g10b_gauss_window(aug)
+    if want("g11"):
+        g11_padding(aug)
     if want("g8"):
         g8_kinks(aug)
     if want("g9"):

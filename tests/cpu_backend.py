@@ -75,16 +75,17 @@ def bias_field_only(cp, tables, eps, use_log=True, cp_scale=1.0):
 
 def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     """adv_morph.py:454-491 without the final clamp; the 3D step-count norm may be reduced across ranks.
-    opts = (num_steps, smooth_iter, sigma, positions_only) as in advchain_amd.ops._DemonsField."""
-    n, smooth_iter, sigma, pos_only = opts if opts is not None else (8, 1, 1.0, False)
-    if 2 * int(4 * sigma + 0.5) + 1 != 9:
+    opts = (num_steps, smooth_iter, sigma, positions_only[, taps]) as in advchain_amd.ops._DemonsField."""
+    n, smooth_iter, sigma, pos_only = tuple(opts)[:4] if opts is not None else (8, 1, 1.0, False)
+    taps = opts[4] if (opts is not None and len(opts) > 4) else 2 * int(4 * sigma + 0.5) + 1
+    if taps != 9 and not pos_only:
         raise NotImplementedError("9-tap window only")
     dims = tuple(tables.full_dims)
     d = len(dims)
     base = O.identity_grid(vel.shape[0], dims)
     u = scale * vel
     for _ in range(smooth_iter):
-        u = O.gaussian_smooth(u, sigma=sigma)
+        u = O.gaussian_smooth(u, sigma=sigma, kernel_size=taps)
     u = F.interpolate(u, size=dims, mode="bilinear" if d == 2 else "trilinear", align_corners=False)
     if nsteps_rule:
         ss = (u.detach().double() ** 2).sum().float().reshape(1)
@@ -100,7 +101,7 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     if pos_only:
         return (phi - phi0) + base
     composed = O.compose_fields(base, (phi - phi0) + base)
-    return O.gaussian_smooth(composed - base, sigma=sigma) + base
+    return O.gaussian_smooth(composed - base, sigma=sigma, kernel_size=taps) + base
 
 
 def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
@@ -108,8 +109,8 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=N
             demons_field(vel, -scale, tables, nsteps_rule, reduce_sumsq, opts))
 
 
-def gauss_smooth(x, sigma=1.0):
-    return O.gaussian_smooth(x, sigma=sigma)
+def gauss_smooth(x, sigma=1.0, taps=None):
+    return O.gaussian_smooth(x, sigma=sigma, kernel_size=5 if taps is None else taps)
 
 
 def upsample_field(coef, tables, scale):

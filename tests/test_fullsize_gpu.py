@@ -159,9 +159,10 @@ def test_march_scatter_agrees_with_the_window_scatter_at_full_size(shape, amp, b
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_whole_solver_call_at_full_size(name):
-    """One adversarial_training call of every BASELINE config at its full per-GPU size (cfg-4: 8x1x128x128x64 full chain
+    """One adversarial_training call of every BASELINE config at its full per-GPU size (cfg-1: 4x1x192x192, 1 step -- also
+    pinned on the reference itself at that size: tests/golden/g6l_2d_cfg1_192.npz; cfg-4: 8x1x128x128x64 full chain
     with 3D noise, 5 steps; cfg-5: 4x1x160x160x80 morph-only, rows of 80, 10 steps + the anatomy ladder)."""
     import contextlib
     import io

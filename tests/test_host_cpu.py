@@ -208,6 +208,53 @@ def test_nan_guard_skips_the_update(cpu_ops):
     assert maxdiff(t.param, O_unit(before)) < 1e-6  # no ascent step; only the final rescale (unit L2) happened
 
 
+def test_device_nan_guard_is_for_the_built_in_updates_only(cpu_ops):
+    """a subclass that overrides optimize_parameters() may never hand `_gate` to the gated kernels -- it must get
+    the reference's host-side check (adv_compose_solver.py:343-347); and the gate is cleared even when the step raises."""
+    from advchain_amd.augmentor import AdvNoise
+    from advchain_amd.augmentor.adv_compose_solver import ComposeAdversarialTransformSolver, _native_update
+    ds = [2, 1, 8, 8]
+    cfg = dict(epsilon=1.0, xi=1e-6, data_size=ds)
+
+    class OwnStep(AdvNoise):
+        def optimize_parameters(self, step_size=None):
+            self.param = (self.param + 1.0).detach()
+
+    class Plain(AdvNoise):
+        pass
+
+    a, b, c = AdvNoise(2, cfg, device=CPU), OwnStep(2, cfg, device=CPU), Plain(2, cfg, device=CPU)
+    assert _native_update(a) and _native_update(c) and not _native_update(b)
+
+    class Raises(AdvNoise):
+        def optimize_parameters(self, step_size=None):
+            assert self._gate is not None
+            raise RuntimeError("boom")
+
+    class FakeCuda(torch.Tensor):      # a CPU tensor that claims to live on the GPU: the device-guard branch on this box
+        is_cuda = True
+
+    t = Raises(2, cfg, device=CPU)
+    t.optimize_parameters = AdvNoise.optimize_parameters.__get__(t)       # instance attribute: the CLASS still overrides
+    assert not _native_update(t)
+    t2 = AdvNoise(2, cfg, device=CPU)
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=[t2], divergence_types=["mse"], divergence_weights=[1.0])
+    solver._global_value = lambda d: d.as_subclass(FakeCuda)
+    t2.init_parameters()
+    boom = {"n": 0}
+
+    def failing_backward(dist, flags):
+        boom["n"] += 1
+        assert t2._gate is not None           # the gate is armed while the step runs ...
+        raise RuntimeError("backward failed")
+    solver._backward_to_transforms = failing_backward
+    data = torch.rand(*ds)
+    with pytest.raises(RuntimeError, match="backward failed"):
+        solver.optimizing_transform(model=make_model(2), data=data, init_output=make_model(2)(data).detach(),
+                                    optimize_flags=[True], n_iter=1, step_sizes=[1])
+    assert boom["n"] == 1 and t2._gate is None      # ... and cleared although the step raised
+
+
 def O_unit(x):
     from oracle import advchain_oracle as O
     return O.unit_normalize(x)

@@ -688,6 +688,51 @@ def test_affine_warp(dims, C, pad):
     assert float((n_out.cpu() != n_ref).float().mean()) < 2e-3  # rounding ties at .5 may differ by fp order
 
 
+@pytest.mark.parametrize("dims", [(64, 96), (32, 40, 64)])
+def test_affine_gin_high_dynamic_range(dims):
+    """grad_in of the affine warp through the LDS box (k_affine_box_gin, affine_box.hip) accumulates in 32-bit fixed point
+    scaled by the largest |grad_out| of the tile's sample box: the ABSOLUTE error of a cell is bounded by
+    n_corners * gmax / 2^30 per deposit (documented in INTEGRATION.md) whatever the dynamic range -- here a 1e-5 background
+    under isolated spikes of 1 -- and the cells a spike does not share a box with keep fp32 relative precision.  Against
+    float64 autograd on the CPU."""
+    ops = _ops()
+    d = len(dims)
+    g = torch.Generator().manual_seed(11)
+    N, C = 2, 4
+    x = torch.rand(N, C, *dims, generator=g)
+    w = 1e-5 * (torch.rand(N, C, *dims, generator=g) + 0.5)
+    spikes = torch.rand(N, C, *dims, generator=g) > 0.9995
+    w[spikes] = 1.0
+    theta = torch.eye(d, d + 1).repeat(N, 1, 1) + 0.05 * torch.randn(N, d, d + 1, generator=g)
+    xd = x.double().requires_grad_(True)
+    out = F.grid_sample(xd, F.affine_grid(theta.double(), xd.size(), align_corners=True), align_corners=True)
+    (out * w.double()).sum().backward()
+    ref = xd.grad
+    xg = x.to(DEV).requires_grad_(True)
+    (ops.affine_warp(xg, theta.to(DEV)) * w.to(DEV)).sum().backward()
+    err = (xg.grad.cpu().double() - ref).abs()
+    n_corner = 2 ** d
+    # every deposit rounds to the quantum n_max * gmax / 2^30 (n_max <= 27 samples per cell in 3D, 9 in 2D), 2^d deposits
+    # per sample and a handful of samples per cell; + the fp32 rounding of the sampling positions on the spikes themselves
+    assert float(err.max()) < 64 * (3 ** d) * n_corner / 2.0 ** 30 + 2e-6, float(err.max())
+    # background cells: absolute error far below the background's own magnitude (1e-5) -- it is NOT flushed to zero
+    bg = ref.abs() < 1e-4
+    assert float(err[bg].mean()) < 2e-7, float(err[bg].mean())
+    assert float((xg.grad.cpu()[bg] != 0).float().mean()) > 0.9
+
+
+def test_grid_sample_onto_a_single_voxel():
+    """only the GATHERED tensor needs two voxels (paired corner gathers); a resampling warp may produce one."""
+    ops = _ops()
+    inp = rand((2, 3, 6, 7), 5)
+    grid = rand((2, 1, 1, 2), 6)
+    ref = F.grid_sample(inp, grid, align_corners=True)
+    out = ops.raw_grid_sample_fwd(inp.to(DEV), to_planar(grid).to(DEV), 0, 0, False)
+    assert out.shape == ref.shape and maxdiff(out.cpu(), ref) < TOL
+    with pytest.raises(Exception):
+        ops.raw_grid_sample_fwd(torch.zeros(1, 1, 1, 1, device=DEV), to_planar(grid[:1]).to(DEV), 0, 0, False)
+
+
 @pytest.mark.parametrize("dims,C", [((17, 23), 3), ((32, 40), 1), ((64, 48), 4)])
 @pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
 def test_bicubic_grid_sample_and_affine_warp(dims, C, pad):
@@ -919,14 +964,16 @@ def test_demons_field_golden():
             assert err < (3e-3 if big else 1e-4), (key, sgn, err)
 
 
-def test_demons_compose_arguments_golden():
-    """G10: AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults --
+@pytest.mark.parametrize("fixture", ["g10_demons_args", "g10b_gauss_window"])
+def test_demons_compose_arguments_golden(fixture):
+    """G10 (g10b: the windows `gaussian_ks` decides -- sigma = 0.3 keeps the 5 taps of gaussian_ks, gaussian_ks = 11 / 7
+    above the rule, adv_morph.py:393-398): AdvMorph.DemonsCompose with the arguments / attributes the reference's own calls leave at their defaults --
     num_steps, smooth_iter, sigma (the 9-tap window of the fused kernels and others: 5 / 17 taps through the plain K-tap
     Gaussian), smooth=False, an initial deformation other than the identity (adv_morph.py:236-242,454-491) -- against the
     reference's grids and gradients, Euler steps instead of scaling and squaring (2D; in 3D the reference's loop raises a
     TypeError and so does this); forward() / _field honour the same attributes; windows beyond 129 taps raise."""
     from advchain_amd.augmentor import AdvMorph
-    fx = Fixture("g10_demons_args")
+    fx = Fixture(fixture)
     for key, m in fx.json().items():
         t = AdvMorph(spatial_dims=m["spatial_dims"], config_dict=m["config"], device=torch.device(DEV))
         t.init_parameters()
