@@ -181,12 +181,10 @@ k_grid_sample_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
 //                  'integrated_offsets + base_grid' of adv_morph.py:143,176 + 474,483; Q1 aliasing)
 // =============================================================================================
 template <int DIM, int VEC>
-__global__ void __launch_bounds__(kBlock)
-k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
-                   Dims d, int final_mode, float* __restrict__ disp_out) {
+__device__ __forceinline__ void
+compose_self_fwd_body(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
+                      const Dims& d, int final_mode, float* __restrict__ disp_out, int n, int64_t v) {
   const int64_t V = d.voxels();
-  const int n = blockIdx.y;
-  const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
   const int na = active_count(v, V, VEC);
   if (na == 0) return;
   const float* pn = phi + (int64_t)n * DIM * V;
@@ -253,6 +251,27 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
     }
     wave_max_to_slots(dmax, disp_out);
   }
+}
+
+template <int DIM, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
+                   Dims d, int final_mode, float* __restrict__ disp_out) {
+  compose_self_fwd_body<DIM, VEC>(phi, out, phi0, d, final_mode, disp_out, blockIdx.y,
+                                  (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x);
+}
+
+// The same squaring as a REPEAT behind the fused kernel of expo_fused2d.hip: that kernel has normally produced `out`
+// already, and raises *gate only when one of its windows moved too far for its sub-pixel premise.  While the flag is down
+// the launch returns at once -- a small grid-stride grid (nbx workgroups' worth of work on gridDim.x workgroups), so that
+// returning costs a microsecond, not the dispatch of thousands of workgroups.
+template <int DIM, int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_compose_self_fwd_gated(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
+                         Dims d, int final_mode, float* __restrict__ disp_out, const float* __restrict__ gate, int nbx) {
+  if (*gate == 0.f) return;
+  for (int b = blockIdx.x; b < nbx; b += gridDim.x)
+    compose_self_fwd_body<DIM, VEC>(phi, out, phi0, d, final_mode, disp_out, blockIdx.y, (int64_t)b * (kBlock * VEC) + threadIdx.x);
 }
 
 // gphi must be zero-initialised by the caller (scatter target).
@@ -730,6 +749,8 @@ bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const
                                     int64_t N, int64_t C, int ndim, Dims d, hipStream_t st);
 
 // sample_march.hip: two squarings per launch (f1 experiment, ADVCHAIN_FUSE2)
+int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, float* disp_rows,
+                                     float* fail_flag, hipStream_t stream);
 int advchain_compose2_march_launch(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
                                    hipStream_t st);
 
@@ -900,8 +921,10 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
 
-int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
-                              const int64_t* dims, int final_mode, float* disp_out, void* stream) {
+// gate != nullptr: a repeat of a squaring the fused kernel (expo_fused2d.hip) has normally done already -- direct kernels
+// only, each returning at once while *gate == 0
+static int compose_self_fwd_impl(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
+                                 const int64_t* dims, int final_mode, float* disp_out, const float* gate, void* stream) {
   const int disp_hint = (final_mode >> 8) & 0xff;   // bits 8..15: displacement estimate of phi in voxels (0 = unknown), a performance hint
   final_mode &= 0xff;
   ADVCHAIN_CHECK_ARG(phi && out && phi != out, "compose_self_fwd: null/aliased pointer");
@@ -912,13 +935,22 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
-  {
+  if (!gate) {
     const int rc = advchain_sample_tiled_launch(true, phi, nullptr, out, phi0, N, ndim, ndim, d, PAD_BORDER, 0,
                                                 final_mode, 0, disp_out, (hipStream_t)stream, disp_hint);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   const bool vec4 = use_unroll(V, ndim);
   hipStream_t st = (hipStream_t)stream;
+  if (gate) {      // a repeat behind the fused 2D kernel: returns at once while the flag is down
+    ADVCHAIN_CHECK_ARG(ndim == 2 && final_mode == 0, "compose_self_fwd: gated repeats are 2D, not final");
+    const int nbx = advchain_blocks(V, kBlock * 2);
+    const int per = (int)((1024 + N - 1) / N);          // ~1024 workgroups in all
+    dim3 gg((unsigned)(nbx < per ? nbx : per), (unsigned)N);
+    hipLaunchKernelGGL((k_compose_self_fwd_gated<2, 2>), gg, dim3(kBlock), 0, st, phi, out, phi0, d, final_mode, disp_out, gate, nbx);
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   // 2D: two voxels per thread (twice the waves of the 4-voxel form at fewer registers: 12.0 against 13.4 us per cfg-2
   // squaring once the gathers are issued together); ADVCHAIN_UNR4 / ADVCHAIN_UNR1 force the other forms
   static const bool unr2 = getenv("ADVCHAIN_UNR4") == nullptr && getenv("ADVCHAIN_UNR1") == nullptr;
@@ -938,6 +970,11 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
+}
+
+int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
+                              const int64_t* dims, int final_mode, float* disp_out, void* stream) {
+  return compose_self_fwd_impl(phi, out, phi0, N, ndim, dims, final_mode, disp_out, nullptr, stream);
 }
 
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
@@ -1032,7 +1069,7 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
 // ---- the whole scaling-and-squaring chain in one call (the same launches as n calls of the two entries above; the host
 // side of a solver step is as long as its GPU side, and a chain is 2 x n of its ~700 launches)
 int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_t N, int ndim, const int64_t* dims, int n,
-                            float* disp_rows, const int32_t* hints, void* stream) {
+                            float* disp_rows, const int32_t* hints, float* fuse_flag, void* stream) {
   ADVCHAIN_CHECK_ARG(phi0 && pos && n >= 1 && n <= 64 && (n == 1 || fields), "expo_chain_fwd: null pointer / bad n");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_fwd: bad dims");
   const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
@@ -1040,6 +1077,21 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   // f1 experiment: ADVCHAIN_FUSE2=1 fuses pairs of squarings whose hints say "below one voxel" (phi_m and phi_m+1), =2 the
   // first three pairs whatever the hints say (results do not depend on it: lanes beyond the ring fall back)
   static const int fuse2 = getenv("ADVCHAIN_FUSE2") ? atoi(getenv("ADVCHAIN_FUSE2")) : 0;
+  // 2D: the leading squarings whose inputs the hints put below one pixel run as ONE launch (expo_fused2d.hip: whole-row LDS
+  // windows, bit-identical fields).  The kernel verifies the premise itself and raises *fuse_flag when a window moves too
+  // far; the ordinary launches of those squarings follow it, gated on the flag (they return at once while it is down).
+  static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 4;   // A/B knob (0 = off)
+  int fused = 0;
+  if (ndim == 2 && fuse_flag && hints && fuse_max >= 2) {
+    int k = 0;
+    while (k < n - 1 && k < fuse_max && (hints[k] & 0xff) == 1) ++k;
+    if (k >= 2) {
+      const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, disp_rows, fuse_flag,
+                                                      (hipStream_t)stream);
+      if (rf == ADVCHAIN_OK) fused = k;
+      else if (rf != ADVCHAIN_ERR_UNSUPPORTED) return rf;
+    }
+  }
   for (int m = 0; m + 1 < n; ++m) {
     if (fuse2 && ndim == 3 && m + 2 < n &&
         (fuse2 >= 2 ? m < 6 : (hints && (hints[m] & 0xff) == 1 && (hints[m + 1] & 0xff) == 1))) {
@@ -1053,8 +1105,9 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
       if (rc2 != ADVCHAIN_ERR_UNSUPPORTED) return rc2;
     }
     float* dst = fields + (int64_t)m * F;
-    const int rc = advchain_compose_self_fwd(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
-                                             disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, stream);
+    const int rc = compose_self_fwd_impl(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
+                                         disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr,
+                                         m < fused ? fuse_flag : nullptr, stream);
     if (rc != ADVCHAIN_OK) return rc;
     src = dst;
   }

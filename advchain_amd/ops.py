@@ -146,6 +146,7 @@ DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
 ADAPTIVE_HALO = os.environ.get("ADVCHAIN_NO_ADAPTIVE_HALO") is None   # measure the displacement in forward and size the backward halos from it
 PAIR_FIELDS = os.environ.get("ADVCHAIN_NO_PAIR_FIELDS") is None       # a solver step integrates field(+v) and field(-v) as one batch
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
+FUSE_2D = True        # the leading sub-pixel squarings of a 2D chain in one launch (expo_fused2d.hip); False: A/B tests
 
 
 def _scatter_workspace(N, dims, device):
@@ -846,7 +847,9 @@ class _DemonsField(torch.autograd.Function):
         # row m of `disp`: max-slots for the displacement of phis[m], written by the kernel that produces it; row n: the
         # sampling positions `pos`, which bound the returned grid (clipping to [-1,1] and the normalised Gaussian only
         # shrink a displacement).  Read back once (asynchronously): the backward sizes every step exactly from it.
-        disp = _persistent_zeros("disp", (n + 1, DISP_SLOTS), vel.device) if ADAPTIVE_HALO else None
+        # (row n + 1, slot 0: the flag of the fused 2D squarings -- 1 when a window moved too far for them and the ordinary
+        # launches ran instead; zeroed with the rest by the row-maxima kernel below)
+        disp = _persistent_zeros("disp", (n + 2, DISP_SLOTS), vel.device) if ADAPTIVE_HALO else None
         row = (lambda m: None) if disp is None else (lambda m: disp[m])
         # what the squarings of the PREVIOUS field of this shape measured (a field changes little between two ascent
         # steps): picks the forward kernel per squaring, nothing else
@@ -858,7 +861,8 @@ class _DemonsField(torch.autograd.Function):
         pos = torch.empty_like(phi0)
         harr = None if hints is None else (ctypes.c_int32 * n)(*[_hint_bits(hints[m]) >> 8 for m in range(n)])
         _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
-                                                       _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr, _stream()),
+                                                       _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
+                                                       None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
                    "expo_chain_fwd")
         q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
         ctx.save_for_backward(pos, phi0, fields)

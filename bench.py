@@ -180,8 +180,42 @@ def solver_kwargs(wl, device):
     return kw
 
 
+class _ModelTimer(object):
+    """HIP events around every call of the user's model inside a step -- the forward passes (get_init_output, every ascent
+    step, the final pass) and the input-gradient backward of every ascent step -- on the stream the step runs on.  Used in
+    a separate instrumented pass AFTER the timed region (same process, same tensors), so that the timed steps carry no
+    extra events: model_ms = GPU time between those events per step; path_ms = step time - model_ms."""
+
+    def __init__(self, model):
+        self.model, self.pairs, self.handles = model, [], []
+
+    def __enter__(self):
+        def pre(*_):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._open = e
+
+        def post(*_):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs.append((self._open, e))
+        m = self.model
+        self.handles = [m.register_forward_pre_hook(pre), m.register_forward_hook(post),
+                        m.register_full_backward_pre_hook(pre), m.register_full_backward_hook(post)]
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+
+    def total_ms(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.pairs)
+
+
 def run_gpu(workload, wl, steps, warmup, rank, world, device):
-    """K timed steps of one workload.  Returns (max-over-ranks seconds, roofline of the dominant entry, breakdown)."""
+    """K timed steps of one workload.  Returns (max-over-ranks seconds, roofline of the dominant entry, breakdown,
+    extras: model / path split of a step, per-rank step times and collectives per step when sharded)."""
     import torch.distributed as dist
     from advchain_amd import _lib
     pg = dist.group.WORLD if world > 1 else None
@@ -233,6 +267,14 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     gc.collect()
     gc.disable()
     lib.records = []
+    n_coll = [0]
+    if world > 1:        # collectives per step: every all_reduce the path issues goes through torch.distributed.all_reduce
+        orig_all_reduce = dist.all_reduce
+
+        def counted_all_reduce(*a, **k):
+            n_coll[0] += 1
+            return orig_all_reduce(*a, **k)
+        dist.all_reduce = counted_all_reduce
     sync()
     t0 = time.perf_counter()
     with lib.timed([dominant] if dominant else [], every=1 if dominant in CHAIN_ENTRIES else 5):   # one call in five carries an event pair (every call of a chain entry: it is 8+ launches)
@@ -241,6 +283,22 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     sync()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    extras = {}
+    if world > 1:
+        dist.all_reduce = orig_all_reduce
+        extras["all_reduces_per_step"] = round(n_coll[0] / float(steps), 2)
+    # model / path split: an instrumented pass of a few steps after the timed region (events around the model's forward
+    # and backward calls only; the solver's own kernels carry none)
+    k_split = max(1, min(steps, 5))
+    with _ModelTimer(model) as mt:
+        for _ in range(k_split):
+            step()
+    model_ms = mt.total_ms() / k_split
+    extras["model_ms_per_step"] = round(model_ms, 3)
+    extras["path_ms_per_step"] = round(elapsed / steps * 1e3 - model_ms, 3)
+    extras["model_split_note"] = ("model = HIP-event time of the user model's forward calls and input-gradient backward calls "
+                                  "(stock MIOpen / rocBLAS kernels) per adversarial_training call, measured over %d further "
+                                  "steps after the timed region; path = ms_per_step - model" % k_split)
     roof = None
     if dominant and lib.records:
         durs, bts, nl = [], [], 0
@@ -261,10 +319,21 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                 "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b)}
     if world > 1:
+        extras["rank_ms_per_step"] = _rank_spread(elapsed / steps * 1e3, world, device)
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, roof, breakdown
+    return elapsed, roof, breakdown, extras
+
+
+def _rank_spread(ms, world, device):
+    """min / max / per-rank ms_per_step over the ranks (load imbalance at a glance; `value` uses the max)."""
+    import torch.distributed as dist
+    mine = torch.tensor([ms], device=device, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    vals = [round(float(v.item()), 3) for v in every]
+    return {"min": min(vals), "max": max(vals), "by_rank": vals}
 
 
 def profiled_traffic(workload, entry):
@@ -455,21 +524,29 @@ def run_stub(steps, warmup, rank, world):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    extras = {}
+    if world > 1:
+        extras["rank_ms_per_step"] = _rank_spread(elapsed / steps * 1e3, world, torch.device("cpu"))
+        extras["all_reduces_per_step"] = 0.0
     t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item()), None, {}
+    return float(t.item()), None, {}, extras
 
 
 SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
 
 
-def result_record(name, wl, world, steps, warmup, elapsed, roof, breakdown):
+def result_record(name, wl, world, steps, warmup, elapsed, roof, breakdown, extras=None):
     unit = "images/s" if len(wl["dims"]) == 2 else "volumes/s"
-    return {"value": round(wl["batch"] * world * steps / elapsed, 3), "unit": unit, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 3), "workload": "%s: %s" % (name, wl["desc"]),
-            "global_batch": wl["batch"] * world, "adv_steps": wl["n_iter"], "roofline": roof,
-            "kernel_time_ms_first_step": breakdown}
+    rec = {"value": round(wl["batch"] * world * steps / elapsed, 3), "unit": unit, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "workload": "%s: %s" % (name, wl["desc"]),
+           "global_batch": wl["batch"] * world, "adv_steps": wl["n_iter"], "roofline": roof,
+           "kernel_time_ms_first_step": breakdown}
+    ex = dict(extras or {})
+    ex.pop("model_split_note", None)
+    rec.update(ex)
+    return rec
 
 
 def main():
@@ -519,11 +596,11 @@ def main():
             raise SystemExit("bench.py: all_reduce saw %d ranks, expected %d" % (rccl_ranks, world))
     wl = WORKLOADS[args.workload]
     if stub:
-        elapsed, roof, breakdown = run_stub(args.steps, args.warmup, rank, world)
+        elapsed, roof, breakdown, extras = run_stub(args.steps, args.warmup, rank, world)
     else:
-        elapsed, roof, breakdown = run_gpu(args.workload, wl, args.steps, args.warmup, rank, world, device)
+        elapsed, roof, breakdown, extras = run_gpu(args.workload, wl, args.steps, args.warmup, rank, world, device)
     if rank == 0:
-        rec = result_record(args.workload, wl, world, args.steps, args.warmup, elapsed, roof, breakdown)
+        rec = result_record(args.workload, wl, world, args.steps, args.warmup, elapsed, roof, breakdown, extras)
         out = {
             "metric": "augmented images/sec (N adv steps, chain=noise+bias+morph+affine)",
             "value": rec["value"], "unit": "images/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
@@ -535,6 +612,7 @@ def main():
             "roofline": roof,
             "kernel_time_ms_first_step": breakdown,
         }
+        out.update(extras)      # model_ms_per_step / path_ms_per_step (+ rank_ms_per_step, all_reduces_per_step when sharded)
         if world == 1 and not stub:
             if not (args.no_secondary or args.only_workload):
                 # the 3D configs of BASELINE.json, timed by the same code on the same device (fewer steps: they are
@@ -545,8 +623,8 @@ def main():
                         continue
                     w2 = WORKLOADS[name]
                     k2 = max(3, min(args.steps, 5))
-                    e2, r2, b2 = run_gpu(name, w2, k2, 1, 0, 1, device)
-                    other[name] = result_record(name, w2, 1, k2, 1, e2, r2, b2)
+                    e2, r2, b2, x2 = run_gpu(name, w2, k2, 1, 0, 1, device)
+                    other[name] = result_record(name, w2, 1, k2, 1, e2, r2, b2, x2)
                     other[name].pop("kernel_time_ms_first_step")
                 out["other_workloads"] = other
             if not args.only_workload:

@@ -549,7 +549,8 @@ def g6l_large(aug):
     inputs (data and initial parameters are regenerated from the seeds by the tests: tests/helpers.py).  Large tensors are
     stored as a strided sample plus float64 moments (tests/helpers.sampled_record) so that a fixture stays below 1 MB.
     Cases with an AdvMorph also store (a) a sample of the first deformation field and (b) PER COEFFICIENT, how far the
-    reference's own first-step velocity gradient moves when its fields are jittered by G6L_JITTER (max over 3 trials):
+    reference's own first-step gradients (velocity, and the bias / affine parameters, which see the field through the
+    warps around them) move when its fields are jittered by G6L_JITTER (max over 3 trials):
     the derivative of a (tri)linear interpolant jumps at grid nodes, so single coefficients of that gradient are
     sensitive to field differences far below the 2e-5 the fields themselves are held to (tests/golden/g8_kinks.npz)."""
     for tag, c in G6L_CASES.items():
@@ -574,15 +575,36 @@ def g6l_large(aug):
         if "morph" in c["names"]:
             mi = c["names"].index("morph")
             recs["morph_field"] = run["fields"][0]
-            base = steps[mi]["grad"]
+            small = [ti for ti in range(len(chain)) if steps[ti]["grad"].numel() <= 8192]      # bias, morph, affine
             for lvl, amp in enumerate(G6L_JITTER):
-                spread = torch.zeros_like(base)
+                spread = {ti: torch.zeros_like(steps[ti]["grad"]) for ti in small}
                 for trial in range(3):
-                    pert = _g6l_run(aug, dict(c, n_iter=1), jitter=amp, trial=trial + 1)["steps"][mi]["grad"]
-                    spread = torch.maximum(spread, (pert - base).abs())
-                out["morph_grad_spread_%d" % lvl] = spread
-                print("  %s: reference morph-gradient spread at field jitter %g: max %.2e of scale, %d of %d coefficients above 1e-4"
-                      % (tag, amp, float(spread.max() / base.abs().max()), int((spread > 1e-4 * base.abs().max()).sum()), spread.numel()))
+                    pert = _g6l_run(aug, dict(c, n_iter=1), jitter=amp, trial=trial + 1)["steps"]
+                    for ti in small:
+                        spread[ti] = torch.maximum(spread[ti], (pert[ti]["grad"] - steps[ti]["grad"]).abs())
+                for ti in small:
+                    # grad_spread_<transform>_<level>; the morph one keeps its round-4 name as well
+                    out["grad_spread_%d_%d" % (ti, lvl)] = spread[ti]
+                    base = steps[ti]["grad"]
+                    print("  %s: reference %s-gradient spread at field jitter %g: max %.2e of scale, %d of %d coefficients above 1e-4"
+                          % (tag, c["names"][ti], amp, float(spread[ti].max() / base.abs().max()),
+                             int((spread[ti] > 1e-4 * base.abs().max()).sum()), base.numel()))
+                out["morph_grad_spread_%d" % lvl] = spread[mi]
+            if n_it > 1:
+                # a free-running run of several steps amplifies the same field differences (the sign updates of the affine
+                # parameters flip): how far the reference's OWN final loss / adv_data move, per jitter level
+                fl, ad = [], []
+                for amp in G6L_JITTER:
+                    worst_l = worst_a = 0.0
+                    for trial in range(3):
+                        pr = _g6l_run(aug, c, jitter=amp, trial=trial + 11)
+                        worst_l = max(worst_l, abs(float(pr["loss"]) - float(loss)))
+                        worst_a = max(worst_a, float((pr["solver"].adv_data - solver.adv_data).abs().max()))
+                    fl.append(worst_l)
+                    ad.append(worst_a)
+                out["meta"]["free_running_spread"] = dict(final_loss=fl, adv_data=ad)
+                print("  %s: reference free-running spread over %d steps: final loss %s (of %.4g), adv_data %s"
+                      % (tag, n_it, ["%.2e" % v for v in fl], float(loss), ["%.2e" % v for v in ad]))
         for k, v in recs.items():
             for kk, vv in sampled_record(v).items():
                 out[k + "__" + kk] = vv

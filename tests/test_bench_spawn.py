@@ -25,6 +25,10 @@ def test_gpus_2_self_spawns_two_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2
     assert rec["config"]["global_batch"] == 64 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    # load imbalance and collective count in the same line
+    spread = rec["rank_ms_per_step"]
+    assert len(spread["by_rank"]) == 2 and spread["min"] <= spread["max"] and abs(spread["max"] - rec["ms_per_step"]) < 0.5
+    assert "all_reduces_per_step" in rec
 
 
 def test_world_size_mismatch_fails_loudly():

@@ -1,0 +1,119 @@
+"""The fused early squarings of the 2D scaling-and-squaring chain (advchain_amd/csrc/expo_fused2d.hip; reference loop
+adv_morph.py:116-146) against the one-launch-per-squaring chain: bit for bit -- fields, positions, displacement rows --
+whether the sub-pixel premise holds (one fused launch, the gated launches return at once), fails everywhere (the fused
+kernel only raises its flag) or fails for ONE window of one image (the ordinary launches redo every squaring)."""
+import ctypes
+
+import pytest
+import torch
+
+from tests.helpers import rand
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _chain(phi0, n, hints, fuse):
+    from advchain_amd import _lib, ops
+    N, d = phi0.shape[0], phi0.dim() - 2
+    dims = tuple(phi0.shape[2:])
+    lib = _lib.load()
+    rows = torch.zeros(n + 2, ops.DISP_SLOTS, device=DEV)
+    fields = torch.full((n - 1,) + tuple(phi0.shape), float("nan"), device=DEV)
+    pos = torch.empty_like(phi0)
+    harr = None if hints is None else (ctypes.c_int32 * n)(*hints)
+    _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(phi0), ops._ptr(fields), ops._ptr(pos), N, d, _lib.dims_array(dims), n,
+                                           ops._ptr(rows), harr, ops._ptr(rows[n + 1]) if fuse else None, ops._stream()),
+               "expo_chain_fwd")
+    torch.cuda.synchronize()
+    return fields, pos, rows[:n + 1].max(1).values, float(rows[n + 1, 0])
+
+
+def _phi0(N, dims, amp_px, seed):
+    """identity + a smooth displacement of at most amp_px pixels"""
+    from oracle import advchain_oracle as O
+    import torch.nn.functional as F
+    low = rand((N, 2, 5, 5), seed)
+    u = F.interpolate(low, size=dims, mode="bilinear", align_corners=True)
+    u = u / u.abs().max()
+    scale = torch.tensor([2.0 / (dims[1] - 1), 2.0 / (dims[0] - 1)]).view(1, 2, 1, 1)      # channel 0 = x <-> last axis
+    return (O.identity_grid(N, dims) + amp_px * u * scale).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("dims", [(256, 256), (192, 192), (40, 64), (100, 128), (37, 320), (24, 512)])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_fused_levels_equal_the_per_squaring_launches(dims, k):
+    n = 8
+    phi0 = _phi0(3, dims, 0.9 / 2 ** (k - 1) * 0.95, 11 + k)        # phi_{k-1} stays just below one pixel
+    hints = [1] * k + [0] * (n - k)
+    ref = _chain(phi0, n, None, False)
+    out = _chain(phi0, n, hints, True)
+    assert out[3] == 0.0, "the fused kernel raised its flag on a sub-pixel field"
+    assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+    for m in range(n - 1):
+        assert torch.equal(out[0][m], ref[0][m]), (dims, k, m)
+    # the gated launches really returned at once: poison the first k fields, run with hints again -> still the fused values
+    # (a fused launch that silently did nothing would leave NaN here, since the gated launches do not run either)
+    assert not torch.isnan(out[0][:k]).any()
+
+
+@pytest.mark.parametrize("case", ["all", "one_window", "nan"])
+def test_fused_premise_violated_falls_back(case):
+    """Hints that are too optimistic: the kernel's own check refuses, raises the flag, and the gated ordinary launches
+    produce the fields -- results never depend on the hints."""
+    n, dims = 8, (128, 256)
+    phi0 = _phi0(4, dims, 0.05, 3)
+    if case == "all":
+        phi0 = _phi0(4, dims, 3.0, 3)
+    elif case == "one_window":      # a 2-pixel bump in a few rows of one image
+        phi0[2, 0, 70:74, 100:140] += 2.0 * 2.0 / (dims[1] - 1)
+    else:
+        phi0[1, 1, 5, 7] = float("nan")
+    hints = [1, 1, 1, 1, 0, 0, 0, 0]
+    ref = _chain(phi0, n, None, False)
+    out = _chain(phi0, n, hints, True)
+    assert out[3] == 1.0
+    for m in range(n - 1):
+        assert torch.equal(torch.nan_to_num(out[0][m], nan=7.0), torch.nan_to_num(ref[0][m], nan=7.0)), (case, m)
+    assert torch.equal(torch.nan_to_num(out[1], nan=7.0), torch.nan_to_num(ref[1], nan=7.0))
+    assert torch.equal(torch.nan_to_num(out[2], nan=7.0), torch.nan_to_num(ref[2], nan=7.0))
+
+
+def test_unsupported_shapes_take_the_ordinary_launches():
+    """Rows that are not a multiple of 64 pixels (or 3D fields): the chain ignores the flag and runs its ordinary launches."""
+    n = 5
+    phi0 = _phi0(2, (48, 100), 0.05, 5)
+    ref = _chain(phi0, n, None, False)
+    out = _chain(phi0, n, [1] * n, True)
+    assert out[3] == 0.0 and torch.equal(out[1], ref[1])
+    for m in range(n - 1):
+        assert torch.equal(out[0][m], ref[0][m])
+
+
+def test_demons_field_uses_the_fused_chain_and_matches():
+    """Through the product operator: the second evaluation of a field of one shape has hints and fuses; same bits as with
+    fusing switched off (ops.FUSE_2D)."""
+    from advchain_amd import bands, ops
+    dims, vs, N = (256, 256), [16, 16], 4
+    tabs = bands.upsample_tables(vs, list(dims), DEV)
+    v = rand((N, 2) + tuple(vs), 21).to(DEV)
+    v = v / v.reshape(N, -1).norm(dim=1).view(N, 1, 1, 1)
+    outs = {}
+    for fuse in (False, True):
+        ops.FUSE_2D = fuse
+        ops._CHAIN_HINTS.clear()
+        try:
+            res = []
+            for rep in range(2):
+                vv = v.clone().requires_grad_(True)
+                qp, qm = ops.demons_field_pair(vv, 1.5, tabs, False)
+                (qp.sum() + 2 * qm.sum()).backward()          # (the backward records the hints the next forward uses)
+                res.append((qp.detach().clone(), qm.detach().clone(), vv.grad.clone()))
+            outs[fuse] = res
+        finally:
+            ops.FUSE_2D = True
+    key = [k for k in ops._CHAIN_HINTS][0]
+    assert ops._CHAIN_HINTS[key][-1] == 0.0          # the fuse flag rode back with the displacement rows: never raised
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)

@@ -210,7 +210,7 @@ def test_teacher_forced_step_at_realistic_size(case):
         assert fdiff < 2e-5, (case, "field", fdiff)
         levels = meta["jitter_levels"]
         lvl = min([i for i, a in enumerate(levels) if a >= fdiff] or [len(levels) - 1])
-        morph_allow = 2.0 * fx.t("morph_grad_spread_%d" % lvl)
+        morph_allow = lvl
     data = smooth_data(N, 1, dims, seed).to(DEV)
     model = make_model(sd, device=DEV)
     # ---- the ascent step through the product's own loop, gradients captured before the update
@@ -238,14 +238,16 @@ def test_teacher_forced_step_at_realistic_size(case):
     for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
         gkey = "grad_%d" % ti
         scale = float(fx.t(gkey + "__full").abs().max()) if gkey + "__full" in fx else float(fx.t(gkey + "__moments")[3])
-        if sp["name"] == "morph" and morph_allow is not None:
-            # 1e-4 of scale on EVERY coefficient, plus -- coefficient by coefficient -- twice what the reference's own
-            # gradient moves under a field difference of the size measured above (zero for most coefficients; r3 used a
-            # blanket 3e-4 of scale here)
+        skey = "grad_spread_%d_%s" % (ti, morph_allow)
+        if morph_allow is not None and skey in fx:
+            # the gradients behind the deformation field (velocity; bias / affine parameters through the warps around them):
+            # 1e-4 of scale on EVERY coefficient, plus -- coefficient by coefficient -- twice what the REFERENCE's own
+            # gradient moves under a field difference of the size measured above (zero for most coefficients; round 3 used a
+            # blanket 3e-4 of scale for the velocity gradient)
             diff = (captured[ti].cpu() - fx.t(gkey + "__full")).abs()
-            over = diff - (TOL * scale + morph_allow)
-            assert float(over.max()) < 0, (case, "morph grad: %d coefficients over, worst %.3e of scale (field diff %.2e, level %d)"
-                                           % (int((over > 0).sum()), float(diff.max()) / scale, fdiff, lvl))
+            over = diff - (TOL * scale + 2.0 * fx.t(skey))
+            assert float(over.max()) < 0, (case, "%s grad: %d coefficients over, worst %.3e of scale (field diff %.2e, level %d)"
+                                           % (sp["name"], int((over > 0).sum()), float(diff.max()) / scale, fdiff, lvl))
         else:
             err = compare_sampled(fx, gkey, captured[ti], 0)
             assert err < TOL * max(scale, 1e-12), (case, sp["name"], "grad err %.3e scale %.3e" % (err, scale))
@@ -298,7 +300,8 @@ def test_teacher_forced_step_at_realistic_size(case):
             g_ref = fx.t("grad_%d_s%d__full" % (ti, k))
             scale = float(g_ref.abs().max())
             diff = (captured[ti].cpu() - g_ref).abs()
-            allow = TOL * scale + (2.0 * fx.t("morph_grad_spread_%d" % (len(meta["jitter_levels"]) - 1)) if sp["name"] == "morph" else 0.0)
+            skey = "grad_spread_%d_%d" % (ti, len(meta["jitter_levels"]) - 1)     # (measured at step 0; theta_1 is close to theta_0)
+            allow = TOL * scale + (2.0 * fx.t(skey) if skey in fx else 0.0)
             assert float((diff - allow).max()) < 0, (case, k, sp["name"], float(diff.max()) / scale)
             p_ref = fx.t("param_out_%d_s%d__full" % (ti, k))
             sel = g_ref.abs() > 1e-3 * scale if sp["name"] == "affine" else torch.ones_like(g_ref, dtype=torch.bool)
@@ -309,11 +312,18 @@ def test_teacher_forced_step_at_realistic_size(case):
     with contextlib.redirect_stdout(io.StringIO()):
         loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=True, step_sizes=1)
     ref = fx.f("final_loss")
-    assert abs(float(loss) - ref) < 1e-7 + TOL * abs(ref), (float(loss), ref)
-    assert compare_sampled(fx, "adv_data", solver.adv_data, 0) < TOL
+    loss_tol, data_tol, free = 1e-7 + TOL * abs(ref), TOL, meta.get("free_running_spread")
+    if free is not None:
+        # several free-running steps: the sign updates of the affine parameters flip under field differences of a few 1e-6
+        # (chaos of the ascent, g6s_sensitivity.npz) -- the fixture holds how far the REFERENCE's own final loss and
+        # adv_data move at the field difference measured above; per-step parity is the teacher-forced part
+        loss_tol = max(loss_tol, 2.0 * free["final_loss"][lvl])
+        data_tol = max(data_tol, 2.0 * free["adv_data"][lvl])
+    assert abs(float(loss) - ref) < loss_tol, (float(loss), ref)
+    assert compare_sampled(fx, "adv_data", solver.adv_data, 0) < data_tol
     for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
-        if sp["name"] == "affine":
-            continue        # (covered above where the sign is well defined)
+        if sp["name"] == "affine" or (free is not None and data_tol > 10 * TOL):
+            continue        # (affine: covered above where the sign is well defined; chaotic free-running case: see above)
         key = "final_param_%d" % ti
         pscale = float(fx.t(key + "__full").abs().max()) if key + "__full" in fx else float(fx.t(key + "__moments")[3])
         assert compare_sampled(fx, key, t.param, 0) < TOL * max(1.0, pscale), (case, sp["name"], "final param")

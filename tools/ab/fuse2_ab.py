@@ -37,7 +37,7 @@ def main():
 
     def run():
         _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(phi0), ops._ptr(fields), ops._ptr(pos), N, 3, _lib.dims_array(dims), n,
-                                               ops._ptr(disp), None, ops._stream()), "chain")
+                                               ops._ptr(disp), None, None, ops._stream()), "chain")
     for _ in range(3):
         run()
     torch.cuda.synchronize()
