@@ -25,6 +25,7 @@ ARCH = "gfx950"
 PER_FILE_FLAGS = {
     "adjoint_march.hip": ["-fno-slp-vectorize"],
     "adjoint_gather.hip": ["-fno-slp-vectorize"],
+    "adjoint_fused2d.hip": ["-fno-slp-vectorize"],      # (the same code generation as the per-squaring gather form: bit-identical results)
     "fields.hip": ["-fno-slp-vectorize"],
 }
 if os.environ.get("ADVCHAIN_BUILD_SLP_EVERYWHERE"):     # A/B knob: the compiler default for every source

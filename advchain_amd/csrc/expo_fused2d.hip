@@ -20,18 +20,19 @@
 //     fuses only if 2^(k-1) d0 (1 + 1e-3) + 1e-3 < 1 -- by induction |phi_j - id| <= 2^j d0 on the shrinking windows
 //     (phi_j(x) - x = (phi_{j-1}(p) - p) + (p - x), an interpolant of displacements plus a displacement; the border clip
 //     only shortens p - x), so every corner of every level lies in the rows the previous level produced.  A workgroup whose
-//     window fails the test raises `fail_flag` and does nothing; the chain then runs its k ordinary launches, which are
-//     enqueued behind this kernel and return at once while the flag is down (k_compose_self_fwd's `gate`).
+//     window fails the test raises `fail_flag` and does nothing; ONE fallback launch enqueued behind this kernel
+//     (k_expo_fallback2d, sampler.hip: the k ordinary squarings on a persistent grid with a grid barrier) then produces the
+//     fields, and returns at once while the flag is down -- one empty launch costs ~5 us, k of them cost what fusing saves.
 #include "sampler_common.h"
 
 namespace advchain {
 
-constexpr int kFuseMaxLevels = 4;
+constexpr int kFuseMaxLevels = 5;
 
 // NT threads; a wave handles PPW segments of 64 consecutive pixels of the window (segment s of the window = row
 // s / (W / 64), columns 64 * (s % (W / 64)) ..); requires W % 64 == 0.
 template <int NT, int PPW>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT)      // (101 VGPRs, two workgroups a CU; capped at 80 for three it spills and is 4 % slower)
 k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, int64_t F, Dims d, int k, int TH,
                    float* __restrict__ disp_rows, float* __restrict__ fail_flag) {
   extern __shared__ float2 win[];            // [WY][W] (x, y) of the current level
@@ -97,6 +98,7 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
     scol[i] = (seg - (seg / SPR) * SPR) << 6;
   }
 
+  const float topx = (float)(W - 1), topy = (float)(S1 - 1), hx = 0.5f * topx, hy = 0.5f * topy;
   for (int lev = 1; lev <= k; ++lev) {
     // rows this level produces: the window shrunk by `lev` rows either side, inside the image
     const int rlo = max(wy0 + lev, 0), rhi = min(wy0 + WY - lev, S1) - 1;
@@ -114,9 +116,9 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
       // the window is finite (a NaN / inf raises the flag above), so the position is a finite number clipped into
       // [0, S - 1], the lower corner is always inside, and the upper corner is outside only where its weight is exactly 0
       // -- `ok ? v : 0` then adds the same +-0 as v * 0 with a finite v.  Same operations, same order, same roundings.
-      float xs = ((own.x + 1.f) * 0.5f) * (float)(W - 1), ys = ((own.y + 1.f) * 0.5f) * (float)(S1 - 1);
-      xs = fminf(fmaxf(xs, 0.f), (float)(W - 1));
-      ys = fminf(fmaxf(ys, 0.f), (float)(S1 - 1));
+      // ((c + 1) * 0.5) * (S - 1) == (c + 1) * (0.5 (S - 1)) bit for bit: the halving is exact
+      const float xs = __builtin_amdgcn_fmed3f((own.x + 1.f) * hx, 0.f, topx);
+      const float ys = __builtin_amdgcn_fmed3f((own.y + 1.f) * hy, 0.f, topy);
       const float fx = floorf(xs), fy = floorf(ys);
       const int ix = (int)fx, iy = (int)fy;
       const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs, vy1 = ys - fy, vy0 = (fy + 1.f) - ys;   // (vy: the y weights)
@@ -176,12 +178,12 @@ int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N
   const int W = d.s2;
   if (W % 64 != 0 || W > 512 || d.s1 < 8) return ADVCHAIN_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(phi0) | reinterpret_cast<uintptr_t>(fields)) & 15) return ADVCHAIN_ERR_UNSUPPORTED;
-  constexpr int NT = 512, PPW = 12;
-  // rows per workgroup: the window (TH + 2k rows of W pairs) within 48 KiB (three workgroups a CU) and within the PPW
+  constexpr int NT = 512, PPW = 13;
+  // rows per workgroup: the window (TH + 2k rows of W pairs) within 56 KiB (two workgroups a CU) and within the PPW
   // segments a wave can carry; 16 where that fits
   const int spr = W / 64;
   int TH = 16;
-  while (TH > 4 && ((TH + 2 * k) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * k) * W * sizeof(float2) > 48 * 1024)) TH -= 4;
+  while (TH > 4 && ((TH + 2 * k) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * k) * W * sizeof(float2) > 56 * 1024)) TH -= 4;
   if ((TH + 2 * k) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * k) * W * sizeof(float2) > 64 * 1024) return ADVCHAIN_ERR_UNSUPPORTED;
   const int64_t F = N * 2 * d.voxels();
   const size_t lds = (size_t)(TH + 2 * k) * W * sizeof(float2);

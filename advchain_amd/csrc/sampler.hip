@@ -261,17 +261,37 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
                                   (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x);
 }
 
-// The same squaring as a REPEAT behind the fused kernel of expo_fused2d.hip: that kernel has normally produced `out`
-// already, and raises *gate only when one of its windows moved too far for its sub-pixel premise.  While the flag is down
-// the launch returns at once -- a small grid-stride grid (nbx workgroups' worth of work on gridDim.x workgroups), so that
-// returning costs a microsecond, not the dispatch of thousands of workgroups.
-template <int DIM, int VEC>
+// The first k squarings of a 2D chain as the FALLBACK behind the fused kernel of expo_fused2d.hip.  That kernel has normally
+// produced phi_1..phi_k already and raises *flag only when one of its windows moved too far for its sub-pixel premise:
+// while the flag is down this launch returns at once (one ~5 us launch instead of k -- an empty launch is not free).  When
+// it does run, it is the k ordinary squarings (compose_self_fwd_body<2, 2>: the same bits) on a small persistent grid with
+// a grid-wide barrier between two of them: every workgroup of the grid is resident (the host sizes the grid for that), an
+// arrival counter in device memory, agent-scope fences either side so that what another XCD's L2 still holds is written
+// back / re-read.  `barrier`: one zero-initialised 32-bit counter per call.
 __global__ void __launch_bounds__(kBlock)
-k_compose_self_fwd_gated(const float* __restrict__ phi, float* __restrict__ out, const float* __restrict__ phi0,
-                         Dims d, int final_mode, float* __restrict__ disp_out, const float* __restrict__ gate, int nbx) {
-  if (*gate == 0.f) return;
-  for (int b = blockIdx.x; b < nbx; b += gridDim.x)
-    compose_self_fwd_body<DIM, VEC>(phi, out, phi0, d, final_mode, disp_out, blockIdx.y, (int64_t)b * (kBlock * VEC) + threadIdx.x);
+k_expo_fallback2d(const float* __restrict__ phi0, float* __restrict__ fields, int64_t F, Dims d, int k, int N, int nbx,
+                  float* __restrict__ disp_rows, const float* __restrict__ flag, unsigned int* __restrict__ barrier) {
+  if (*flag == 0.f) return;
+  const int items = N * nbx;
+  for (int lev = 1; lev <= k; ++lev) {
+    const float* src = lev == 1 ? phi0 : fields + (int64_t)(lev - 2) * F;
+    float* dst = fields + (int64_t)(lev - 1) * F;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+      const int n = it / nbx, b = it - n * nbx;
+      compose_self_fwd_body<2, 2>(src, dst, nullptr, d, 0, disp_rows ? disp_rows + (int64_t)lev * kDispSlots : nullptr, n,
+                                  (int64_t)b * (kBlock * 2) + threadIdx.x);
+    }
+    if (lev == k) break;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();                                   // this workgroup's stores are visible device-wide
+      atomicAdd(barrier, 1u);
+      const unsigned int target = (unsigned int)lev * gridDim.x;
+      while (atomicAdd(barrier, 0u) < target) __builtin_amdgcn_s_sleep(4);
+      __threadfence();                                   // and nothing stale is read behind the barrier
+    }
+    __syncthreads();
+  }
 }
 
 // gphi must be zero-initialised by the caller (scatter target).
@@ -751,6 +771,8 @@ bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const
 // sample_march.hip: two squarings per launch (f1 experiment, ADVCHAIN_FUSE2)
 int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, float* disp_rows,
                                      float* fail_flag, hipStream_t stream);
+int advchain_adjoint_fused2d_launch(const float* gk, const float* phi0, const float* fields, float* g0, int64_t N, advchain::Dims d,
+                                    int k, int32_t* workspace, hipStream_t st);
 int advchain_compose2_march_launch(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
                                    hipStream_t st);
 
@@ -921,10 +943,8 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
 
-// gate != nullptr: a repeat of a squaring the fused kernel (expo_fused2d.hip) has normally done already -- direct kernels
-// only, each returning at once while *gate == 0
-static int compose_self_fwd_impl(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
-                                 const int64_t* dims, int final_mode, float* disp_out, const float* gate, void* stream) {
+int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
+                              const int64_t* dims, int final_mode, float* disp_out, void* stream) {
   const int disp_hint = (final_mode >> 8) & 0xff;   // bits 8..15: displacement estimate of phi in voxels (0 = unknown), a performance hint
   final_mode &= 0xff;
   ADVCHAIN_CHECK_ARG(phi && out && phi != out, "compose_self_fwd: null/aliased pointer");
@@ -935,22 +955,13 @@ static int compose_self_fwd_impl(const float* phi, float* out, const float* phi0
   const Dims d = make_dims(ndim, dims);
   const int64_t V = d.voxels();
   ADVCHAIN_CHECK_ARG(V < (1ll << 31), "compose_self_fwd: per-sample volume too large");
-  if (!gate) {
+  {
     const int rc = advchain_sample_tiled_launch(true, phi, nullptr, out, phi0, N, ndim, ndim, d, PAD_BORDER, 0,
                                                 final_mode, 0, disp_out, (hipStream_t)stream, disp_hint);
     if (rc != ADVCHAIN_ERR_UNSUPPORTED) return rc;
   }
   const bool vec4 = use_unroll(V, ndim);
   hipStream_t st = (hipStream_t)stream;
-  if (gate) {      // a repeat behind the fused 2D kernel: returns at once while the flag is down
-    ADVCHAIN_CHECK_ARG(ndim == 2 && final_mode == 0, "compose_self_fwd: gated repeats are 2D, not final");
-    const int nbx = advchain_blocks(V, kBlock * 2);
-    const int per = (int)((1024 + N - 1) / N);          // ~1024 workgroups in all
-    dim3 gg((unsigned)(nbx < per ? nbx : per), (unsigned)N);
-    hipLaunchKernelGGL((k_compose_self_fwd_gated<2, 2>), gg, dim3(kBlock), 0, st, phi, out, phi0, d, final_mode, disp_out, gate, nbx);
-    ADVCHAIN_LAUNCH_CHECK();
-    return ADVCHAIN_OK;
-  }
   // 2D: two voxels per thread (twice the waves of the 4-voxel form at fewer registers: 12.0 against 13.4 us per cfg-2
   // squaring once the gathers are issued together); ADVCHAIN_UNR4 / ADVCHAIN_UNR1 force the other forms
   static const bool unr2 = getenv("ADVCHAIN_UNR4") == nullptr && getenv("ADVCHAIN_UNR1") == nullptr;
@@ -970,11 +981,6 @@ static int compose_self_fwd_impl(const float* phi, float* out, const float* phi0
   }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
-}
-
-int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, int64_t N, int ndim,
-                              const int64_t* dims, int final_mode, float* disp_out, void* stream) {
-  return compose_self_fwd_impl(phi, out, phi0, N, ndim, dims, final_mode, disp_out, nullptr, stream);
 }
 
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
@@ -1079,8 +1085,9 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   static const int fuse2 = getenv("ADVCHAIN_FUSE2") ? atoi(getenv("ADVCHAIN_FUSE2")) : 0;
   // 2D: the leading squarings whose inputs the hints put below one pixel run as ONE launch (expo_fused2d.hip: whole-row LDS
   // windows, bit-identical fields).  The kernel verifies the premise itself and raises *fuse_flag when a window moves too
-  // far; the ordinary launches of those squarings follow it, gated on the flag (they return at once while it is down).
-  static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 4;   // A/B knob (0 = off)
+  // far; ONE fallback launch behind it (k_expo_fallback2d) then runs those squarings the ordinary way, and returns at once
+  // while the flag is down.
+  static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 5;   // A/B knob (0 = off)
   int fused = 0;
   if (ndim == 2 && fuse_flag && hints && fuse_max >= 2) {
     int k = 0;
@@ -1088,11 +1095,25 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
     if (k >= 2) {
       const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, disp_rows, fuse_flag,
                                                       (hipStream_t)stream);
-      if (rf == ADVCHAIN_OK) fused = k;
-      else if (rf != ADVCHAIN_ERR_UNSUPPORTED) return rf;
+      if (rf == ADVCHAIN_OK) {
+        // the fallback behind it: returns at once unless the flag went up; a persistent grid every workgroup of which is
+        // resident (8 workgroups of 256 threads fit a CU; 2 per CU asked for)
+        fused = k;
+        const Dims d2 = make_dims(ndim, dims);
+        const int nbx = advchain_blocks(d2.voxels(), kBlock * 2);
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t items = N * (int64_t)nbx;
+        const int64_t cap = 2 * (int64_t)(cus > 0 ? cus : 64);
+        hipLaunchKernelGGL(k_expo_fallback2d, dim3((unsigned)(items < cap ? items : cap)), dim3(kBlock), 0, (hipStream_t)stream,
+                           phi0, fields, F, d2, k, (int)N, nbx, disp_rows, fuse_flag, reinterpret_cast<unsigned int*>(fuse_flag + 1));
+        ADVCHAIN_LAUNCH_CHECK();
+      } else if (rf != ADVCHAIN_ERR_UNSUPPORTED) return rf;
     }
   }
-  for (int m = 0; m + 1 < n; ++m) {
+  if (fused) src = fields + (int64_t)(fused - 1) * F;
+  for (int m = fused; m + 1 < n; ++m) {
     if (fuse2 && ndim == 3 && m + 2 < n &&
         (fuse2 >= 2 ? m < 6 : (hints && (hints[m] & 0xff) == 1 && (hints[m + 1] & 0xff) == 1))) {
       float* mid = fields + (int64_t)m * F;
@@ -1105,9 +1126,8 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
       if (rc2 != ADVCHAIN_ERR_UNSUPPORTED) return rc2;
     }
     float* dst = fields + (int64_t)m * F;
-    const int rc = compose_self_fwd_impl(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
-                                         disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr,
-                                         m < fused ? fuse_flag : nullptr, stream);
+    const int rc = advchain_compose_self_fwd(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
+                                             disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, stream);
     if (rc != ADVCHAIN_OK) return rc;
     src = dst;
   }
@@ -1123,14 +1143,43 @@ int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const floa
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(grad_phi0 != scratch && grad_pos != grad_phi0 && grad_pos != scratch, "expo_chain_bwd: aliased buffers");
   const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
+  // 2D: the steps at the END of the backward (squarings kf-1 .. 0) whose inputs have an EXACT sub-pixel bound run as one
+  // launch (adjoint_fused2d.hip: k levels of the gather form without leaving LDS, bit-identical to the separate launches)
+  int kf = 0;
+  if (ndim == 2 && workspace && n >= 2) {
+    while (kf < n && kf < 4 && halos[n - 1 - kf] == -1) ++kf;
+    if (kf < 2) kf = 0;
+  }
   const float* g = grad_pos;
-  for (int i = 0; i < n; ++i) {                      // squaring m = n-1 .. 0; the last one writes grad_phi0
+  for (int i = 0; i < n - kf; ++i) {                 // squaring m = n-1 .. kf; the last step of the call writes grad_phi0
     const int m = n - 1 - i;
     const float* phi = m == 0 ? phi0 : fields + (int64_t)(m - 1) * F;
-    float* out = (m % 2 == 0) ? grad_phi0 : scratch;
+    float* out = ((m - kf) % 2 == 0) ? (kf ? scratch : grad_phi0) : (kf ? grad_phi0 : scratch);
     const int rc = advchain_compose_self_bwd(g, phi, out, workspace, i > 0 ? 1 : 0, halos[i], N, ndim, dims, stream);
     if (rc != ADVCHAIN_OK) return rc;
     g = out;
+  }
+  if (kf) {
+    const int rf = advchain_adjoint_fused2d_launch(g, phi0, fields, grad_phi0, N, make_dims(ndim, dims), kf, workspace,
+                                                   (hipStream_t)stream);
+    if (rf == ADVCHAIN_ERR_UNSUPPORTED) {            // the shape does not fit: the separate launches (g sits in `scratch`)
+      for (int m = kf - 1; m >= 0; --m) {
+        const float* phi = m == 0 ? phi0 : fields + (int64_t)(m - 1) * F;
+        float* out = (m % 2 == 0) ? grad_phi0 : scratch;
+        if (out == g) {                              // keep input and output apart: one copy, only on this fallback route
+          float* other = out == grad_phi0 ? scratch : grad_phi0;
+          (void)hipMemcpyAsync(other, g, sizeof(float) * F, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+          g = other;
+        }
+        const int rc = advchain_compose_self_bwd(g, phi, out, workspace, (n - 1 - m) > 0 ? 1 : 0, halos[n - 1 - m], N, ndim, dims, stream);
+        if (rc != ADVCHAIN_OK) return rc;
+        g = out;
+      }
+    } else if (rf != ADVCHAIN_OK) {
+      return rf;
+    } else {
+      ADVCHAIN_LAUNCH_CHECK();
+    }
   }
   return ADVCHAIN_OK;
 }

@@ -41,7 +41,7 @@ def _phi0(N, dims, amp_px, seed):
 
 
 @pytest.mark.parametrize("dims", [(256, 256), (192, 192), (40, 64), (100, 128), (37, 320), (24, 512)])
-@pytest.mark.parametrize("k", [2, 3, 4])
+@pytest.mark.parametrize("k", [2, 3, 4, 5])
 def test_fused_levels_equal_the_per_squaring_launches(dims, k):
     n = 8
     phi0 = _phi0(3, dims, 0.9 / 2 ** (k - 1) * 0.95, 11 + k)        # phi_{k-1} stays just below one pixel
@@ -117,3 +117,35 @@ def test_demons_field_uses_the_fused_chain_and_matches():
     for a, b in zip(outs[False], outs[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("dims", [(256, 256), (192, 192), (40, 64), (100, 128), (37, 320), (16, 24)])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_fused_backward_levels_equal_the_per_squaring_launches(dims, k):
+    """advchain_expo_chain_bwd with exact sub-pixel bounds on its last k steps (one fused launch, adjoint_fused2d.hip) against
+    n calls of advchain_compose_self_bwd with the same bounds: the gradient w.r.t. phi_0, bit for bit."""
+    from advchain_amd import _lib, ops
+    n, N = 7, 3
+    phi0 = _phi0(N, dims, 0.9 / 2 ** (k - 1) * 0.95, 31 + k)
+    fields, pos, dm, _ = _chain(phi0, n, None, False)
+    dm = dm.tolist()
+    halos = [ops.squaring_halo(dm[m], 2) for m in range(n - 1, -1, -1)]
+    assert halos[-k:] == [-1] * k, halos                  # phi_0..phi_{k-1}: exact bound below one pixel
+    if k < 4:
+        assert halos[-k - 1] != -1, halos
+    gpos = rand((N, 2) + tuple(dims), 41).to(DEV)
+    ws = ops._scatter_workspace(N, dims, DEV)
+    phis = [phi0] + list(fields.unbind(0))
+    g = gpos
+    for i, phi in enumerate(reversed(phis)):
+        g = ops.raw_compose_self_bwd(g, phi, ws, chain=i > 0, halo=halos[i])
+    out, scratch = torch.full_like(gpos, float("nan")), torch.full_like(gpos, float("nan"))
+    lib = _lib.load()
+    _lib.check(lib.advchain_expo_chain_bwd(ops._ptr(gpos), ops._ptr(phi0), ops._ptr(fields), ops._ptr(out), ops._ptr(scratch),
+                                           ops._ptr(ws), (ctypes.c_int32 * n)(*halos), N, 2, _lib.dims_array(dims), n,
+                                           ops._stream()), "expo_chain_bwd")
+    torch.cuda.synchronize()
+    if all(h < 0 for h in halos):
+        assert torch.equal(out, g), float((out - g).abs().max())
+    else:       # (a window-scatter step in front: float atomics, compared to rounding)
+        assert float((out - g).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max()))

@@ -69,11 +69,38 @@ def main():
     same = torch.equal(fields, ref[0]) and torch.equal(pos, ref[1])
     print("expo_chain_fwd  batch %d x 2 x %d x %d: one launch per squaring %.1f us, fused leading squarings %.1f us; flag %.0f; bit-identical %s"
           % (NB, dims[0], dims[1], t_plain, t_fused, float(disp[n + 1, 0]), same))
-    for k in (2, 3, 4):
-        os.environ["X"] = "1"
+    for k in (2, 3, 4, 5):
         hk = [1] * k + [9] * (n - k)
         if all(h == 1 for h in hints[:k]):
             print("   k = %d: %.1f us" % (k, timeit(lambda: fwd(hk, True))))
+    # ---- backward: the chain entry (fuses the trailing exact sub-pixel steps) against n separate calls
+    fwd(None, False)
+    halos = [ops.squaring_halo(dm[m], 2) for m in range(n - 1, -1, -1)]
+    gpos = torch.rand_like(phi0)
+    ws = ops._scatter_workspace(NB, dims, dev)
+    out, scratch = torch.empty_like(gpos), torch.empty_like(gpos)
+    harr = (ctypes.c_int32 * n)(*halos)
+
+    def bwd_chain():
+        _lib.check(lib.advchain_expo_chain_bwd(ops._ptr(gpos), ops._ptr(phi0), ops._ptr(fields), ops._ptr(out), ops._ptr(scratch),
+                                               ops._ptr(ws), harr, NB, 2, _lib.dims_array(dims), n, ops._stream()), "bwd")
+    phis = [phi0] + list(fields.unbind(0))
+    bufs = [torch.empty_like(gpos), torch.empty_like(gpos)]
+
+    def bwd_steps():
+        g = gpos
+        for i, phi in enumerate(reversed(phis)):
+            o = bufs[i % 2]
+            _lib.check(lib.advchain_compose_self_bwd(ops._ptr(g), ops._ptr(phi), ops._ptr(o), ops._ptr(ws), int(i > 0), halos[i], NB, 2,
+                                                     _lib.dims_array(dims), ops._stream()), "step")
+            g = o
+        return g
+    t_steps, t_chain = timeit(bwd_steps), timeit(bwd_chain)
+    ref_g = bwd_steps().clone()
+    bwd_chain()
+    torch.cuda.synchronize()
+    print("expo_chain_bwd  halos %s: %d separate launches %.1f us, chain entry (fused tail) %.1f us; max |diff| %.3e of %.3e"
+          % (halos, n, t_steps, t_chain, float((out - ref_g).abs().max()), float(ref_g.abs().max())))
 
 
 if __name__ == "__main__":
