@@ -237,6 +237,7 @@ class ComposeAdversarialTransformSolver(object):
             chain_of_transforms = self.chain_of_transforms
         for tr in chain_of_transforms:
             tr.eval()
+        ops.HINT_SLOT = 0           # (kernel-selection hints are kept per position in the call: 0 = the final pass)
         self._shared_fields(chain_of_transforms, True)
         try:
             adv_data = self.forward(data, chain_of_transforms)
@@ -283,6 +284,7 @@ class ComposeAdversarialTransformSolver(object):
         while stop_flag is False:
             model.zero_grad()
             i_iter += 1
+            ops.HINT_SLOT = i_iter      # (ascent step i of this call resembles ascent step i of the previous call)
             self.make_learnable_transformation(optimize_flags=optimize_flags,
                                                chain_of_transforms=self.chain_of_transforms)
             self._shared_fields(self.chain_of_transforms, True)

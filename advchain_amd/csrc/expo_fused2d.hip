@@ -16,13 +16,14 @@
 //   * one window buffer, updated in place: results wait in registers across a barrier (2 barriers per level);
 //   * the arithmetic is that of k_compose_self_fwd<2, .> (Taps<2, PAD_BORDER>, the paired-corner select of CornerOffsets,
 //     the fma chain of sample_linear<2>): the fields are BIT-IDENTICAL to the unfused launches (tests/test_fused2d_gpu.py);
-//   * the sub-pixel premise is CHECKED, not assumed: every workgroup measures the displacement d0 of its own window and
-//     fuses only if 2^(k-1) d0 (1 + 1e-3) + 1e-3 < 1 -- by induction |phi_j - id| <= 2^j d0 on the shrinking windows
-//     (phi_j(x) - x = (phi_{j-1}(p) - p) + (p - x), an interpolant of displacements plus a displacement; the border clip
-//     only shortens p - x), so every corner of every level lies in the rows the previous level produced.  A workgroup whose
-//     window fails the test raises `fail_flag` and does nothing; ONE fallback launch enqueued behind this kernel
-//     (k_expo_fallback2d, sampler.hip: the k ordinary squarings on a persistent grid with a grid barrier) then produces the
-//     fields, and returns at once while the flag is down -- one empty launch costs ~5 us, k of them cost what fusing saves.
+//   * the sub-pixel premise is CHECKED, not assumed, level by level: a workgroup knows the displacement of what its window
+//     currently holds (measured while staging phi_0, then on every level's results) and runs the next level only if it is
+//     below 0.999 pixel -- every corner of that level then lies in the rows the previous level produced.  A workgroup that
+//     has to stop after j < k levels records the deficit k - j in `fail_flag` (a float, atomic max over the workgroups; 0 =
+//     every workgroup did all k levels).  The chain enqueues the ordinary launch of each of the k squarings behind this
+//     kernel, gated on the flag (k_compose_self_fwd_gated, sampler.hip): launch m returns at once unless deficit > k - m,
+//     so when a field grew past what the hints promised only the squarings some window could not do are repeated -- on
+//     every pixel, which rewrites identical bits where the fused kernel did get that far.
 #include "sampler_common.h"
 
 namespace advchain {
@@ -79,15 +80,9 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
   for (int o = 32; o > 0; o >>= 1) dloc = fmaxf(dloc, __shfl_xor(dloc, o, 64));
   if (lane == 0) red[wave] = dloc;
   __syncthreads();
-  float dwin = 0.f;
+  float dcur = 0.f;                          // displacement of what the window holds, over the rows the next level reads
 #pragma unroll
-  for (int w = 0; w < NWV; ++w) dwin = fmaxf(dwin, red[w]);
-  // displacement of the input of the LAST fused squaring (phi_{k-1}) is at most 2^(k-1) d0: it must stay below one pixel
-  const float bound = dwin * (float)(1 << (k - 1)) * 1.001f + 1.0e-3f;
-  if (!(bound < 1.f)) {      // block-uniform
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(fail_flag), __float_as_uint(1.f));
-    return;
-  }
+  for (int w = 0; w < NWV; ++w) dcur = fmaxf(dcur, red[w]);
 
   // the segments of this wave: window row and first column (wave-uniform, computed once)
   int srow[PPW], scol[PPW];
@@ -100,10 +95,14 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
 
   const float topx = (float)(W - 1), topy = (float)(S1 - 1), hx = 0.5f * topx, hy = 0.5f * topy;
   for (int lev = 1; lev <= k; ++lev) {
+    if (!(dcur < 0.999f)) {                    // block-uniform (NaN included): this window cannot do level `lev`
+      if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(fail_flag), __float_as_uint((float)(k - lev + 1)));
+      return;
+    }
     // rows this level produces: the window shrunk by `lev` rows either side, inside the image
     const int rlo = max(wy0 + lev, 0), rhi = min(wy0 + WY - lev, S1) - 1;
     float rx[PPW], ry[PPW];
-    float dmax = 0.f;
+    float dmax = 0.f, dall = 0.f;              // displacement of phi_lev over the owned rows / over every row of the level
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int wr = srow[i];                         // wave-uniform
@@ -138,11 +137,18 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
       ax = tap_acc<2>(ax, a1.x, w10); ay = tap_acc<2>(ay, a1.y, w10);
       ax = tap_acc<2>(ax, b1.x, w11); ay = tap_acc<2>(ay, b1.y, w11);
       rx[i] = ax; ry[i] = ay;
-      if (disp_rows && gy >= y0 && gy < y0 + TH)      // the displacement of phi_lev, over the rows this workgroup owns
-        dmax = fmaxf(dmax, fmaxf(fabsf(((ax + 1.f) * 0.5f) * (float)(W - 1) - (float)px),       // voxel_displacement() of a
-                                 fabsf(((ay + 1.f) * 0.5f) * (float)(S1 - 1) - (float)gy)));    // finite value
+      const float dpx = fmaxf(fabsf(((ax + 1.f) * 0.5f) * (float)(W - 1) - (float)px),          // voxel_displacement() of a
+                              fabsf(((ay + 1.f) * 0.5f) * (float)(S1 - 1) - (float)gy));        // finite value
+      dall = fmaxf(dall, dpx);
+      if (gy >= y0 && gy < y0 + TH) dmax = fmaxf(dmax, dpx);      // ... over the rows this workgroup owns
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dall = fmaxf(dall, __shfl_xor(dall, o, 64));
+    if (lane == 0) red[wave] = dall;
     __syncthreads();                                  // every tap of this level has been read
+    dcur = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) dcur = fmaxf(dcur, red[w]);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int wr = srow[i];

@@ -130,6 +130,13 @@ def _hint_bits(disp):
     return min(int(disp) + 1, 255) << 8
 
 
+def _fine_bits(disp):
+    """Displacement estimate in 1/1024 voxel (at least 1 when known, 0 = unknown): bits 8.. of a chain hint."""
+    if disp is None or not disp == disp or disp < 0:
+        return 0
+    return max(1, min(int(disp * 1024.0) + 1, (1 << 22) - 1))
+
+
 def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, disp_hint=None):
     N, C = inp.shape[:2]
     nd = inp.dim() - 2
@@ -853,13 +860,20 @@ class _DemonsField(torch.autograd.Function):
         row = (lambda m: None) if disp is None else (lambda m: disp[m])
         # what the squarings of the PREVIOUS field of this shape measured (a field changes little between two ascent
         # steps): picks the forward kernel per squaring, nothing else
-        key = (str(s1.device), tuple(s1.shape), n)
+        # ... of the same POSITION in the caller's trajectory when it says so (the solver numbers its ascent steps: the field
+        # of step i resembles step i of the previous call -- 0.14 / 0.20 / 0.24 / 0.32 px after steps 1..4 at cfg-2 against 0.03
+        # for a fresh draw -- far better than it resembles step i - 1 of this call)
+        key = (str(s1.device), tuple(s1.shape), n, HINT_SLOT)
+        pend = _PENDING_BOUNDS.pop(key, None)      # a chain whose backward never ran (the final pass): its read-back, if it has arrived
+        if pend is not None and pend.event.query():
+            _note_chain_bounds(key, pend.values(), n)
         hints = _CHAIN_HINTS.get(key)
         phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
         fields = torch.empty((n - 1,) + tuple(phi0.shape), device=phi0.device, dtype=torch.float32)
         pos = torch.empty_like(phi0)
-        harr = None if hints is None else (ctypes.c_int32 * n)(*[_hint_bits(hints[m]) >> 8 for m in range(n)])
+        harr = None if hints is None else (ctypes.c_int32 * n)(*[(_hint_bits(hints[m]) >> 8) | (_fine_bits(hints[m]) << 8)
+                                                                 for m in range(n)])
         _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
                                                        _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
                                                        None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
@@ -867,6 +881,8 @@ class _DemonsField(torch.autograd.Function):
         q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
         ctx.save_for_backward(pos, phi0, fields)
         ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp, reset=True))
+        if ctx.disp is not None:
+            _PENDING_BOUNDS[key] = ctx.disp
         global _LAST_FIELD_BOUND
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)
@@ -896,7 +912,8 @@ class _DemonsField(torch.autograd.Function):
         n = ctx.nsteps
         if ctx.disp is not None:
             dm = ctx.disp.values()
-            _CHAIN_HINTS[ctx.hint_key] = list(dm)
+            _PENDING_BOUNDS.pop(ctx.hint_key, None)
+            _note_chain_bounds(ctx.hint_key, dm, n)
             halos = [squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
         else:
             big = 2 if d == 3 else 16
@@ -925,6 +942,10 @@ class _DemonsField(torch.autograd.Function):
 
 
 _LAST_FIELD_BOUND = None
+HINT_SLOT = 0      # set by the solver: which step of its loop the next chain belongs to (keys the kernel-selection hints)
+FUSE_STATS = {"chains": 0, "refused": 0}     # chains whose backward read its bounds / whose fused forward squarings fell back
+
+
 class _HintCache(dict):
     """A small bounded map (kernel-selection hints keyed by device and shape; cleared when it outgrows its cap)."""
     CAP = 256
@@ -935,7 +956,19 @@ class _HintCache(dict):
         dict.__setitem__(self, key, value)
 
 
-_CHAIN_HINTS = _HintCache()     # (device, velocity shape, n) -> displacement of phi_0..phi_n measured by the last backward of such a chain
+_PENDING_BOUNDS = _HintCache()  # chain key -> the read-back of the last forward of that key, until somebody looks at it
+
+
+def _note_chain_bounds(key, dm, n):
+    """The displacements phi_0..phi_n (+ the deficit of the fused 2D squarings) a chain measured become the kernel-selection
+    hints of the next chain with the same key."""
+    FUSE_STATS["chains"] += 1
+    if len(dm) > n + 1 and dm[n + 1] > 0:      # some window could not do all the levels the hints promised
+        FUSE_STATS["refused"] += 1
+    _CHAIN_HINTS[key] = list(dm)
+
+
+_CHAIN_HINTS = _HintCache()     # (device, velocity shape, n, slot) -> displacement of phi_0..phi_n measured by the last backward of such a chain
 _WARP_HINTS = _HintCache()      # (device, spatial dims) -> displacement of the last grid of that shape whose bound was read
 
 

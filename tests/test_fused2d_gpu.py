@@ -21,7 +21,9 @@ def _chain(phi0, n, hints, fuse):
     rows = torch.zeros(n + 2, ops.DISP_SLOTS, device=DEV)
     fields = torch.full((n - 1,) + tuple(phi0.shape), float("nan"), device=DEV)
     pos = torch.empty_like(phi0)
-    harr = None if hints is None else (ctypes.c_int32 * n)(*hints)
+    # (bits 8.. of a hint: the displacement estimate in 1/1024 pixel; 1 = "known and tiny" -- the tests decide k by how many
+    # leading hints say so)
+    harr = None if hints is None else (ctypes.c_int32 * n)(*[h | ((1 << 8) if h == 1 else 0) for h in hints])
     _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(phi0), ops._ptr(fields), ops._ptr(pos), N, d, _lib.dims_array(dims), n,
                                            ops._ptr(rows), harr, ops._ptr(rows[n + 1]) if fuse else None, ops._stream()),
                "expo_chain_fwd")
@@ -57,6 +59,20 @@ def test_fused_levels_equal_the_per_squaring_launches(dims, k):
     assert not torch.isnan(out[0][:k]).any()
 
 
+def test_partial_deficit_repeats_only_the_missing_levels():
+    """Hints promise 4 sub-pixel levels, the field allows 2 (phi_2 moves more than a pixel): the fused kernel stops after
+    level 2 everywhere it must, records a deficit of 2, and the gated launches of levels 3 and 4 run -- same bits."""
+    n, dims = 8, (128, 256)
+    phi0 = _phi0(4, dims, 0.4, 9)                   # phi_1 ~0.8 px, phi_2 ~1.6 px
+    ref = _chain(phi0, n, None, False)
+    assert ref[2][1] < 0.999 and ref[2][2] > 1.0, ref[2][:4]
+    out = _chain(phi0, n, [1, 1, 1, 1, 0, 0, 0, 0], True)
+    assert out[3] == 2.0
+    assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+    for m in range(n - 1):
+        assert torch.equal(out[0][m], ref[0][m]), m
+
+
 @pytest.mark.parametrize("case", ["all", "one_window", "nan"])
 def test_fused_premise_violated_falls_back(case):
     """Hints that are too optimistic: the kernel's own check refuses, raises the flag, and the gated ordinary launches
@@ -72,7 +88,7 @@ def test_fused_premise_violated_falls_back(case):
     hints = [1, 1, 1, 1, 0, 0, 0, 0]
     ref = _chain(phi0, n, None, False)
     out = _chain(phi0, n, hints, True)
-    assert out[3] == 1.0
+    assert out[3] == 4.0          # the deficit: a window could not do any of the 4 levels
     for m in range(n - 1):
         assert torch.equal(torch.nan_to_num(out[0][m], nan=7.0), torch.nan_to_num(ref[0][m], nan=7.0)), (case, m)
     assert torch.equal(torch.nan_to_num(out[1], nan=7.0), torch.nan_to_num(ref[1], nan=7.0))

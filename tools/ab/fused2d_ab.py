@@ -46,7 +46,7 @@ def main():
                    "chain")
     fwd(None, False)
     dm = ops.raw_slot_rows_max(disp).tolist()
-    hints = [ops._hint_bits(x) >> 8 for x in dm[:n]]
+    hints = [(ops._hint_bits(x) >> 8) | (ops._fine_bits(x) << 8) for x in dm[:n]]
     print("displacement of phi_0..phi_%d (px): %s" % (n - 1, " ".join("%.2f" % x for x in dm[:n])), " pos %.2f" % dm[n])
     print("hints", hints)
     ref = (fields.clone(), pos.clone())
@@ -70,8 +70,8 @@ def main():
     print("expo_chain_fwd  batch %d x 2 x %d x %d: one launch per squaring %.1f us, fused leading squarings %.1f us; flag %.0f; bit-identical %s"
           % (NB, dims[0], dims[1], t_plain, t_fused, float(disp[n + 1, 0]), same))
     for k in (2, 3, 4, 5):
-        hk = [1] * k + [9] * (n - k)
-        if all(h == 1 for h in hints[:k]):
+        hk = [1 | (1 << 8)] * k + [9] * (n - k)
+        if all((h & 0xff) == 1 for h in hints[:k]):
             print("   k = %d: %.1f us" % (k, timeit(lambda: fwd(hk, True))))
     # ---- backward: the chain entry (fuses the trailing exact sub-pixel steps) against n separate calls
     fwd(None, False)
