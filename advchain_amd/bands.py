@@ -108,6 +108,19 @@ class BandTables(object):
         self.itab = torch.from_numpy(np.concatenate(ints).astype(np.int32)).to(device)
         self.ftab = torch.from_numpy(np.concatenate(floats).astype(np.float32)).to(device)
         self.mats = mats  # kept on the host for tests / debugging
+        # the densified bands of the innermost axis (advchain_band_reduce_rows_dense): wd[k][j] = weight of input lo[k] + j
+        # for coefficient k -- what the adjoint kernels used to rebuild per workgroup from (start, lo, hi, w)
+        start, lo, hi = ints[-3], ints[-2], ints[-1]
+        w = floats[-1].reshape(self.S[-1], self.B[-1])
+        WB = int(max(1, (hi - lo).max()))
+        wd = np.zeros((self.g[-1], WB), dtype=np.float32)
+        for k in range(self.g[-1]):
+            for j in range(int(hi[k] - lo[k])):
+                s2 = int(lo[k]) + j
+                b = k - int(start[s2])
+                if 0 <= b < self.B[-1]:
+                    wd[k, j] = w[s2, b]
+        self.dense_inner = (torch.from_numpy(wd.reshape(-1)).to(device), torch.from_numpy(lo.astype(np.int32)).to(device), WB)
 
     @property
     def coef_dims(self):

@@ -257,29 +257,39 @@ k_band_reduce_axis(const float* __restrict__ in, const float* __restrict__ in2, 
 }
 
 // Innermost-axis variant (inner == 1, S % 4 == 0): the full-resolution pass, which reads the whole gradient once.
-// A wave stages R consecutive rows in its LDS slab with 16-byte loads (fusing (in - in2)); lane (row, k) then takes
-// its banded dot product from LDS.  The band of coefficient k is densified once per workgroup into LDS
-// (Wd[k][j] = weight of input lo[k] + j), so the inner loop touches no global memory.
-constexpr int kBrSlab = 1024;        // floats per wave
-__global__ void __launch_bounds__(kBlock)
+// A wave stages RW consecutive rows in its LDS slab with 16-byte loads (fusing (in - in2)); lane (r, kg) then takes the
+// banded dot products of coefficients kg, kg + KG, kg + 2 KG, ... of row r from LDS.  The band of coefficient k is
+// densified once per workgroup into LDS (Wd[k][j] = weight of input lo[k] + j), so the inner loop touches no global
+// memory.
+//
+// Bank conflicts were this kernel (round 3: 31 us for 67 MB at cfg-2, 2.2 TB/s): with lanes = (4 rows) x (16 coefficients),
+// rows 256 floats apart and bands starting every 16 floats, the 64 reads of one tap hit 4 banks -- a 16-way conflict, 16
+// LDS passes per ds_read.  Now rows are S + 1 floats apart (bank = row + column), a wave holds RW = 64 / KG rows and the KG
+// coefficients in flight at a step are NEIGHBOURS (kg + KG i): for a 16x upsampling (bands 16 apart, KG = 4) the 64 lanes of
+// a step read 64 different banks.  Same sums in the same order: bit-identical to the round-3 kernel.
+constexpr int kBrThreads = 128;      // 2 waves: a slab of 16 rows x 257 floats per wave is 16 KiB
+template <int KG>
+__global__ void __launch_bounds__(kBrThreads)
 k_band_reduce_rows(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int64_t rows,
-                   BandAxis A, float scale, int R, int iters) {
-  __shared__ __attribute__((aligned(16))) float slab[kBlock / 64][kBrSlab];
+                   BandAxis A, float scale, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float slabs[];      // [waves][RW][S + 1]
   __shared__ float Wd[kBrMaxW];
   __shared__ int lo_s[64];
+  constexpr int RW = 64 / KG, NWV = kBrThreads / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int S = A.S, g = A.g, B = A.B;
   const int WB = stage_band(A, Wd, lo_s);
   const bool dense = WB > 0;                  // otherwise: weights straight from the (global) band table
   const int q = S >> 2;                          // float4 per row
-  float* my = slab[wave];
-  const int row = lane / g, k = lane - row * g;  // lanes >= R * g idle in the dot phase
+  const int pitch = S + 1;
+  float* my = slabs + wave * RW * pitch;
+  const int r = lane % RW, kg = lane / RW;
   for (int it = 0; it < iters; ++it) {
-    const int64_t base = (((int64_t)blockIdx.x * iters + it) * (kBlock / 64) + wave) * R;
+    const int64_t base = (((int64_t)blockIdx.x * iters + it) * NWV + wave) * RW;
     __syncthreads();   // previous pass consumed (first time: the tables are in place)
-    for (int idx = lane; idx < R * q; idx += 64) {
-      const int r = idx / q, x4 = idx - r * q;
-      const int64_t gr = base + r;
+    for (int idx = lane; idx < RW * q; idx += 64) {
+      const int rr = idx / q, x4 = idx - rr * q;
+      const int64_t gr = base + rr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < rows) {
         v = *reinterpret_cast<const float4*>(in + gr * S + 4 * x4);
@@ -288,25 +298,140 @@ k_band_reduce_rows(const float* __restrict__ in, const float* __restrict__ in2, 
           v = make_float4(v.x - u.x, v.y - u.y, v.z - u.z, v.w - u.w);
         }
       }
-      *reinterpret_cast<float4*>(my + r * S + 4 * x4) = v;
+      float* dst = my + rr * pitch + 4 * x4;     // (rows are S + 1 apart: dword stores)
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
     __syncthreads();
-    const int64_t gr = base + row;
-    if (row < R && gr < rows) {
-      const float* x = my + row * S;
-      const int lo = dense ? lo_s[k] : A.lo[k];
-      float acc = 0.f;
+    const int64_t gr = base + r;
+    if (gr < rows) {
+      const float* x = my + r * pitch;
       if (dense) {
-        const float* w = Wd + k * WB;
-        const int len = min(WB, S - lo);
-        for (int j = 0; j < len; ++j) acc = fmaf(x[lo + j], w[j], acc);
-      } else {
-        for (int s2 = lo; s2 < A.hi[k]; ++s2) {
-          const int b = k - A.start[s2];
-          if (b >= 0 && b < B) acc = fmaf(x[s2], A.w[s2 * B + b], acc);
+        // two coefficients of the lane at a time, eight taps requested before the first is used: the sums keep their
+        // order (one fma chain per coefficient, ascending j) but the LDS round trips overlap.  A tap beyond the row
+        // (lo + j >= S) carries weight 0 in Wd; its index is clamped into the row instead of leaving the loop early.
+        for (int k0 = kg; k0 < g; k0 += 2 * KG) {
+          const int k1 = k0 + KG;
+          const bool two = k1 < g;
+          const int lo0 = lo_s[k0], lo1 = lo_s[two ? k1 : k0];
+          const float* w0 = Wd + k0 * WB;
+          const float* w1 = Wd + (two ? k1 : k0) * WB;
+          float a0 = 0.f, a1 = 0.f;
+          int j = 0;
+          for (; j + 8 <= WB; j += 8) {
+            float x0[8], x1[8], c0[8], c1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              x0[u] = x[min(lo0 + j + u, S - 1)]; c0[u] = w0[j + u];
+              x1[u] = x[min(lo1 + j + u, S - 1)]; c1[u] = w1[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 = fmaf(x0[u], c0[u], a0); a1 = fmaf(x1[u], c1[u], a1); }
+          }
+          for (; j < WB; ++j) {
+            a0 = fmaf(x[min(lo0 + j, S - 1)], w0[j], a0);
+            a1 = fmaf(x[min(lo1 + j, S - 1)], w1[j], a1);
+          }
+          out[gr * g + k0] = a0 * scale;
+          if (two) out[gr * g + k1] = a1 * scale;
         }
+      } else
+      for (int k = kg; k < g; k += KG) {
+        const int lo = A.lo[k];
+        float acc = 0.f;
+        {
+          for (int s2 = lo; s2 < A.hi[k]; ++s2) {
+            const int b = k - A.start[s2];
+            if (b >= 0 && b < B) acc = fmaf(x[s2], A.w[s2 * B + b], acc);
+          }
+        }
+        out[gr * g + k] = acc * scale;
       }
-      out[gr * g + k] = acc * scale;
+    }
+  }
+}
+
+// The same pass with the densified bands handed in by the caller (bands.py builds them once per table on the host): the
+// round-4 profile showed the kernel above spending its time not on bytes but on the per-workgroup table preparation -- four
+// dependent L2 round trips (lo / hi -> start -> w) in front of the first barrier, 2048 times per launch (27-31 us for 67 MB
+// at cfg-2).  Here a workgroup requests its first rows, then the dense table (one coalesced load), and only then waits;
+// the rows of the next iteration are requested before the dot products of the current one.
+template <int KG>
+__global__ void __launch_bounds__(kBrThreads)
+k_band_reduce_rows_dense(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int64_t rows,
+                         const float* __restrict__ wd, const int* __restrict__ lo_g, int S, int g, int WB, float scale, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float slabs[];      // [waves][RW][S + 1], then Wd[g * WB]
+  __shared__ int lo_s[64];
+  constexpr int RW = 64 / KG, NWV = kBrThreads / 64;
+  constexpr int QMAX = 8;                        // float4 per lane and iteration at most: RW * (S / 4) <= 512
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = S >> 2;
+  const int pitch = S + 1;
+  float* my = slabs + wave * RW * pitch;
+  float* Wd = slabs + NWV * RW * pitch;
+  const int r = lane % RW, kg = lane / RW;
+  const int nq = RW * q;
+  float4 v[QMAX];
+  auto request = [&](int it) {
+    const int64_t base = (((int64_t)blockIdx.x * iters + it) * NWV + wave) * RW;
+#pragma unroll
+    for (int u = 0; u < QMAX; ++u) {
+      const int idx = lane + 64 * u;
+      const int rr = idx / q, x4 = idx - rr * q;
+      const int64_t gr = base + rr;
+      const bool ok = idx < nq && gr < rows;
+      const int64_t off = ok ? gr * S + 4 * x4 : 0;      // (unconditional loads from a clamped address)
+      float4 a = *reinterpret_cast<const float4*>(in + off);
+      if (in2) {
+        const float4 b = *reinterpret_cast<const float4*>(in2 + off);
+        a = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+      }
+      v[u] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  request(0);
+  for (int i = threadIdx.x; i < g * WB; i += kBrThreads) Wd[i] = wd[i];
+  if (threadIdx.x < g) lo_s[threadIdx.x] = lo_g[threadIdx.x];
+  for (int it = 0; it < iters; ++it) {
+    const int64_t base = (((int64_t)blockIdx.x * iters + it) * NWV + wave) * RW;
+    if (it > 0) __syncthreads();                 // the previous pass has consumed the slab
+#pragma unroll
+    for (int u = 0; u < QMAX; ++u) {
+      const int idx = lane + 64 * u;
+      if (idx >= nq) continue;
+      const int rr = idx / q, x4 = idx - rr * q;
+      float* dst = my + rr * pitch + 4 * x4;     // (rows are S + 1 apart: dword stores)
+      dst[0] = v[u].x; dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w;
+    }
+    __syncthreads();
+    if (it + 1 < iters) request(it + 1);         // in flight under the dot products
+    const int64_t gr = base + r;
+    if (gr < rows) {
+      const float* x = my + r * pitch;
+      for (int k0 = kg; k0 < g; k0 += 2 * KG) {
+        const int k1 = k0 + KG;
+        const bool two = k1 < g;
+        const int lo0 = lo_s[k0], lo1 = lo_s[two ? k1 : k0];
+        const float* w0 = Wd + k0 * WB;
+        const float* w1 = Wd + (two ? k1 : k0) * WB;
+        float a0 = 0.f, a1 = 0.f;
+        int j = 0;
+        for (; j + 8 <= WB; j += 8) {
+          float x0[8], x1[8], c0[8], c1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            x0[u] = x[min(lo0 + j + u, S - 1)]; c0[u] = w0[j + u];
+            x1[u] = x[min(lo1 + j + u, S - 1)]; c1[u] = w1[j + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { a0 = fmaf(x0[u], c0[u], a0); a1 = fmaf(x1[u], c1[u], a1); }
+        }
+        for (; j < WB; ++j) {
+          a0 = fmaf(x[min(lo0 + j, S - 1)], w0[j], a0);
+          a1 = fmaf(x[min(lo1 + j, S - 1)], w1[j], a1);
+        }
+        out[gr * g + k0] = a0 * scale;
+        if (two) out[gr * g + k1] = a1 * scale;
+      }
     }
   }
 }
@@ -982,18 +1107,67 @@ int advchain_band_reduce_axis(const float* in, const float* in2, float* out, con
   if (total == 0) return ADVCHAIN_OK;
   const BandAxis& A = T.a[axis];
   const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
-  if (inner == 1 && A.S % 4 == 0 && A.S <= kBrSlab && A.g <= 64 && aligned) {
-    int R = 64 / A.g;
-    if (R * A.S > kBrSlab) R = kBrSlab / A.S;
-    const int iters = 4;
-    const int64_t rows_per_block = (int64_t)(kBlock / 64) * R * iters;
-    hipLaunchKernelGGL(k_band_reduce_rows, dim3(advchain_blocks(outer, (int)rows_per_block)), dim3(kBlock), 0,
-                       (hipStream_t)stream, in, in2, out, outer, A, scale, R, iters);
+  if (inner == 1 && A.S % 4 == 0 && A.S <= 1024 && A.g <= 64 && aligned) {
+    // coefficient groups per wave KG (a wave holds 64 / KG rows of S + 1 floats): 4 is conflict-free for a 16x upsampling,
+    // but 16 rows a wave leave a 16 k-row problem with 1024 waves -- take 8 (2-way conflicts) or 16 (4-way) until there
+    // are ~4096 waves, and whatever keeps the slab of a wave within 16 KiB
+    int KG = A.g >= 4 ? 4 : (A.g >= 2 ? 2 : 1);
+    while (KG < 16 && KG * 2 <= A.g && ((size_t)(64 / KG) * (A.S + 1) * sizeof(float) > 16 * 1024 + 512 || outer / (64 / KG) < 4096)) KG *= 2;
+    const int RW = 64 / KG;
+    int iters = (int)(outer / ((int64_t)RW * (kBrThreads / 64) * 2048));      // ~2048 workgroups at least
+    iters = iters < 1 ? 1 : (iters > 4 ? 4 : iters);
+    const int64_t rows_per_block = (int64_t)(kBrThreads / 64) * RW * iters;
+    const size_t lds = (size_t)(kBrThreads / 64) * RW * (A.S + 1) * sizeof(float);
+    dim3 grid(advchain_blocks(outer, (int)rows_per_block)), block(kBrThreads);
+    hipStream_t st = (hipStream_t)stream;
+    switch (KG) {
+      case 1: hipLaunchKernelGGL(k_band_reduce_rows<1>, grid, block, lds, st, in, in2, out, outer, A, scale, iters); break;
+      case 2: hipLaunchKernelGGL(k_band_reduce_rows<2>, grid, block, lds, st, in, in2, out, outer, A, scale, iters); break;
+      case 4: hipLaunchKernelGGL(k_band_reduce_rows<4>, grid, block, lds, st, in, in2, out, outer, A, scale, iters); break;
+      case 8: hipLaunchKernelGGL(k_band_reduce_rows<8>, grid, block, lds, st, in, in2, out, outer, A, scale, iters); break;
+      default: hipLaunchKernelGGL(k_band_reduce_rows<16>, grid, block, lds, st, in, in2, out, outer, A, scale, iters); break;
+    }
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
   }
   hipLaunchKernelGGL(k_band_reduce_axis, dim3(advchain_blocks(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      in2, out, outer, (int)inner, T.a[axis], scale);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// The innermost-axis adjoint pass with the caller's densified bands: wd[g][WB] (weight of input lo[k] + j for coefficient
+// k, zero beyond the band) and lo[g].  in: (rows, S) [- in2] -> out: (rows, g).  ADVCHAIN_ERR_UNSUPPORTED for shapes the
+// kernel does not take (the caller then uses advchain_band_reduce_axis): S % 4, S <= 1024, g <= 64, g * WB <= 4096,
+// 16-byte aligned inputs.
+int advchain_band_reduce_rows_dense(const float* in, const float* in2, float* out, const float* wd, const int32_t* lo,
+                                    int64_t rows, int64_t S, int64_t g, int64_t WB, float scale, void* stream) {
+  ADVCHAIN_CHECK_ARG(in && out && wd && lo, "band_reduce_rows_dense: null pointer");
+  ADVCHAIN_CHECK_ARG(rows >= 0 && S >= 1 && g >= 1 && WB >= 1, "band_reduce_rows_dense: bad shape");
+  if (rows == 0) return ADVCHAIN_OK;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+  if (S % 4 != 0 || S > 1024 || g > 64 || g * WB > kBrMaxW || !aligned) return ADVCHAIN_ERR_UNSUPPORTED;
+  // coefficient groups per wave KG (a wave holds RW = 64 / KG rows): 4 is conflict-free for a 16x upsampling; fewer rows a
+  // wave (KG = 8, 16) until there are ~4096 waves and RW * S / 4 <= 512 float4 per wave and iteration
+  int KG = g >= 4 ? 4 : (g >= 2 ? 2 : 1);
+  while (KG < 16 && ((64 / KG) * (S / 4) > 512 || rows / (64 / KG) < 4096)) KG *= 2;      // (KG may exceed g: idle lanes in the dot phase)
+  const int RW = 64 / KG;
+  if (RW * (S / 4) > 512) return ADVCHAIN_ERR_UNSUPPORTED;
+  int iters = (int)(rows / ((int64_t)RW * (kBrThreads / 64) * 2048));      // ~2048 workgroups at least
+  iters = iters < 1 ? 1 : (iters > 4 ? 4 : iters);
+  const int64_t rows_per_block = (int64_t)(kBrThreads / 64) * RW * iters;
+  const size_t lds = ((size_t)(kBrThreads / 64) * RW * (S + 1) + (size_t)(g * WB)) * sizeof(float);
+  dim3 grid(advchain_blocks(rows, (int)rows_per_block)), block(kBrThreads);
+  hipStream_t st = (hipStream_t)stream;
+#define BRD_GO(KG_) hipLaunchKernelGGL(k_band_reduce_rows_dense<KG_>, grid, block, lds, st, in, in2, out, rows, wd, lo, (int)S, (int)g, (int)WB, scale, iters)
+  switch (KG) {
+    case 1: BRD_GO(1); break;
+    case 2: BRD_GO(2); break;
+    case 4: BRD_GO(4); break;
+    case 8: BRD_GO(8); break;
+    default: BRD_GO(16); break;
+  }
+#undef BRD_GO
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

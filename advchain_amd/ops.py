@@ -424,9 +424,18 @@ def raw_tp_adjoint(gfull, tables, gfull2=None, scale=1.0):
             inner *= shape[a]
         shape[ax] = g[ax]
         out = torch.empty((N, C) + tuple(shape[3 - tables.ndim:]), device=gfull.device, dtype=torch.float32)
-        _lib.check(lib.advchain_band_reduce_axis(_ptr(cur), _ptr(cur2), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
-                                                 Sa, ga, Ba, ax, outer, inner, float(scale) if first else 1.0,
-                                                 _stream()), "band_reduce_axis")
+        rc = -2
+        if ax == 2 and inner == 1 and getattr(tables, "dense_inner", None) is not None:
+            # the full-resolution pass with the bands densified once per table (same sums, same order)
+            wd, lo, WB = tables.dense_inner
+            rc = lib.advchain_band_reduce_rows_dense(_ptr(cur), _ptr(cur2), _ptr(out), _ptr(wd), _ptr(lo), outer, S[2], g[2], WB,
+                                                     float(scale) if first else 1.0, _stream())
+            if rc != -2:
+                _lib.check(rc, "band_reduce_rows_dense")
+        if rc == -2:
+            _lib.check(lib.advchain_band_reduce_axis(_ptr(cur), _ptr(cur2), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
+                                                     Sa, ga, Ba, ax, outer, inner, float(scale) if first else 1.0,
+                                                     _stream()), "band_reduce_axis")
         cur, cur2, first = out, None, False
     if first:  # degenerate: nothing to reduce
         cur = (gfull - gfull2 if gfull2 is not None else gfull) * scale

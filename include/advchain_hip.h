@@ -203,6 +203,13 @@ int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, c
 int advchain_band_reduce_axis(const float* in, const float* in2, float* out, const int32_t* itab, const float* ftab,
                               const int64_t* S, const int64_t* g, const int64_t* B, int axis, int64_t outer,
                               int64_t inner, float scale, void* stream);
+/* The innermost-axis pass of the same adjoint (inner == 1: the full-resolution pass, which reads the whole gradient once) with
+ * the bands densified by the caller once per table: wd[g][WB] = weight of input lo[k] + j for coefficient k (zero beyond its
+ * band), lo[g].  in: (rows, S) [minus in2] -> out: (rows, g) * scale.  Returns ADVCHAIN_ERR_UNSUPPORTED (-2) for shapes it
+ * does not take (S % 4 != 0, S > 1024, g > 64, g * WB > 4096, unaligned inputs): use advchain_band_reduce_axis then.
+ * Same sums in the same order as that entry. */
+int advchain_band_reduce_rows_dense(const float* in, const float* in2, float* out, const float* wd, const int32_t* lo,
+                                    int64_t rows, int64_t S, int64_t g, int64_t WB, float scale, void* stream);
 
 /* ---- bias field ------------------------------------------------------------------------
  * replaces: AdvBias.compute_smoothed_bias + clip_bias + multiply, adv_bias.py:279-356,186:
