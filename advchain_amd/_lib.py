@@ -54,6 +54,8 @@ PROTOTYPES = {
     "advchain_norm_axpy_gated": (_I, [_P, _P, _P, _P, _F, _L, _L, _P, _P, _P]),
     "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
     "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
+    "advchain_consistency_fused_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
+    "advchain_consistency_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
 }
 
 _lib = None

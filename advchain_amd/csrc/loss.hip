@@ -777,6 +777,249 @@ k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f2, really fused (round 4): the forward keeps NO per-voxel intermediate but the edge responses R the backward's stencil
+// adjoint needs -- softmax(pred), softmax(ref), their difference, the masked squared error, the KL sum and the 3^d edge
+// stencils all happen in the marching kernel's registers, straight from the logits; the backward recomputes the softmax at
+// its own voxel instead of reading P and D back.  Round 3 ran three kernels with P and D (2K channels, written once and
+// read twice) in between: 27 channel passes forward + 19 backward at K = 4; now 15 + 19 (9 compulsory reads + 6 R forward),
+// and two launches instead of three.  The price is arithmetic nobody waits for: a voxel's softmax is evaluated by every
+// strip that reads it as a stencil neighbour (3x in z, (mlen + 2) / mlen in y).
+// Same per-voxel arithmetic as k_softmax_diff_v4 / k_edge_fwd_march4 / k_consistency_bwd_march4.
+// ---------------------------------------------------------------------------------------------
+// softmax of the 4 voxels at `o` (+ k V) of both logit maps: P, T (the reference itself when it already holds probabilities);
+// with LOGS also log-softmax terms for the KL sum
+template <int K, bool LOGS>
+__device__ __forceinline__ void softmax_pair4(const float* __restrict__ pred, const float* __restrict__ ref, int64_t o, int V,
+                                              int ref_is_prob, float (&P)[K][4], float (&T)[K][4], float (&lq)[LOGS ? K : 1][4],
+                                              float (&lt)[LOGS ? K : 1][4]) {
+  float p[K][4], r[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 a = *reinterpret_cast<const float4*>(pred + o + (int64_t)k * V);
+    const float4 b = *reinterpret_cast<const float4*>(ref + o + (int64_t)k * V);
+    p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w;
+    r[k][0] = b.x; r[k][1] = b.y; r[k][2] = b.z; r[k][3] = b.w;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float mp = -INFINITY, mr = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { mp = fmaxf(mp, p[k][q]); mr = fmaxf(mr, r[k][q]); }
+    float sp = 0.f, sr = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sp += expf(p[k][q] - mp); sr += expf(r[k][q] - mr); }
+    const float lsp = LOGS ? logf(sp) : 0.f, lsr = LOGS ? logf(sr) : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float zp = p[k][q] - mp, zr = r[k][q] - mr;
+      P[k][q] = expf(zp) / sp;
+      T[k][q] = ref_is_prob ? r[k][q] : expf(zr) / sr;
+      if (LOGS) { lq[k][q] = zp - lsp; lt[k][q] = zr - lsr; }
+    }
+  }
+}
+
+template <int DIM, int K, bool KL, bool EDGES>
+__global__ void __launch_bounds__(kBlock)
+k_loss_fused_fwd4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
+                  float* __restrict__ R, float* __restrict__ sums, Dims d, int mlen, int ref_is_prob) {
+  __shared__ float smem[16];
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};          // mse, edge A, edge B, kl
+  int i0, y0, x;
+  bool first, last, ok;
+  strip_decode4(d, mlen, i0, y0, x, first, last, ok);
+  const int y1 = min(y0 + mlen, d.s1);
+  Quad zs[EDGES ? K - 1 : 1][3], zd[EDGES ? K - 1 : 1][3];
+  // row j1 of the planes i0 - 1 .. i0 + 1: softmax difference of its 4 voxels, folded over z and x into window slot `slot`;
+  // the voxels of the strip's OWN rows (plane i0) also enter the mse / kl sums
+  auto row = [&](int j1, int slot) {
+    if (EDGES) {
+#pragma unroll
+      for (int k = 1; k < K; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { zs[k - 1][slot].v[q] = 0.f; zd[k - 1][slot].v[q] = 0.f; }
+    }
+#pragma unroll
+    for (int a0 = ((DIM == 3 && EDGES) ? 0 : 1); a0 < ((DIM == 3 && EDGES) ? 3 : 2); ++a0) {
+      const int j0 = i0 + a0 - 1;
+      const bool in = (j0 >= 0) && (j0 < d.s0) && (j1 >= 0) && (j1 < d.s1);
+      const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1);
+      const int v = (c0 * d.s1 + c1) * d.s2 + x;
+      float P[K][4], T[K][4], lq[KL ? K : 1][4], lt[KL ? K : 1][4];
+      softmax_pair4<K, KL>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, P, T, lq, lt);
+      if (a0 == 1 && in && ok && j1 >= y0 && j1 < y1) {
+        float m[4] = {1.f, 1.f, 1.f, 1.f};
+        if (mask) {
+          const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+          m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float e = P[k][q] * m[q] - T[k][q] * m[q];
+            acc[0] += e * e;
+            if (KL) acc[3] += kl_term(T[k][q], lt[k][q], lq[k][q], m[q], ref_is_prob);
+          }
+      }
+      if (EDGES) {
+        const float w = DIM == 3 ? hsm(a0) : 1.f;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          float c[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) c[q] = in ? P[k][q] - T[k][q] : 0.f;      // D; zero padding outside the volume
+          const float pw = lane_prev_f(c[3]), nx = lane_next_f(c[0]);
+          const float l[4] = {first ? 0.f : pw, c[0], c[1], c[2]};
+          const float r[4] = {c[1], c[2], c[3], last ? 0.f : nx};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            zs[k - 1][slot].v[q] += w * (l[q] + 2.f * c[q] + r[q]);
+            zd[k - 1][slot].v[q] += w * (l[q] - r[q]);
+          }
+        }
+      }
+    }
+  };
+  if (EDGES) { row(y0 - 1, 0); }
+  row(y0, 1);
+  for (int i1 = y0; i1 < y1; ++i1) {
+    if (EDGES) {
+      row(i1 + 1, 2);
+      const int v = (i0 * d.s1 + i1) * d.s2 + x;
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (mask) {
+        const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+      }
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        float ra[4], rb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float ga, gb;
+          if (DIM == 2) {
+            ga = zd[k - 1][0].v[q] + 2.f * zd[k - 1][1].v[q] + zd[k - 1][2].v[q];
+            gb = zs[k - 1][0].v[q] - zs[k - 1][2].v[q];
+          } else {
+            ga = zs[k - 1][0].v[q] - zs[k - 1][2].v[q];
+            gb = zd[k - 1][0].v[q] + 2.f * zd[k - 1][1].v[q] + zd[k - 1][2].v[q];
+          }
+          const float ea = ga * m[q], eb = gb * m[q];
+          if (ok) { acc[1] += ea * ea; acc[2] += eb * eb; }
+          ra[q] = 2.f * m[q] * m[q] * ga;
+          rb[q] = 2.f * m[q] * m[q] * gb;
+        }
+        if (R && ok) {
+          *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+          *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        }
+        zs[k - 1][0] = zs[k - 1][1]; zs[k - 1][1] = zs[k - 1][2];
+        zd[k - 1][0] = zd[k - 1][1]; zd[k - 1][1] = zd[k - 1][2];
+      }
+    } else if (i1 + 1 < y1) {
+      row(i1 + 1, 1);
+    }
+  }
+  block_sum<4>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + sum_slot(), acc[0]);
+    if (EDGES) {
+      atomic_add_f32(sums + kSumSlots + sum_slot(), acc[1]);
+      atomic_add_f32(sums + 2 * kSumSlots + sum_slot(), acc[2]);
+    }
+    if (KL) atomic_add_f32(sums + 3 * kSumSlots + sum_slot(), acc[3]);
+  }
+}
+
+// backward of the fused form: k_consistency_bwd_march4 with P and D = P - T recomputed from the logits at the voxel
+template <int DIM, int K, bool KL>
+__global__ void __launch_bounds__(kBlock)
+k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ R,
+                  const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
+                  float c_mse, float c_a, float c_b, Dims d, int mlen, float c_kl, int ref_is_prob) {
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  int i0, y0, x;
+  bool first, last, ok;
+  strip_decode4(d, mlen, i0, y0, x, first, last, ok);
+  const float gs = gscale ? gscale[0] : 1.f;
+  Quad za[K - 1][3], zb[K - 1][3];
+  auto fold = [&](int k, int j1, Quad& a, Quad& b) {
+    const float* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
+    Quad as, ad, bs, bd;
+    fold_row4<DIM>(Ra, i0, j1, x, first, last, d, as, ad);
+    fold_row4<DIM>(Ra + V, i0, j1, x, first, last, d, bs, bd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a.v[q] = DIM == 3 ? as.v[q] : -ad.v[q];
+      b.v[q] = DIM == 3 ? -bd.v[q] : bs.v[q];
+    }
+  };
+  if (R) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      fold(k, y0 - 1, za[k - 1][0], zb[k - 1][0]);
+      fold(k, y0, za[k - 1][1], zb[k - 1][1]);
+    }
+  }
+  const int y1 = min(y0 + mlen, d.s1);
+  for (int i1 = y0; i1 < y1; ++i1) {
+    const int v = (i0 * d.s1 + i1) * d.s2 + x;
+    float gp[K][4], pk[K][4], tk[K][4], mt[KL ? K : 1][4], lq[1][4], lt[1][4];
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, klS[4] = {0.f, 0.f, 0.f, 0.f};
+    float m[4] = {1.f, 1.f, 1.f, 1.f};
+    if (mask) {
+      const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+      m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+    }
+    softmax_pair4<K, false>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, pk, tk, lq, lt);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k >= 1 && R) fold(k, i1 + 1, za[k - 1][2], zb[k - 1][2]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dv = pk[k][q] - tk[k][q];
+        float g = c_mse * 2.f * m[q] * m[q] * dv;
+        if (k >= 1 && R) {
+          float sa, sb;
+          if (DIM == 2) {
+            sa = za[k - 1][0].v[q] + 2.f * za[k - 1][1].v[q] + za[k - 1][2].v[q];
+            sb = zb[k - 1][2].v[q] - zb[k - 1][0].v[q];
+          } else {
+            sa = za[k - 1][2].v[q] - za[k - 1][0].v[q];
+            sb = zb[k - 1][0].v[q] + 2.f * zb[k - 1][1].v[q] + zb[k - 1][2].v[q];
+          }
+          g += c_a * sa + c_b * sb;
+        }
+        g *= gs;
+        gp[k][q] = g;
+        dot[q] += g * pk[k][q];
+        if (KL) { mt[k][q] = m[q] * kl_prob(pk[k][q] - dv, ref_is_prob); klS[q] += mt[k][q]; }
+      }
+      if (k >= 1 && R) {
+        za[k - 1][0] = za[k - 1][1]; za[k - 1][1] = za[k - 1][2];
+        zb[k - 1][0] = zb[k - 1][1]; zb[k - 1][1] = zb[k - 1][2];
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o4[q] = pk[k][q] * (gp[k][q] - dot[q]);
+          if (KL) o4[q] += gs * c_kl * (pk[k][q] * klS[q] - mt[k][q]);
+        }
+        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+  }
+}
+
 static inline dim3 march_grid(const Dims& d, int64_t N) {
   const int strips = (d.s2 >> 6) * ((d.s1 + kMarch - 1) / kMarch) * d.s0;
   return dim3((unsigned)((strips + kBlock / 64 - 1) / (kBlock / 64)), (unsigned)N);
@@ -971,6 +1214,68 @@ int advchain_consistency_bwd(const float* P, const float* D, const float* R, con
     else if (rows) hipLaunchKernelGGL(k_consistency_bwd_rows<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
     else hipLaunchKernelGGL(k_consistency_bwd<2>, g, b, 0, st, P, D, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, (int)K, d, mask_channels, c_kl, kl_is_gt);
   }
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// ---- f2 fused (round 4): see k_loss_fused_fwd4.  ADVCHAIN_ERR_UNSUPPORTED (-2) for what the 16-byte marching form does not
+// take (rows of 4j <= 256 voxels, K = 2..4, at most a one-channel mask, 16-byte aligned tensors): use the entries above.
+int advchain_consistency_fused_fwd(const float* pred, const float* ref, const float* mask, float* R, float* sums, int64_t N,
+                                   int64_t K, int ndim, const int64_t* dims, int mask_channels, int ref_is_prob, int want_edges,
+                                   int want_kl, void* stream) {
+  ADVCHAIN_CHECK_ARG(pred && ref && sums, "consistency_fused_fwd: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fused_fwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_fused_fwd: bad N/K (K <= 16)");
+  static const bool off = getenv("ADVCHAIN_NO_FUSED_LOSS") != nullptr;   // A/B knob
+  // 3D: measured SLOWER than the three-kernel form (same box, K = 4: 4 x 4 x 128 x 128 x 64 230 against 199 us, 8 x 4 x
+  // 160 x 160 x 80 978 against 835 us) -- the z fold of the marching stencil reads three planes per row, so every voxel's
+  // softmax is evaluated 3 x (mlen + 2) / mlen times and the row step issues 24 instead of 9 loads; it wins in 2D (124
+  // against 141 us at 32 x 4 x 256 x 256), where a row is folded once.  3D therefore stays on the unfused entries unless
+  // ADVCHAIN_FUSED_LOSS_3D is set (A/B); what 3D needs is a plane exchange through LDS, not this kernel.
+  static const bool on3d = getenv("ADVCHAIN_FUSED_LOSS_3D") != nullptr;
+  if (off || (ndim == 3 && !on3d) || K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const Dims d = lmake_dims(ndim, dims);
+  if (d.voxels() >= (1ll << 31) || !march4_ok(d, pred, ref, mask, R)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (N == 0) return ADVCHAIN_OK;
+  const bool edges = want_edges && K > 1;
+  if (edges && !R) R = nullptr;                      // (no gradient wanted: the sums only)
+  const int mlen = march4_len(d, N);
+  const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+#define FUSED_FWD(DIM_, K_) do { \
+    if (want_kl) { if (edges) hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, true, true>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); \
+                   else hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, true, false>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); } \
+    else { if (edges) hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, false, true>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); \
+           else hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, false, false>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); } } while (0)
+  if (ndim == 3) { switch (K) { case 2: FUSED_FWD(3, 2); break; case 3: FUSED_FWD(3, 3); break; default: FUSED_FWD(3, 4); break; } }
+  else { switch (K) { case 2: FUSED_FWD(2, 2); break; case 3: FUSED_FWD(2, 3); break; default: FUSED_FWD(2, 4); break; } }
+#undef FUSED_FWD
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_consistency_fused_bwd(const float* pred, const float* ref, const float* R, const float* mask,
+                                   const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, float c_kl,
+                                   int ref_is_prob, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                                   void* stream) {
+  ADVCHAIN_CHECK_ARG(pred && ref && grad_pred, "consistency_fused_bwd: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fused_bwd: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_fused_bwd: bad N/K (K <= 16)");
+  if (K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
+  const Dims d = lmake_dims(ndim, dims);
+  if (d.voxels() >= (1ll << 31) || !march4_ok(d, pred, ref, R, mask) || (reinterpret_cast<uintptr_t>(grad_pred) & 15) != 0)
+    return ADVCHAIN_ERR_UNSUPPORTED;
+  if (N == 0) return ADVCHAIN_OK;
+  const int mlen = march4_len(d, N);
+  const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  const bool kl = c_kl != 0.f;
+#define FUSED_BWD(DIM_, K_) do { \
+    if (kl) hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, true>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); \
+    else hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, false>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); } while (0)
+  if (ndim == 3) { switch (K) { case 2: FUSED_BWD(3, 2); break; case 3: FUSED_BWD(3, 3); break; default: FUSED_BWD(3, 4); break; } }
+  else { switch (K) { case 2: FUSED_BWD(2, 2); break; case 3: FUSED_BWD(2, 3); break; default: FUSED_BWD(2, 4); break; } }
+#undef FUSED_BWD
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

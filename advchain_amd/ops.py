@@ -153,6 +153,7 @@ DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
 ADAPTIVE_HALO = os.environ.get("ADVCHAIN_NO_ADAPTIVE_HALO") is None   # measure the displacement in forward and size the backward halos from it
 PAIR_FIELDS = os.environ.get("ADVCHAIN_NO_PAIR_FIELDS") is None       # a solver step integrates field(+v) and field(-v) as one batch
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
+FUSED_LOSS = True     # the consistency loss straight from the logits (no P / D intermediates); False: A/B tests
 FUSE_2D = True        # the leading sub-pixel squarings of a 2D chain in one launch (expo_fused2d.hip); False: A/B tests
 
 
@@ -1068,8 +1069,6 @@ class _Consistency(torch.autograd.Function):
         nd = pred.dim() - 2
         dims = _lib.dims_array(pred.shape[2:])
         mch = 1 if mask is None else mask.shape[1]
-        P = torch.empty_like(pred)
-        D = torch.empty_like(pred)
         need_grad = ctx.needs_input_grad[0]
         want_kl = coef[3] != 0.0
         R = None
@@ -1080,17 +1079,32 @@ class _Consistency(torch.autograd.Function):
         sums = torch.empty(4, device=pred.device, dtype=torch.float32)
         value = torch.empty((), device=pred.device, dtype=torch.float32)
         slots = _persistent_zeros("loss", (4, 64), pred.device)   # per-workgroup partials, 64 slots per sum; zeroed by the finisher
+        lib = _lib.load()
         try:
-            _lib.check(_lib.load().advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
-                                                            _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
-                                                            int(want_edges), int(want_kl), _stream()), "consistency_fwd")
-            _lib.check(_lib.load().advchain_consistency_finish(_ptr(slots), _lib.float_array(coef), _ptr(sums), _ptr(value), 1,
-                                                               _stream()), "consistency_finish")
+            # f2 fused: one marching kernel straight from the logits, nothing saved but R (K = 2..4, rows of 4j <= 256 voxels)
+            rc = lib.advchain_consistency_fused_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(R), _ptr(slots), N, K, nd, dims, mch,
+                                                    int(ref_is_prob), int(want_edges), int(want_kl), _stream()) if FUSED_LOSS else -2
+            fused = rc != -2
+            if fused:
+                _lib.check(rc, "consistency_fused_fwd")
+                P = D = None
+            else:
+                P = torch.empty_like(pred)
+                D = torch.empty_like(pred)
+                _lib.check(lib.advchain_consistency_fwd(_ptr(pred), _ptr(ref), _ptr(mask), _ptr(P), _ptr(D), _ptr(R),
+                                                        _ptr(slots), N, K, nd, dims, mch, int(ref_is_prob),
+                                                        int(want_edges), int(want_kl), _stream()), "consistency_fwd")
+            _lib.check(lib.advchain_consistency_finish(_ptr(slots), _lib.float_array(coef), _ptr(sums), _ptr(value), 1,
+                                                       _stream()), "consistency_finish")
         except BaseException:
             _forget_persistent(slots)
             raise
         if need_grad:
-            ctx.save_for_backward(P, D, R, mask)
+            if fused:
+                ctx.save_for_backward(pred, ref, R, mask)
+            else:
+                ctx.save_for_backward(P, D, R, mask)
+        ctx.fused = fused
         ctx.cfg = (coef, mch, int(ref_is_prob))
         ctx.mark_non_differentiable(sums)
         ctx.set_materialize_grads(False)      # (no zero tensor for the gradient of `sums`)
@@ -1100,16 +1114,17 @@ class _Consistency(torch.autograd.Function):
     def backward(ctx, gloss, _gsums):
         if gloss is None:
             return None, None, None, None, None, None
-        P, D, R, mask = ctx.saved_tensors
+        P, D, R, mask = ctx.saved_tensors              # (fused: pred, ref, R, mask)
         coef, mch, is_gt = ctx.cfg
         N, K = P.shape[:2]
         nd = P.dim() - 2
         gs = _dev(gloss.reshape(1), "grad")
         gpred = torch.empty_like(P)
-        _lib.check(_lib.load().advchain_consistency_bwd(_ptr(P), _ptr(D), _ptr(R), _ptr(mask), _ptr(gs), _ptr(gpred),
-                                                        float(coef[0]), float(coef[1]), float(coef[2]), float(coef[3]),
-                                                        is_gt, N, K, nd, _lib.dims_array(P.shape[2:]), mch, _stream()),
-                   "consistency_bwd")
+        entry = _lib.load().advchain_consistency_fused_bwd if ctx.fused else _lib.load().advchain_consistency_bwd
+        _lib.check(entry(_ptr(P), _ptr(D), _ptr(R), _ptr(mask), _ptr(gs), _ptr(gpred),
+                         float(coef[0]), float(coef[1]), float(coef[2]), float(coef[3]),
+                         is_gt, N, K, nd, _lib.dims_array(P.shape[2:]), mch, _stream()),
+                   "consistency_fused_bwd" if ctx.fused else "consistency_bwd")
         return gpred, None, None, None, None, None
 
 

@@ -310,6 +310,21 @@ int advchain_consistency_bwd(const float* P, const float* D, const float* R, con
                              const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, float c_kl,
                              int kl_is_gt, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
                              void* stream);
+/* f2, fused (round 4): the same loss without its per-voxel intermediates.  fused_fwd: softmax(pred), softmax(ref) (or ref
+ * itself), the masked squared error, the KL sum and the 3^d edge stencils in ONE marching kernel straight from the logits;
+ * it writes only R (2(K-1) channels; may be NULL when no gradient is wanted) and adds to the same 4 x 64 slot sums as
+ * advchain_consistency_fwd (finish with advchain_consistency_finish).  fused_bwd: grad_pred from pred, ref, R -- the softmax is
+ * recomputed at the voxel instead of reading P and D back.  Same per-voxel arithmetic as the unfused entries (replaces the
+ * same reference lines: common/loss.py:8-87,102-220,223-249).  Both return ADVCHAIN_ERR_UNSUPPORTED (-2) for what the 16-byte
+ * marching form does not take -- rows of 4j <= 256 voxels, K = 2..4, a mask of at most one channel, 16-byte aligned
+ * tensors: use the unfused entries then. */
+int advchain_consistency_fused_fwd(const float* pred, const float* ref, const float* mask, float* R, float* sums, int64_t N,
+                                   int64_t K, int ndim, const int64_t* dims, int mask_channels, int ref_is_prob, int want_edges,
+                                   int want_kl, void* stream);
+int advchain_consistency_fused_bwd(const float* pred, const float* ref, const float* R, const float* mask,
+                                   const float* grad_scale, float* grad_pred, float c_mse, float c_a, float c_b, float c_kl,
+                                   int ref_is_prob, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
+                                   void* stream);
 
 #ifdef __cplusplus
 }
