@@ -510,7 +510,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 using namespace advchain;
 
 static int march_zc(const Dims& d, int64_t N, int ty) {
-  static const int forced = getenv("ADVCHAIN_MARCH_ZC") ? atoi(getenv("ADVCHAIN_MARCH_ZC")) : 0;   // tuning knob
+  static const int forced = getenv("ADVCHAIN_MARCH_ZC") ? atoi(getenv("ADVCHAIN_MARCH_ZC")) : 0;   // A/B knob
   if (forced > 0) return forced;
   // enough workgroups to fill 256 CUs four deep, but chunks no shorter than 8 planes (2 of ZC + 2 steps are halo work)
   const int64_t cols = N * ((d.s1 + ty - 1) / ty);
@@ -530,7 +530,7 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
     attr_set = true;
   }
   static const int dbg = (getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0) |
-                         (getenv("ADVCHAIN_NO_XCD_MAP") ? 0 : kMarchXcd);
+                         (kMarchXcd);
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
   const int nseg = (WIDE || d.s2 <= 64) ? 1 : (d.s2 + kSegOwn - 1) / kSegOwn;
   const int zc = march_zc(d, N * nseg, G::TY);
@@ -557,7 +557,7 @@ static bool march_shape_ok(const Dims& d, const void* a, const void* b, const vo
 int advchain_self_adjoint_march_launch(const float* gout, const float* phi, float* gphi, int64_t N, Dims d,
                                        int32_t* workspace, hipStream_t st) {
   if (!march_shape_ok(d, gout, phi, gphi, nullptr, nullptr)) return ADVCHAIN_ERR_UNSUPPORTED;
-  static const int rpw = getenv("ADVCHAIN_MARCH_SELF_RPW") ? atoi(getenv("ADVCHAIN_MARCH_SELF_RPW")) : 2;   // tuning knob
+  static const int rpw = 2;   // measured optimum (was a tuning knob until round 4)
   if (march_wide(d)) launch_march<3, true, false, kMarchBorder, 4, 2, true>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   else if (rpw == 2) launch_march<3, true, false, kMarchBorder, 4, 2>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);
   else if (rpw == 8) launch_march<3, true, false, kMarchBorder, 8, 1>(gout, phi, phi, gphi, nullptr, N, d, workspace, st);

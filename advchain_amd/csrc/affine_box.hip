@@ -584,7 +584,7 @@ static inline bool box_shape_ok(const Dims& d, const void* a, const void* b, con
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
-static const int g_box_tz = getenv("ADVCHAIN_AFFINE_BOX_TZ") ? atoi(getenv("ADVCHAIN_AFFINE_BOX_TZ")) : 8;   // tuning knob: 8 | 4
+static const int g_box_tz = 8;   // measured optimum (was a tuning knob until round 4): 8 | 4
 
 // Returns true when the box kernel took the launch (linear, zeros padding).
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,

@@ -1286,7 +1286,7 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
                                        reinterpret_cast<uintptr_t>(aux)) & 15) == 0;
   dim3 grid(advchain_blocks(v4 ? total / 4 : total, kBlock));
   int riw = (v4 && d.s2 >= 4 && 64 % (d.s2 / 4) == 0 && (total / 4) % 64 == 0) ? 1 : 0;   // x rows aligned to waves
-  static const bool no_riw2 = getenv("ADVCHAIN_NO_GAUSS_RIW2") != nullptr, no_zmarch = getenv("ADVCHAIN_NO_GAUSS_ZMARCH") != nullptr;   // A/B knobs
+  static const bool no_riw2 = false, no_zmarch = getenv("ADVCHAIN_NO_GAUSS_ZMARCH") != nullptr;   // A/B knob
   if (!riw && v4 && axis == 2 && d.s2 >= 8 && d.s2 / 4 <= 64 && !no_riw2) {   // rows that do not divide a wave: whole rows per wave
     riw = 2;
     const int64_t rows = total / d.s2, rpw = 64 / (d.s2 / 4);

@@ -208,16 +208,16 @@ k_sample_tiled(const float* __restrict__ in, const float* __restrict__ grid, flo
 using namespace advchain;
 
 static bool choose_gtile(int ndim, const Dims& d, int C, int halo_hint, GTile& tc) {
-  static const int h3 = getenv("ADVCHAIN_GTILE_H3") ? atoi(getenv("ADVCHAIN_GTILE_H3")) : 1;   // tuning knobs
-  static const int h2 = getenv("ADVCHAIN_GTILE_H2") ? atoi(getenv("ADVCHAIN_GTILE_H2")) : 8;
+  static const int h3 = 1;   // measured optimum (was a tuning knob until round 4)
+  static const int h2 = 8;
   if (d.s2 < 8 || d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return false;   // 24-bit index products
-  static const bool tiles_2d = getenv("ADVCHAIN_GTILE_2D") != nullptr;
+  static const bool tiles_2d = false;
   if (ndim == 2 && !tiles_2d) return false;   // measured: in 2D (4 corners) the direct 4-chain gather kernels are faster
   int h = ndim == 3 ? h3 : h2;
   if (halo_hint > 0) h = halo_hint;
-  static const int t0_3 = getenv("ADVCHAIN_GTILE_T0") ? atoi(getenv("ADVCHAIN_GTILE_T0")) : 2;   // measured: small tiles (more resident workgroups) beat low halo amplification
-  static const int t1_3 = getenv("ADVCHAIN_GTILE_T1") ? atoi(getenv("ADVCHAIN_GTILE_T1")) : 8;
-  static const int t1_2 = getenv("ADVCHAIN_GTILE_T1_2D") ? atoi(getenv("ADVCHAIN_GTILE_T1_2D")) : 16;
+  static const int t0_3 = 2;   // measured: small tiles (more resident workgroups) beat low halo amplification
+  static const int t1_3 = 8;
+  static const int t1_2 = 16;
   if (ndim == 3) { tc.t0 = t0_3; tc.t1 = t1_3; tc.h0 = tc.h1 = h; }
   else { tc.t0 = 1; tc.t1 = t1_2; tc.h0 = 0; tc.h1 = h; }
   if (d.s2 <= 96) { tc.t2 = d.s2; tc.h2 = 0; }     // whole rows: no x halo
@@ -270,10 +270,10 @@ int advchain_sample_ring_launch(const float* in, const float* grid, float* out, 
 // below a voxel, 116 against 465 at 4 voxels).  `hint` = the caller's displacement estimate in voxels, rounded up
 // (0 = unknown): a performance hint, results do not depend on it.
 static bool march_forward_pays(bool self, int64_t C, const Dims& d, int hint) {
-  static const bool always = getenv("ADVCHAIN_FWD_MARCH_ALWAYS") != nullptr;   // A/B knob: the round-2 policy before the hint
+  static const bool always = false;   // measured optimum (was a tuning knob until round 4): the round-2 policy before the hint
   if (always) return true;
   static const bool no_flat = getenv("ADVCHAIN_NO_FLAT_FWD") != nullptr;   // A/B knob
-  static const int flat_hint_max = getenv("ADVCHAIN_FLAT_FWD_HINT_MAX") ? atoi(getenv("ADVCHAIN_FLAT_FWD_HINT_MAX")) : 1;   // tuning knob
+  static const int flat_hint_max = 1;   // measured optimum (was a tuning knob until round 4)
   if (d.s2 > 64 && d.s2 <= 128 && !no_flat) return hint <= flat_hint_max;   // lane <-> flat voxel (k_sample_march_flat): no idle lanes
   if (d.s2 > 64) return !self && C == 4 && hint <= 1;
   return hint <= 1;

@@ -1038,7 +1038,7 @@ static inline bool march4_ok(const Dims& d, const void* a, const void* b, const 
 // rows marched per strip: as long as possible (each strip re-reads 2 halo rows) while the launch still has ~1024 waves
 // (measured: 8 rows beat 4 at 2048 waves, 3D 84 vs 92 us; 2D 1024 waves: 8 and 4 rows equal)
 static inline int march4_len(const Dims& d, int64_t N) {
-  static const int forced = getenv("ADVCHAIN_MARCH4_LEN") ? atoi(getenv("ADVCHAIN_MARCH4_LEN")) : 0;   // tuning knob
+  static const int forced = 0;   // measured optimum (was a tuning knob until round 4)
   if (forced > 0) return forced;
   const int groups_per_wave = 64 / (d.s2 / 4);
   for (int m = kMarch; m > 2; m /= 2)

@@ -493,267 +493,16 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
   if (SELF && disp_out) wave_max_to_slots(dmax, disp_out);
 }
 
-// ---------------------------------------------------------------------------------------------
-// f1 experiment: TWO squarings per launch.  phi -> phi' = phi o phi is computed on
-// the owned rows plus one halo row either side and kept in a second LDS ring; phi'' = phi' o phi' of the owned rows is
-// taken from that ring.  phi' is still written (the backward wants every field); what the fusion saves is the second
-// launch and its re-read of phi' (1.56x the field with the halos of its own tiles).  What it costs: (TY+2)/TY x
-// (ZC+2)/ZC more level-1 taps, two barriers per plane, and 71 KiB of LDS (two workgroups a CU instead of four).
-// Selected by ADVCHAIN_FUSE2=1 for the squarings whose displacement hint is small; measured in profiles/r03/f1_*.
-// Rows of at most 64 voxels, border padding (the self-composition), no final mode.
-// ---------------------------------------------------------------------------------------------
-template <int NW_, int RPW_>
-struct Fuse2Cfg {
-  static constexpr int NW = NW_, RPW = RPW_, TY = NW * RPW, RA = TY + 4, RB = TY + 2, NT = NW * 64, P = 72;
-  static constexpr int PSA = 3 * RA * P, PSB = 3 * RB * P, TRW = 2 * RPW * 64;
-  // three slots per ring: the plane three steps ahead waits in registers and is committed behind the barrier that ends the
-  // level-1 phase, into the slot of the plane level 1 has just finished with
-  static constexpr size_t LDS = (size_t)(3 * PSA + 3 * PSB + NW * TRW) * sizeof(float);
-  static_assert(RA * 16 <= NT, "one staging item per thread");
-};
-
-// phi' at the voxel (ix, iy, iz) of the volume, straight from global memory (the slow path of a level-2 corner that is not
-// in the ring): the arithmetic of the level-1 tap
-__device__ __forceinline__ void fuse2_phi1_global(const float* __restrict__ phin, int V, const Dims& d, int ix, int iy, int iz,
-                                                  float (&v)[3]) {
-  const int s = (iz * d.s1 + iy) * d.s2 + ix;
-  Taps<3, PAD_BORDER> t;
-  t.build(phin[s], phin[(size_t)V + s], phin[(size_t)2 * V + s], d);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) v[c] = sample_linear<3, PAD_BORDER, false>(phin + (size_t)c * V, t, d);
-}
-
-template <int NW_, int RPW_>
-__global__ void __launch_bounds__(NW_ * 64)
-k_compose2_march(const float* __restrict__ in, float* __restrict__ mid, float* __restrict__ out, Dims d, int n1, int zc,
-                 float* __restrict__ disp_mid, float* __restrict__ disp_out) {
-  using G = Fuse2Cfg<NW_, RPW_>;
-  constexpr int P = G::P, RA = G::RA, RB = G::RB, PSA = G::PSA, PSB = G::PSB, TY = G::TY, RPW = G::RPW, NW = G::NW;
-  extern __shared__ float lds[];
-  float* const ringA = lds;                      // [slot 3][3][RA][P]   phi, rows y0-2 .. y0+TY+1
-  float* const ringB = lds + 3 * PSA;            // [slot 3][3][RB][P]   phi', rows y0-1 .. y0+TY
-  float* const trbuf = ringB + 3 * PSB;
-  const int V = (int)d.voxels();
-  const int n = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ty = blockIdx.x % n1, tz = blockIdx.x / n1;
-  const int y0 = ty * TY;
-  const int za = tz * zc, zb = min(za + zc, d.s0);
-  const float* inn = in + (int64_t)n * 3 * V;
-  float* midn = mid + (int64_t)n * 3 * V;
-  float* outn = out + (int64_t)n * 3 * V;
-  const int plane_stride = d.s1 * d.s2;
-  const bool xowned = lane < d.s2;
-  const float topx = (float)(d.s2 - 1), topy = (float)(d.s1 - 1), topz = (float)(d.s0 - 1);
-
-  // zero columns of every staged row of both rings (never written again)
-  for (int e = threadIdx.x; e < (3 * 3 * RA + 3 * 3 * RB) * 2; e += G::NT) {
-    const int row = e >> 1, side = e & 1;
-    *reinterpret_cast<float4*>(lds + row * P + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // staging item of this thread: 4 consecutive x of ring-A row r_st, 3 channels
-  const bool has_item = threadIdx.x < RA * 16;
-  const int r_st = threadIdx.x >> 4, q_st = threadIdx.x & 15;
-  const int sy_st = y0 - 2 + r_st, x_st = 4 * q_st;
-  const bool row_ok = has_item && sy_st >= 0 && sy_st < d.s1 && x_st < d.s2;
-  const int row_off = min(max(sy_st, 0), d.s1 - 1) * d.s2 + (x_st < d.s2 ? x_st : 0);
-  const int lds_item = r_st * P + 4 + 4 * q_st;
-  auto fetch = [&](int p, float (*v)[4]) {
-    const uint32_t s = (uint32_t)(min(max(p, 0), d.s0 - 1) * plane_stride + row_off);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(inn + (size_t)c * V + s);
-      v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
-    }
-  };
-  auto commit = [&](int p, float (*v)[4]) {
-    const bool ok = row_ok && p >= 0 && p < d.s0;
-    float* slot = ringA + (((p % 3) + 3) % 3) * PSA + lds_item;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      *reinterpret_cast<float4*>(slot + c * RA * P) = make_float4(ok ? v[c][0] : 0.f, ok ? v[c][1] : 0.f, ok ? v[c][2] : 0.f,
-                                                                  ok ? v[c][3] : 0.f);
-  };
-  // one trilinear tap of a 3-channel field held in a ring: own value (gx, gy, gz) -> res; `staged` lanes read LDS
-  auto tap_coords = [&](float gx, float gy, float gz, float& xs, float& ys, float& zs) {
-    xs = ((gx + 1.f) * 0.5f) * topx; ys = ((gy + 1.f) * 0.5f) * topy; zs = ((gz + 1.f) * 0.5f) * topz;
-    xs = fminf(fmaxf(xs, 0.f), topx); ys = fminf(fmaxf(ys, 0.f), topy); zs = fminf(fmaxf(zs, 0.f), topz);
-    xs = __builtin_amdgcn_fmed3f(xs, -16.f, 1.0e9f);
-    ys = __builtin_amdgcn_fmed3f(ys, -16.f, 1.0e9f);
-    zs = __builtin_amdgcn_fmed3f(zs, -16.f, 1.0e9f);
-  };
-  float dmax1 = 0.f, dmax2 = 0.f;
-
-  // ---- level 1: phi'(plane p) on the ring-B rows, from ring-A planes p-1 .. p+1
-  auto level1 = [&](int p) {
-    float* const bslot = ringB + (((p % 3) + 3) % 3) * PSB;
-    for (int rb = wave; rb < RB; rb += NW) {                 // wave-uniform
-      const int uy = y0 - 1 + rb;
-      const int ra = rb + 1;                                 // the same row in ring A
-      float res[3] = {0.f, 0.f, 0.f};
-      if (uy >= 0 && uy < d.s1 && p >= 0 && p < d.s0) {
-        const float* c0 = ringA + (((p % 3) + 3) % 3) * PSA + ra * P + 4 + lane;
-        const float gx = c0[0], gy = c0[RA * P], gz = c0[2 * RA * P];
-        float xs, ys, zs;
-        tap_coords(gx, gy, gz, xs, ys, zs);
-        const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
-        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-        const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs, wy1 = ys - fy, wy0 = (fy + 1.f) - ys, wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
-        const bool staged = (unsigned)(iz - p + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)d.s2;
-        if (staged) {
-          float w[8];
-          w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
-          w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
-          const int oxy = (ra + (iy - uy)) * P + 4 + ix;
-          const float* q0 = ringA + (((iz % 3) + 3) % 3) * PSA + oxy;
-          const float* q1 = ringA + ((((iz + 1) % 3) + 3) % 3) * PSA + oxy;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            float a = 0.f;
-#pragma unroll
-            for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-              for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                for (int cx = 0; cx < 2; ++cx) a = tap_acc<3>(a, ((cz ? q1 : q0) + (c * RA + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
-            res[c] = a;
-          }
-        } else if (xowned) {
-          Taps<3, PAD_BORDER> t;
-          t.build(gx, gy, gz, d);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) res[c] = sample_linear<3, PAD_BORDER, false>(inn + (size_t)c * V, t, d);
-        }
-        if (!xowned) { res[0] = res[1] = res[2] = 0.f; }
-        // the owned rows of the chunk's own planes are the field phi' the backward will ask for
-        if (rb >= 1 && rb <= TY && p >= za && p < zb && xowned) {
-          const uint32_t s = (uint32_t)((p * d.s1 + uy) * d.s2 + lane);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            midn[(size_t)c * V + s] = res[c];
-            if (disp_mid) dmax1 = fmaxf(dmax1, voxel_displacement(res[c], c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0), c == 0 ? lane : (c == 1 ? uy : p)));
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) bslot[(c * RB + rb) * P + 4 + lane] = res[c];
-    }
-  };
-
-  // ---- prologue: level 1 of planes za-1 and za, one staged plane at a time behind it
-  float pr[3][4];
-  if (has_item) {
-    float pa[3][4], pb[3][4];
-    fetch(za - 2, pa); fetch(za - 1, pb); fetch(za, pr);
-    commit(za - 2, pa); commit(za - 1, pb); commit(za, pr);
-    fetch(za + 1, pr);
-  }
-  __syncthreads();
-  level1(za - 1);
-  __syncthreads();
-  if (has_item) { commit(za + 1, pr); fetch(za + 2, pr); }      // (slot of plane za-2)
-  __syncthreads();
-  level1(za);
-  __syncthreads();
-  if (has_item) commit(za + 2, pr);                              // (slot of plane za-1)
-  __syncthreads();
-
-  float* const tr = trbuf + wave * G::TRW;
-  const int own_row0 = wave * RPW;
-  for (int z = za; z < zb; ++z) {
-    if (has_item) fetch(z + 3, pr);
-    level1(z + 1);
-    __syncthreads();
-    // ---- level 2: phi''(plane z) of the owned rows from ring-B planes z-1 .. z+1
-    float res[3][RPW];
-#pragma unroll
-    for (int o = 0; o < RPW; ++o) {
-      const int rb = own_row0 + o + 1;
-      const int uy = y0 - 1 + rb;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) res[c][o] = 0.f;
-      if (uy >= d.s1) continue;
-      const float* c0 = ringB + (z % 3) * PSB + rb * P + 4 + lane;
-      const float gx = c0[0], gy = c0[RB * P], gz = c0[2 * RB * P];
-      float xs, ys, zs;
-      tap_coords(gx, gy, gz, xs, ys, zs);
-      const float fx = floorf(xs), fy = floorf(ys), fz = floorf(zs);
-      const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-      const float wx1 = xs - fx, wx0 = (fx + 1.f) - xs, wy1 = ys - fy, wy0 = (fy + 1.f) - ys, wz1 = zs - fz, wz0 = (fz + 1.f) - zs;
-      float w[8];
-      w[0] = (wx0 * wy0) * wz0; w[1] = (wx1 * wy0) * wz0; w[2] = (wx0 * wy1) * wz0; w[3] = (wx1 * wy1) * wz0;
-      w[4] = (wx0 * wy0) * wz1; w[5] = (wx1 * wy0) * wz1; w[6] = (wx0 * wy1) * wz1; w[7] = (wx1 * wy1) * wz1;
-      const bool staged = (unsigned)(iz - z + 1) <= 1u && (unsigned)(iy - uy + 1) <= 1u && (unsigned)(ix + 1) <= (unsigned)d.s2;
-      if (staged) {
-        const int oxy = (rb + (iy - uy)) * P + 4 + ix;
-        const float* q0 = ringB + (((iz % 3) + 3) % 3) * PSB + oxy;
-        const float* q1 = ringB + ((((iz + 1) % 3) + 3) % 3) * PSB + oxy;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float a = 0.f;
-#pragma unroll
-          for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-            for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-              for (int cx = 0; cx < 2; ++cx) a = tap_acc<3>(a, ((cz ? q1 : q0) + (c * RB + cy) * P)[cx], w[(cz * 2 + cy) * 2 + cx]);
-          res[c][o] = a;
-        }
-      } else if (xowned) {
-        // a displacement of a voxel or more: the corners of phi' are rebuilt from phi in global memory (border padding:
-        // a corner index beyond the volume carries weight 0 and is clamped)
-        float a[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int k = 0; k < 8; ++k) {
-          const int cx = k & 1, cy = (k >> 1) & 1, cz = k >> 2;
-          float v[3];
-          fuse2_phi1_global(inn, V, d, min(ix + cx, d.s2 - 1), min(iy + cy, d.s1 - 1), min(iz + cz, d.s0 - 1), v);
-          const float wk = ((cx ? wx1 : wx0) * (cy ? wy1 : wy0)) * (cz ? wz1 : wz0);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) a[c] = tap_acc<3>(a[c], v[c], wk);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) res[c][o] = a[c];
-      }
-      if (disp_out && xowned) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          dmax2 = fmaxf(dmax2, voxel_displacement(res[c][o], c == 0 ? d.s2 : (c == 1 ? d.s1 : d.s0), c == 0 ? lane : (c == 1 ? uy : z)));
-      }
-    }
-    // results leave 4 voxels per lane through the wave's LDS scratch (2 channels, then 1)
-#pragma unroll
-    for (int c0 = 0; c0 < 3; c0 += 2) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int o = 0; o < RPW; ++o)
-          if (c0 + a < 3) tr[(a * RPW + o) * 64 + lane] = res[c0 + a][o];
-      lds_order();
-      constexpr int ITEMS = 2 * RPW * 16;
-      {
-        const int j = lane;
-        const int a = j / (RPW * 16), o = (j / 16) % RPW, q = j & 15;
-        const float4 v4 = *reinterpret_cast<const float4*>(tr + (a * RPW + o) * 64 + 4 * q);
-        const bool valid = j < ITEMS && c0 + a < 3 && 4 * q < d.s2 && (y0 + own_row0 + o) < d.s1;
-        if (valid)
-          *reinterpret_cast<float4*>(outn + (size_t)(c0 + a) * V + (uint32_t)((z * d.s1 + y0 + own_row0 + o) * d.s2 + 4 * q)) = v4;
-      }
-      lds_order();
-    }
-    if (has_item && z + 3 <= zb + 1) commit(z + 3, pr);
-    __syncthreads();
-  }
-  if (disp_mid) wave_max_to_slots(dmax1, disp_mid);
-  if (disp_out) wave_max_to_slots(dmax2, disp_out);
-}
+// (Round 3 kept an experiment here -- two 3D squarings per launch through a second LDS ring, k_compose2_march behind
+// ADVCHAIN_FUSE2: 3-17 % slower than one launch per squaring because the second ring halved the resident workgroups of a
+// kernel that is 47 % parked.  Measurements and counters: profiles/r03/f1/; the code was removed in round 4.)
 
 }  // namespace advchain
 
 using namespace advchain;
 
 static int fwd_march_zc(const Dims& d, int64_t N, int ty, int C) {
-  static const int forced = getenv("ADVCHAIN_FWD_MARCH_ZC") ? atoi(getenv("ADVCHAIN_FWD_MARCH_ZC")) : 0;   // tuning knob
+  static const int forced = getenv("ADVCHAIN_FWD_MARCH_ZC") ? atoi(getenv("ADVCHAIN_FWD_MARCH_ZC")) : 0;   // A/B knob
   if (forced > 0) return forced;
   // measured at 4 x C x 128 x 128 x 64: the one-channel warp is latency-bound and wants 8 workgroups per CU even at
   // chunks of 4 planes (15.4 us against 17.7 at 8 and 25 at 16 planes); 3-4 channels want 4 per CU and chunks >= 8
@@ -779,7 +528,7 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
   const int nseg = d.s2 <= 64 ? 1 : (d.s2 + kFwdSegOwn - 1) / kFwdSegOwn;
   const int zc = fwd_march_zc(d, N * nseg, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
-  static const bool no_xcd = getenv("ADVCHAIN_NO_XCD_MAP") != nullptr;   // A/B knob
+  static const bool no_xcd = false;   // measured optimum (was a tuning knob until round 4)
   hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
                      final_mode, disp_out, no_xcd ? -nseg : nseg);
 }
@@ -805,7 +554,7 @@ static void launch_fwd_flat(const float* in, const float* grid, float* out, cons
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
   const int zc = fwd_march_zc(d, N, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
-  static const bool no_xcd = getenv("ADVCHAIN_NO_XCD_MAP") != nullptr;   // A/B knob
+  static const bool no_xcd = false;   // measured optimum (was a tuning knob until round 4)
   static const int dbg = getenv("ADVCHAIN_FWD_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_FWD_MARCH_DEBUG")) : 0;   // timing experiments
   hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(nw * 64), G::lds_bytes(nw), st, in, grid, out, phi0, d, n1,
                      zc, final_mode, disp_out, (no_xcd ? 0 : 1) | (dbg << 4));
@@ -849,39 +598,6 @@ int advchain_sample_march_launch(bool self, const float* in, const float* grid, 
     else if (C == 4) (flat && d.s2 <= kFlatPW) ? launch_fwd_flat_mode<4>(mode, in, grid, out, N, d, st) : launch_fwd_march_mode<4>(mode, in, grid, out, N, d, st);
     else return ADVCHAIN_ERR_UNSUPPORTED;
   }
-  ADVCHAIN_LAUNCH_CHECK();
-  return ADVCHAIN_OK;
-}
-
-// Two squarings in one launch (f1 experiment): in -> mid = in o in -> out = mid o mid.  ADVCHAIN_ERR_UNSUPPORTED: run two
-// launches.
-template <int NW, int RPW>
-static void launch_compose2(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
-                            hipStream_t st) {
-  using G = Fuse2Cfg<NW, RPW>;
-  auto kern = k_compose2_march<NW, RPW>;
-  static bool attr_set = false;
-  if (G::LDS > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    attr_set = true;
-  }
-  const int n1 = (d.s1 + G::TY - 1) / G::TY;
-  static const int forced = getenv("ADVCHAIN_FUSE2_ZC") ? atoi(getenv("ADVCHAIN_FUSE2_ZC")) : 0;
-  int zc = forced > 0 ? forced : d.s0;
-  if (forced <= 0) while (zc > 16 && N * n1 * ((d.s0 + zc - 1) / zc) < 1024) zc = (zc + 1) / 2;
-  const int n0 = (d.s0 + zc - 1) / zc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, mid, out, d, n1, zc, disp_mid,
-                     disp_out);
-}
-
-int advchain_compose2_march_launch(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
-                                   hipStream_t st) {
-  const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mid);
-  if (d.s2 < 8 || d.s2 > 64 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 4 || d.voxels() * 4 >= (1ll << 31))
-    return ADVCHAIN_ERR_UNSUPPORTED;
-  static const int shape = getenv("ADVCHAIN_FUSE2_SHAPE") ? atoi(getenv("ADVCHAIN_FUSE2_SHAPE")) : 81;   // 81 = 8 waves x 1 row | 42
-  if (shape == 42) launch_compose2<4, 2>(in, mid, out, N, d, disp_mid, disp_out, st);
-  else launch_compose2<8, 1>(in, mid, out, N, d, disp_mid, disp_out, st);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

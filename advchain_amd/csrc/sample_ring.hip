@@ -163,7 +163,7 @@ using namespace advchain;
 int advchain_sample_ring_launch(const float* in, const float* grid, float* out, int64_t N, Dims d, int padding, int clamp_grid,
                                 int hint, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_RING_FWD") != nullptr;   // A/B knob
-  static const int h_forced = getenv("ADVCHAIN_RING_FWD_H") ? atoi(getenv("ADVCHAIN_RING_FWD_H")) : 0;   // tuning knob
+  static const int h_forced = 0;   // measured optimum (was a tuning knob until round 4)
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(grid);
   if (d.s2 < 8 || d.s2 > 64 || (d.s2 & 3) != 0 || (al & 15) != 0 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31))
@@ -171,7 +171,7 @@ int advchain_sample_ring_launch(const float* in, const float* grid, float* out, 
   int H = h_forced > 0 ? h_forced : hint;
   if (H < 2 || H > 4) return ADVCHAIN_ERR_UNSUPPORTED;
   const int n1 = (int)((d.s1 + 7) / 8);
-  static const int zc_forced = getenv("ADVCHAIN_RING_FWD_ZC") ? atoi(getenv("ADVCHAIN_RING_FWD_ZC")) : 0;
+  static const int zc_forced = 0;
   int zc = (int)d.s0;
   while (zc > 16 && N * n1 * ((d.s0 + zc - 1) / zc) < 1024) zc = (zc + 1) / 2;
   if (zc_forced > 0) zc = zc_forced;

@@ -749,14 +749,11 @@ int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const 
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
                                     int64_t N, int64_t C, int ndim, Dims d, hipStream_t st);
 
-// sample_march.hip: two squarings per launch (f1 experiment, ADVCHAIN_FUSE2)
+// expo_fused2d.hip / adjoint_fused2d.hip: the sub-pixel squarings of a 2D chain in one launch (forward / backward)
 int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, float* disp_rows,
                                      float* fail_flag, hipStream_t stream);
 int advchain_adjoint_fused2d_launch(const float* gk, const float* phi0, const float* fields, float* g0, int64_t N, advchain::Dims d,
                                     int k, int32_t* workspace, hipStream_t st);
-int advchain_compose2_march_launch(const float* in, float* mid, float* out, int64_t N, Dims d, float* disp_mid, float* disp_out,
-                                   hipStream_t st);
-
 // gather_tiled.hip
 int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, float* out, const float* phi0,
                                  int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid, int final_mode,
@@ -765,12 +762,12 @@ int advchain_sample_tiled_launch(bool self, const float* in, const float* grid, 
 // ---------------------------------------------------------------------------------------------
 // dispatch helpers
 // ---------------------------------------------------------------------------------------------
-// UNR = 4 independent voxels per thread once the volume fills the chip; ADVCHAIN_UNR1 forces 1 (A/B tests)
+// UNR = 4 independent voxels per thread once the volume fills the chip
 // Measured on MI355X (tools/kernel_bench.py): 2D gathers gain 1.2x from 4 chains per thread; in 3D the 4 chains
 // sit 4 rows apart in 2 z-planes x C channels and thrash the 32 KiB L1, so one voxel per thread wins (1.3x).
 static inline bool use_unroll(int64_t voxels, int ndim) {
-  static const bool force1 = getenv("ADVCHAIN_UNR1") != nullptr;
-  static const bool force4 = getenv("ADVCHAIN_UNR4") != nullptr;
+  static const bool force1 = false;
+  static const bool force4 = false;
   if (force4) return true;
   return !force1 && ndim == 2 && voxels >= 4 * kBlock;
 }
@@ -944,8 +941,8 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   const bool vec4 = use_unroll(V, ndim);
   hipStream_t st = (hipStream_t)stream;
   // 2D: two voxels per thread (twice the waves of the 4-voxel form at fewer registers: 12.0 against 13.4 us per cfg-2
-  // squaring once the gathers are issued together); ADVCHAIN_UNR4 / ADVCHAIN_UNR1 force the other forms
-  static const bool unr2 = getenv("ADVCHAIN_UNR4") == nullptr && getenv("ADVCHAIN_UNR1") == nullptr;
+  // squaring once the gathers are issued together)
+  static const bool unr2 = true && true;
   if (unr2 && vec4 && ndim == 2) {
     dim3 g2(advchain_blocks(V, kBlock * 2), (unsigned)N);
     hipLaunchKernelGGL((k_compose_self_fwd<2, 2>), g2, dim3(kBlock), 0, st, phi, out, phi0, d, final_mode, disp_out);
@@ -1020,7 +1017,7 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   ADVCHAIN_CHECK_ARG(d.voxels() < (1ll << 31), "affine_warp_fwd: per-sample volume too large");
   dim3 g(affine_grid_blocks(d), (unsigned)N), b(kBlock);
   hipStream_t st = (hipStream_t)stream;
-  static const float thr = getenv("ADVCHAIN_PATCH_THR") ? (float)atof(getenv("ADVCHAIN_PATCH_THR")) : 7.f;   // tuning knob (break-even measured at ~6 degrees)
+  static const float thr = 7.f;   // measured optimum (was a tuning knob until round 4) (break-even measured at ~6 degrees)
   static const bool no_v = getenv("ADVCHAIN_NO_AFFINE_V") != nullptr;   // A/B knob
   if (interp == INTERP_LINEAR && padding == PAD_ZEROS && advchain_affine_box_fwd_launch(in, theta, out, N, C, ndim, d, st)) {
     ADVCHAIN_LAUNCH_CHECK();
@@ -1061,9 +1058,6 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "expo_chain_fwd: bad dims");
   const int64_t F = N * ndim * make_dims(ndim, dims).voxels();
   const float* src = phi0;
-  // f1 experiment: ADVCHAIN_FUSE2=1 fuses pairs of squarings whose hints say "below one voxel" (phi_m and phi_m+1), =2 the
-  // first three pairs whatever the hints say (results do not depend on it: lanes beyond the ring fall back)
-  static const int fuse2 = getenv("ADVCHAIN_FUSE2") ? atoi(getenv("ADVCHAIN_FUSE2")) : 0;
   // 2D: the leading squarings whose inputs the hints put below one pixel run as ONE launch (expo_fused2d.hip: whole-row LDS
   // windows, bit-identical fields).  The kernel verifies the premise itself and raises *fuse_flag when a window moves too
   // far for some of its levels; the ordinary launches of those squarings follow it, gated on that flag.
@@ -1098,17 +1092,6 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   }
   if (fused) src = fields + (int64_t)(fused - 1) * F;
   for (int m = fused; m + 1 < n; ++m) {
-    if (fuse2 && ndim == 3 && m + 2 < n &&
-        (fuse2 >= 2 ? m < 6 : (hints && (hints[m] & 0xff) == 1 && (hints[m + 1] & 0xff) == 1))) {
-      float* mid = fields + (int64_t)m * F;
-      float* dst2 = fields + (int64_t)(m + 1) * F;
-      const int rc2 = advchain_compose2_march_launch(src, mid, dst2, N, make_dims(ndim, dims),
-                                                     disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr,
-                                                     disp_rows ? disp_rows + (int64_t)(m + 2) * kDispSlots : nullptr,
-                                                     (hipStream_t)stream);
-      if (rc2 == ADVCHAIN_OK) { src = dst2; ++m; continue; }
-      if (rc2 != ADVCHAIN_ERR_UNSUPPORTED) return rc2;
-    }
     float* dst = fields + (int64_t)m * F;
     const int rc = advchain_compose_self_fwd(src, dst, nullptr, N, ndim, dims, hints ? (hints[m] & 0xff) << 8 : 0,
                                              disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, stream);

@@ -1181,15 +1181,15 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                    hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_ROWS2D") != nullptr;   // A/B knob
-  static const int hmin = getenv("ADVCHAIN_SCATTER_ROWS2D_HMIN") ? atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_HMIN")) : 3;   // tuning knob
+  static const int hmin = 3;   // measured optimum (was a tuning knob until round 4)
   if (off || !workspace || !gin || padding == PAD_REFLECTION || H < hmin || H > 16 || d.s0 != 1) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 < 16 || d.s2 > 512 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (self ? C != 2 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
-  static const int ty_forced = getenv("ADVCHAIN_SCATTER_ROWS2D_TY") ? atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_TY")) : 0;
+  static const int ty_forced = 0;
   const int nseg = (d.s2 + 63) / 64;
   int TY = H >= 8 ? 32 : 16;
   if (ty_forced > 0) TY = ty_forced;
-  static const size_t lds_cap = getenv("ADVCHAIN_SCATTER_ROWS2D_LDS") ? (size_t)atoi(getenv("ADVCHAIN_SCATTER_ROWS2D_LDS")) : 49152;   // tuning knob
+  static const size_t lds_cap = 49152;   // measured optimum (was a tuning knob until round 4)
   while (TY > 4 && ((size_t)C * TY * d.s2 * 4 > lds_cap || TY * nseg > 64)) TY >>= 1;   // 48 KiB of cells, 8 own items a wave
   const size_t lds = (size_t)C * TY * d.s2 * sizeof(int);
   if (lds > 65536 - 64 || TY * nseg > 64) return ADVCHAIN_ERR_UNSUPPORTED;
@@ -1219,7 +1219,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                   hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_MARCH") != nullptr;   // A/B knob
-  static const int hmax = getenv("ADVCHAIN_SCATTER_MARCH_HMAX") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_HMAX")) : 8;   // tuning knob
+  static const int hmax = 8;   // measured optimum (was a tuning knob until round 4)
   if (off || !workspace || !gin || padding == PAD_REFLECTION || H < 2 || H > hmax || H > 8) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 > 1024 || d.s2 < 8 || d.s0 < 2 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
   const int nseg = d.s2 <= 64 ? 1 : (int)((d.s2 + (64 - 2 * H) - 1) / (64 - 2 * H));
@@ -1312,7 +1312,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     return ADVCHAIN_OK;
   }
   // rows per workgroup: as many as 60 KiB of accumulator planes allow, at most 8
-  static const int ty_forced = getenv("ADVCHAIN_SCATTER_MARCH_TY") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_TY")) : 0;
+  static const int ty_forced = 0;
   int NS = 2 * H + 3;
   int TY = 8;    // (16 halves the y halo work but leaves 512 workgroups at 4 x 128 x 128 x 64)
   if ((size_t)NS * C * TY * 64 * 4 > 65536) NS = 2 * H + 2;

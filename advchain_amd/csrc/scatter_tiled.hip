@@ -308,8 +308,8 @@ using namespace advchain;
 // ~16 after a few un-normalised ascent steps; anything larger goes through the overflow list.  lane <-> x: a row of the region (owned x-range + halo) is one wave.
 static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   TileCfg tc;
-  static const int h3d = getenv("ADVCHAIN_TILE_H3") ? atoi(getenv("ADVCHAIN_TILE_H3")) : 2;   // tuning knobs
-  static const int h2d = getenv("ADVCHAIN_TILE_H2") ? atoi(getenv("ADVCHAIN_TILE_H2")) : 16;  // measured: 16 beats 8/12 at cfg-2
+  static const int h3d = 2;   // measured optimum (was a tuning knob until round 4)
+  static const int h2d = 16;  // measured: 16 beats 8/12 at cfg-2
   if (ndim == 3) {
     tc.h0 = tc.h1 = tc.h2 = h3d;
     tc.t1 = 8;
@@ -332,7 +332,7 @@ static TileCfg choose_tiles(int ndim, const Dims& d, int C, int halo_hint) {
   }
   if (tc.t1 > d.s1) tc.t1 = d.s1;
   if (tc.t0 > d.s0) tc.t0 = d.s0;
-  static const int lds_cap = getenv("ADVCHAIN_TILE_LDS") ? atoi(getenv("ADVCHAIN_TILE_LDS")) : 65536;  // tuning knob
+  static const int lds_cap = 65536;  // measured optimum (was a tuning knob until round 4)
   while ((int64_t)C * tc.t0 * tc.t1 * tc.t2 * 8 > lds_cap) {   // int64 accumulators in dynamic LDS
     if (tc.t0 > 1) tc.t0 = (tc.t0 + 1) / 2;
     else tc.t1 = (tc.t1 + 1) / 2;

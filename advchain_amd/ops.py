@@ -312,7 +312,9 @@ def _halo_3d(disp):
     """3D above one voxel: exact bounds of 2..4 voxels (owner-computes march scatter); beyond: a hint for the window
     scatter.  (The C ABI also takes exact bounds of 5..8 voxels -- one march launch per channel -- but on the smooth
     fields of the solver the window scatter is faster there: cfg-5 121.6 against 131.7 ms per call, cfg-4 61.4 against
-    63.1; on rougher fields it is the other way round, tools/kernel_bench.py: C=4 681 against 2153 us.)"""
+    63.1; on rougher fields it is the other way round, tools/kernel_bench.py: C=4 681 against 2153 us.  Re-measured in round 4
+    with the flat march scatter of round 3 in place, same box, bounds 6 / 8 handed to the march: cfg-5 99.0 against 89.2 ms
+    per call -- still a loss.)"""
     for h in (2, 3, 4):
         if disp < h - 0.001:
             return -h
