@@ -20,10 +20,10 @@
 //     currently holds (measured while staging phi_0, then on every level's results) and runs the next level only if it is
 //     below 0.999 pixel -- every corner of that level then lies in the rows the previous level produced.  A workgroup that
 //     has to stop after j < k levels records the deficit k - j in `fail_flag` (a float, atomic max over the workgroups; 0 =
-//     every workgroup did all k levels).  The chain enqueues the ordinary launch of each of the k squarings behind this
-//     kernel, gated on the flag (k_compose_self_fwd_gated, sampler.hip): launch m returns at once unless deficit > k - m,
-//     so when a field grew past what the hints promised only the squarings some window could not do are repeated -- on
-//     every pixel, which rewrites identical bits where the fused kernel did get that far.
+//     every workgroup did all k levels).  The chain enqueues ONE repeat launch behind this kernel (k_expo_repeat2d,
+//     sampler.hip): it returns at once while the flag is down; otherwise it runs the levels some window could not do the
+//     ordinary way on every pixel (a persistent grid with a grid barrier between levels), which rewrites identical bits
+//     where the fused kernel did get that far.
 #include "sampler_common.h"
 
 namespace advchain {
@@ -194,6 +194,9 @@ int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N
   const int64_t F = N * 2 * d.voxels();
   const size_t lds = (size_t)(TH + 2 * k) * W * sizeof(float2);
   dim3 grid((unsigned)((d.s1 + TH - 1) / TH), (unsigned)N);
+  // a workgroup walks its k levels one after the other: with fewer workgroups than CUs (cfg-1: 8 fields x 12 windows) the k
+  // small launches finish sooner than one long one
+  if ((int64_t)grid.x * grid.y < 256) return ADVCHAIN_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((k_expo_fused_fwd2d<NT, PPW>), grid, dim3(NT), lds, stream, phi0, fields, F, d, k, TH, disp_rows, fail_flag);
   return ADVCHAIN_OK;
 }

@@ -261,18 +261,40 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
                                   (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x);
 }
 
-// The same squaring as a REPEAT behind the fused kernel of expo_fused2d.hip.  That kernel has normally produced `out`
-// already; *gate holds the largest number of trailing levels any of its workgroups could NOT do (0 = none), and this
-// launch -- level `level` of `k` -- returns at once unless gate > k - level.  A small grid-stride grid (nbx workgroups' worth
-// of work on gridDim.x workgroups): returning is then a sub-microsecond tail on the stream, and a repeat that does run is
-// the ordinary arithmetic (compose_self_fwd_body: the same bits, also where the fused kernel had got that far).
-template <int DIM, int VEC>
+// The REPEAT behind the fused kernel of expo_fused2d.hip.  That kernel has normally produced phi_1..phi_k already; *flag holds
+// the largest number of trailing levels any of its workgroups could NOT do (0 = none: this launch returns at once -- ONE
+// launch whatever k, because the host side of a small problem (cfg-1) pays for every launch it enqueues).  Otherwise the
+// missing levels k - deficit + 1 .. k are run here the ordinary way (compose_self_fwd_body<2, 2>: the same bits, also where
+// the fused kernel had got that far) on a small persistent grid, with a grid-wide barrier between two levels: every
+// workgroup of the grid is resident (the host asks for two per CU, eight fit), an arrival counter in device memory, and
+// agent-scope fences either side so that what another XCD's L2 still holds is written back / read again.
+// `barrier`: one zero-initialised 32-bit counter per call (the word behind the flag).
 __global__ void __launch_bounds__(kBlock)
-k_compose_self_fwd_gated(const float* __restrict__ phi, float* __restrict__ out, Dims d, float* __restrict__ disp_out,
-                         const float* __restrict__ gate, float need, int nbx) {
-  if (!(*gate > need)) return;
-  for (int b = blockIdx.x; b < nbx; b += gridDim.x)
-    compose_self_fwd_body<DIM, VEC>(phi, out, nullptr, d, 0, disp_out, blockIdx.y, (int64_t)b * (kBlock * VEC) + threadIdx.x);
+k_expo_repeat2d(const float* __restrict__ phi0, float* __restrict__ fields, int64_t F, Dims d, int k, int N, int nbx,
+                float* __restrict__ disp_rows, const float* __restrict__ flag, unsigned int* __restrict__ barrier) {
+  const int deficit = (int)*flag;
+  if (deficit <= 0) return;
+  const int items = N * nbx;
+  int passed = 0;
+  for (int lev = max(k - deficit + 1, 1); lev <= k; ++lev) {
+    const float* src = lev == 1 ? phi0 : fields + (int64_t)(lev - 2) * F;
+    float* dst = fields + (int64_t)(lev - 1) * F;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+      const int n = it / nbx, b = it - n * nbx;
+      compose_self_fwd_body<2, 2>(src, dst, nullptr, d, 0, disp_rows ? disp_rows + (int64_t)lev * kDispSlots : nullptr, n,
+                                  (int64_t)b * (kBlock * 2) + threadIdx.x);
+    }
+    if (lev == k) break;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();                                   // this workgroup's stores are visible device-wide
+      atomicAdd(barrier, 1u);
+      const unsigned int target = (unsigned int)(++passed) * gridDim.x;
+      while (atomicAdd(barrier, 0u) < target) __builtin_amdgcn_s_sleep(4);
+      __threadfence();                                   // and nothing stale is read behind the barrier
+    }
+    __syncthreads();
+  }
 }
 
 // gphi must be zero-initialised by the caller (scatter target).
@@ -1060,13 +1082,14 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   const float* src = phi0;
   // 2D: the leading squarings whose inputs the hints put below one pixel run as ONE launch (expo_fused2d.hip: whole-row LDS
   // windows, bit-identical fields).  The kernel verifies the premise itself and raises *fuse_flag when a window moves too
-  // far for some of its levels; the ordinary launches of those squarings follow it, gated on that flag.
+  // far for some of its levels; ONE repeat launch behind it (k_expo_repeat2d) then runs exactly those levels the ordinary
+  // way, and returns at once while the flag is down.
   static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 5;   // A/B knob (0 = off)
   int fused = 0;
   if (ndim == 2 && fuse_flag && hints && fuse_max >= 2) {
     // how many: the leading squarings whose hinted input displacement (bits 8.. of a hint: 1/1024 pixel) leaves a quarter
     // of room below one pixel for the field to grow between two ascent steps; a level some window cannot do after all is
-    // repeated by its gated launch
+    // repeated by the launch behind the fused kernel
     int k = 0;
     while (k < n - 1 && k < fuse_max && ((unsigned)hints[k] >> 8) != 0 &&
            (float)((unsigned)hints[k] >> 8) * (1.25f / 1024.f) < 1.f) ++k;
@@ -1074,18 +1097,21 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
       const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, disp_rows, fuse_flag,
                                                       (hipStream_t)stream);
       if (rf == ADVCHAIN_OK) {
-        // the ordinary launch of each fused squaring behind it, gated: level m + 1 of k runs only if some window of the fused
-        // kernel stopped before it (deficit > k - (m + 1))
+        // ONE repeat launch behind it: returns at once unless some window of the fused kernel stopped early, else runs the
+        // missing levels on a persistent grid every workgroup of which is resident (2 per CU asked for, 8 fit)
         fused = k;
         const Dims d2 = make_dims(ndim, dims);
         const int nbx = advchain_blocks(d2.voxels(), kBlock * 2);
-        const int per = (int)((2048 + N - 1) / N);          // ~2048 workgroups in all
-        dim3 gg((unsigned)(nbx < per ? nbx : per), (unsigned)N);
-        for (int m = 0; m < k; ++m) {
-          hipLaunchKernelGGL((k_compose_self_fwd_gated<2, 2>), gg, dim3(kBlock), 0, (hipStream_t)stream,
-                             m == 0 ? phi0 : fields + (int64_t)(m - 1) * F, fields + (int64_t)m * F, d2,
-                             disp_rows ? disp_rows + (int64_t)(m + 1) * kDispSlots : nullptr, fuse_flag, (float)(k - (m + 1)), nbx);
+        static int cus = 0;
+        if (!cus) {
+          int dev = 0;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          if (cus <= 0) cus = 64;
         }
+        const int64_t items = N * (int64_t)nbx, cap = 2 * (int64_t)cus;
+        hipLaunchKernelGGL(k_expo_repeat2d, dim3((unsigned)(items < cap ? items : cap)), dim3(kBlock), 0, (hipStream_t)stream,
+                           phi0, fields, F, d2, k, (int)N, nbx, disp_rows, fuse_flag, reinterpret_cast<unsigned int*>(fuse_flag + 1));
         ADVCHAIN_LAUNCH_CHECK();
       } else if (rf != ADVCHAIN_ERR_UNSUPPORTED) return rf;
     }

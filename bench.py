@@ -295,16 +295,17 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         extras["all_reduces_per_step"] = round(n_coll[0] / float(steps), 2)
     # model / path split: an instrumented pass of a few steps after the timed region (events around the model's forward
     # and backward calls only; the solver's own kernels carry none)
-    k_split = max(1, min(steps, 5))
+    k_split = 0 if PROFILING_RUN else max(1, min(steps, 5))       # (a profiling run holds the timed workload and nothing else)
     with _ModelTimer(solver) as mt:
         for _ in range(k_split):
             step()
-    model_ms = mt.total_ms() / k_split
+    model_ms = mt.total_ms() / max(k_split, 1)
     from advchain_amd import ops as _ops
     if _ops.FUSE_STATS["chains"]:
         extras["fused_chain_refusals"] = "%d of %d" % (_ops.FUSE_STATS["refused"], _ops.FUSE_STATS["chains"])
-    extras["model_ms_per_step"] = round(model_ms, 3)
-    extras["path_ms_per_step"] = round(elapsed / steps * 1e3 - model_ms, 3)
+    if k_split:
+        extras["model_ms_per_step"] = round(model_ms, 3)
+        extras["path_ms_per_step"] = round(elapsed / steps * 1e3 - model_ms, 3)
     extras["model_split_note"] = ("model = HIP-event time of the user model's forward calls and input-gradient backward calls "
                                   "(stock MIOpen / rocBLAS kernels) per adversarial_training call, measured over %d further "
                                   "steps after the timed region; path = ms_per_step - model" % k_split)
@@ -543,6 +544,7 @@ def run_stub(steps, warmup, rank, world):
     return float(t.item()), None, {}, extras
 
 
+PROFILING_RUN = False                   # --only-workload
 SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
 
 
@@ -570,6 +572,8 @@ def main():
                     help="profiling runs: the chosen workload and nothing else (no secondary configs, no north-star "
                          "kernel pair, no CPU baseline)")
     args = ap.parse_args()
+    global PROFILING_RUN
+    PROFILING_RUN = bool(args.only_workload)
     stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -113,12 +113,13 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
  *      displacement of phi_m (m >= 1; row 0 belongs to whoever made phi0), row n that of pos; hints (may be NULL): n
  *      displacement estimates in voxels (0 = unknown) for phi_0..phi_{n-1} (bits 0..7: as for advchain_grid_sample_fwd;
  *      bits 8..: the same estimate in 1/1024 voxel, 0 = unknown -- read by the 2D fusing rule).
- *      fuse_flag (may be NULL; one float, ZERO before the call): 2D only -- allows the leading squarings whose hinted input
+ *      fuse_flag (may be NULL; TWO 32-bit words, ZERO before the call: a float flag and the arrival counter of the repeat
+ *      launch's grid barrier): 2D only -- allows the leading squarings whose hinted input
  *      displacement is below one pixel (at most 5, rows of 64k <= 512 pixels) to run as ONE launch over whole-row LDS
  *      windows (same arithmetic, bit-identical fields).  The kernel checks the premise on every window, level by level; a
- *      window that has to stop early records how many levels it could not do (*fuse_flag = the largest such count), and the
- *      ordinary launches of the fused squarings, enqueued behind it and gated on the flag, repeat exactly those -- results
- *      never depend on the hints.  The caller may read the flag back (> 0: the hints were too optimistic) and must zero it
+ *      window that has to stop early records how many levels it could not do (*fuse_flag = the largest such count), and ONE
+ *      repeat launch enqueued behind it (a persistent grid that returns at once while the flag is down) runs exactly those
+ *      levels the ordinary way -- results never depend on the hints.  The caller may read the flag back (> 0: the hints were too optimistic) and must zero it
  *      before the next call.
  * bwd: grad_pos -> grad_phi0 through the n adjoint steps; halos[i] is the bound for the i-th step in BACKWARD order
  *      (squaring n-1 first); scratch: one field-sized buffer; workspace as for advchain_compose_self_bwd.             */

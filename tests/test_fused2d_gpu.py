@@ -1,6 +1,6 @@
 """The fused early squarings of the 2D scaling-and-squaring chain (advchain_amd/csrc/expo_fused2d.hip; reference loop
 adv_morph.py:116-146) against the one-launch-per-squaring chain: bit for bit -- fields, positions, displacement rows --
-whether the sub-pixel premise holds (one fused launch, the gated launches return at once), fails everywhere (the fused
+whether the sub-pixel premise holds (one fused launch, the repeat launch behind it returns at once), fails everywhere (the fused
 kernel only raises its flag) or fails for ONE window of one image (the ordinary launches redo every squaring)."""
 import ctypes
 
@@ -46,7 +46,8 @@ def _phi0(N, dims, amp_px, seed):
 @pytest.mark.parametrize("k", [2, 3, 4, 5])
 def test_fused_levels_equal_the_per_squaring_launches(dims, k):
     n = 8
-    phi0 = _phi0(3, dims, 0.9 / 2 ** (k - 1) * 0.95, 11 + k)        # phi_{k-1} stays just below one pixel
+    phi0 = _phi0(max(3, -(-256 // max(1, dims[0] // 16))), dims, 0.9 / 2 ** (k - 1) * 0.95, 11 + k)   # phi_{k-1} just below one pixel; >= 256 windows
+
     hints = [1] * k + [0] * (n - k)
     ref = _chain(phi0, n, None, False)
     out = _chain(phi0, n, hints, True)
@@ -54,8 +55,8 @@ def test_fused_levels_equal_the_per_squaring_launches(dims, k):
     assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
     for m in range(n - 1):
         assert torch.equal(out[0][m], ref[0][m]), (dims, k, m)
-    # the gated launches really returned at once: poison the first k fields, run with hints again -> still the fused values
-    # (a fused launch that silently did nothing would leave NaN here, since the gated launches do not run either)
+    # the repeat launch really returned at once: poison the first k fields, run with hints again -> still the fused values
+    # (a fused launch that silently did nothing would leave NaN here, since the repeat launch does not run either)
     assert not torch.isnan(out[0][:k]).any()
 
 
@@ -63,7 +64,7 @@ def test_partial_deficit_repeats_only_the_missing_levels():
     """Hints promise 4 sub-pixel levels, the field allows 2 (phi_2 moves more than a pixel): the fused kernel stops after
     level 2 everywhere it must, records a deficit of 2, and the gated launches of levels 3 and 4 run -- same bits."""
     n, dims = 8, (128, 256)
-    phi0 = _phi0(4, dims, 0.4, 9)                   # phi_1 ~0.8 px, phi_2 ~1.6 px
+    phi0 = _phi0(32, dims, 0.4, 9)                   # phi_1 ~0.8 px, phi_2 ~1.6 px
     ref = _chain(phi0, n, None, False)
     assert ref[2][1] < 0.999 and ref[2][2] > 1.0, ref[2][:4]
     out = _chain(phi0, n, [1, 1, 1, 1, 0, 0, 0, 0], True)
@@ -78,9 +79,9 @@ def test_fused_premise_violated_falls_back(case):
     """Hints that are too optimistic: the kernel's own check refuses, raises the flag, and the gated ordinary launches
     produce the fields -- results never depend on the hints."""
     n, dims = 8, (128, 256)
-    phi0 = _phi0(4, dims, 0.05, 3)
+    phi0 = _phi0(32, dims, 0.05, 3)
     if case == "all":
-        phi0 = _phi0(4, dims, 3.0, 3)
+        phi0 = _phi0(32, dims, 3.0, 3)
     elif case == "one_window":      # a 2-pixel bump in a few rows of one image
         phi0[2, 0, 70:74, 100:140] += 2.0 * 2.0 / (dims[1] - 1)
     else:
@@ -95,10 +96,12 @@ def test_fused_premise_violated_falls_back(case):
     assert torch.equal(torch.nan_to_num(out[2], nan=7.0), torch.nan_to_num(ref[2], nan=7.0))
 
 
-def test_unsupported_shapes_take_the_ordinary_launches():
-    """Rows that are not a multiple of 64 pixels (or 3D fields): the chain ignores the flag and runs its ordinary launches."""
+@pytest.mark.parametrize("N,dims", [(32, (48, 100)), (2, (128, 256))])
+def test_unsupported_shapes_take_the_ordinary_launches(N, dims):
+    """Rows that are not a multiple of 64 pixels, or fewer than 256 windows in all (3D fields likewise): the chain ignores
+    the flag and runs its ordinary launches."""
     n = 5
-    phi0 = _phi0(2, (48, 100), 0.05, 5)
+    phi0 = _phi0(N, dims, 0.05, 5)
     ref = _chain(phi0, n, None, False)
     out = _chain(phi0, n, [1] * n, True)
     assert out[3] == 0.0 and torch.equal(out[1], ref[1])
@@ -110,7 +113,7 @@ def test_demons_field_uses_the_fused_chain_and_matches():
     """Through the product operator: the second evaluation of a field of one shape has hints and fuses; same bits as with
     fusing switched off (ops.FUSE_2D)."""
     from advchain_amd import bands, ops
-    dims, vs, N = (256, 256), [16, 16], 4
+    dims, vs, N = (256, 256), [16, 16], 8        # (paired: 16 fields x 16 windows -- the fused forward wants 256 workgroups)
     tabs = bands.upsample_tables(vs, list(dims), DEV)
     v = rand((N, 2) + tuple(vs), 21).to(DEV)
     v = v / v.reshape(N, -1).norm(dim=1).view(N, 1, 1, 1)

@@ -139,6 +139,49 @@ def main():
     ops.TILED_SCATTER = False
     add("compose_self bwd (atomic path)", lambda: ops.raw_compose_self_bwd(gq, phi), 12 * d * NV)
     ops.TILED_SCATTER = old
+    if d == 2:   # the whole chain of 8 squarings on the paired batch [v; -v] of a solver step, with and without the fused levels
+        import ctypes
+        from advchain_amd import _lib
+        lib = _lib.load()
+        n = 8
+        s1 = ops.raw_gauss_small_pair(t.param, 1.5 * float(os.environ.get("KB_CHAIN_AMP", "4")))   # ~ the field after one ascent step
+        rows_d = torch.zeros(n + 2, ops.DISP_SLOTS, device=dev)
+        p0 = ops.raw_tp_interp(s1, tabs, d, add_identity=True, scale=1.0 / 2 ** n, disp_out=rows_d[0])
+        NB = p0.shape[0]
+        fields = torch.empty((n - 1,) + tuple(p0.shape), device=dev)
+        pos = torch.empty_like(p0)
+        da = _lib.dims_array(dims)
+
+        def chain_fwd(hints, fuse):
+            rows_d[1:].zero_()
+            harr = None if hints is None else (ctypes.c_int32 * n)(*hints)
+            _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(p0), ops._ptr(fields), ops._ptr(pos), NB, d, da, n, ops._ptr(rows_d), harr,
+                                                   ops._ptr(rows_d[n + 1]) if fuse else None, ops._stream()), "chain_fwd")
+        chain_fwd(None, False)
+        dm = ops.raw_slot_rows_max(rows_d).tolist()
+        hints = [(ops._hint_bits(x) >> 8) | (ops._fine_bits(x) << 8) for x in dm[:n]]
+        halos = [ops.squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
+        gp = torch.rand_like(p0)
+        wsb = ops._scatter_workspace(NB, dims, dev)
+        gout, scr = torch.empty_like(gp), torch.empty_like(gp)
+        phis = [p0] + list(fields.unbind(0))
+        bufs = [torch.empty_like(gp), torch.empty_like(gp)]
+
+        def chain_bwd_steps():
+            g = gp
+            for i, ph in enumerate(reversed(phis)):
+                _lib.check(lib.advchain_compose_self_bwd(ops._ptr(g), ops._ptr(ph), ops._ptr(bufs[i % 2]), ops._ptr(wsb), int(i > 0), halos[i],
+                                                         NB, d, da, ops._stream()), "step")
+                g = bufs[i % 2]
+
+        def chain_bwd():
+            _lib.check(lib.advchain_expo_chain_bwd(ops._ptr(gp), ops._ptr(p0), ops._ptr(fields), ops._ptr(gout), ops._ptr(scr), ops._ptr(wsb),
+                                                   (ctypes.c_int32 * n)(*halos), NB, d, da, n, ops._stream()), "chain_bwd")
+        tag = "disp %s" % " ".join("%.1f" % x for x in dm[:n])
+        add("expo_chain fwd x8, paired (%s)" % tag, lambda: chain_fwd(hints, False), (8 * n + 4) * d * NB * V)
+        add("expo_chain fwd x8, fused levels", lambda: chain_fwd(hints, True), (8 * n + 4) * d * NB * V)
+        add("expo_chain bwd x8, separate launches", chain_bwd_steps, 12 * n * d * NB * V)
+        add("expo_chain bwd x8, fused tail %s" % halos, chain_bwd, 12 * n * d * NB * V)
     add("gauss %d passes (d ch, pre2/post1)" % d, lambda: ops.raw_gauss(q, d, pre=2, post=1), 8 * d * NV * d)
     add("affine_warp fwd C=1", lambda: ops.affine_warp(x1, theta), 8 * NV)
     add("affine_warp fwd C=4", lambda: ops.affine_warp(x4, theta), 32 * NV)

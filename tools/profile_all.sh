@@ -6,6 +6,7 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/$tag
 mkdir -p "$out"
 bash $repo/tools/profile_bench.sh $tag > "$out/per_call_summary.txt" 2>&1
+bash $repo/tools/profile_ns_pair.sh $tag > "$out/ns_pair.log" 2>&1
 bash $repo/tools/profile_pmc.sh $tag > "$out/pmc.log" 2>&1
 bash $repo/tools/profile_sq.sh $tag > "$out/sq_issue_summary.txt" 2>&1
 cd $repo

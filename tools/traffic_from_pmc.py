@@ -71,7 +71,21 @@ ENTRIES["advchain_grid_sample_fwd"] = (ENTRIES["advchain_grid_sample_fwd"][0] + 
                                        ENTRIES["advchain_grid_sample_fwd"][1] + r"|k_sample_march_flat<\d, false")
 ENTRIES["advchain_compose_self_bwd"] = (ENTRIES["advchain_compose_self_bwd"][0] + [r"k_scatter_march3d_flat<"],
                                         ENTRIES["advchain_compose_self_bwd"][1] + r"|k_scatter_march3d_flat<")
-WIDE = re.compile(r"k_sample_march_flat<3, true|"r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
+# round 4: the sub-pixel squarings of a 2D chain in one launch each way, the dense-band upsample adjoint, the fused 2D loss
+ENTRIES["advchain_compose_self_fwd"] = (ENTRIES["advchain_compose_self_fwd"][0] + [r"k_expo_fused_fwd2d<", r"k_compose_self_fwd_gated<"],
+                                        ENTRIES["advchain_compose_self_fwd"][1])
+ENTRIES["advchain_compose_self_bwd"] = (ENTRIES["advchain_compose_self_bwd"][0] + [r"k_adjoint_fused2d<"], ENTRIES["advchain_compose_self_bwd"][1])
+ENTRIES["advchain_consistency_fwd"] = ([r"k_softmax_diff", r"k_edge_fwd", r"k_loss_fused_fwd4"], r"k_softmax_diff|k_loss_fused_fwd4")
+ENTRIES["advchain_consistency_bwd"] = ([r"k_consistency_bwd", r"k_loss_fused_bwd4"], r"k_consistency_bwd|k_loss_fused_bwd4")
+# A fused launch covers several squarings, so the launches of the chain entries are counted per SQUARING, as bench.py does
+# (its roofline divides a chain call by n): chain calls x 8, the chain calls read off the one Gaussian launch that opens the
+# backward of a chain (k_gauss_xy<0, .>) / closes its forward (k_gauss_xy<2, .>)
+CHAIN_CALLS = {"advchain_compose_self_fwd": r"k_gauss_xy<2, \d>", "advchain_compose_self_bwd": r"k_gauss_xy<0, \d>"}
+CHAIN_N = 8
+# algorithmic bytes of one squaring on the PAIRED batch [v; -v] (forward 8 d, backward 12 d bytes per voxel)
+PAIRED_VOXELS = {"cfg2": (2, 64 * 256 * 256), "cfg3": (3, 8 * 128 * 128 * 64), "cfg4": (3, 16 * 128 * 128 * 64), "cfg5": (3, 8 * 160 * 160 * 80)}
+HBM_PEAK = 8.0e12
+WIDE = re.compile(r"k_expo_fused_fwd2d|k_adjoint_fused2d|k_band_reduce_rows|k_loss_fused|k_sample_march_flat<3, true|"r"k_adjoint_gather|k_adjoint_march|k_sample_tiled|k_sample_march<3, true|k_gauss_axis_v4|k_gauss_march_z|k_gauss_xy|k_max_displacement|"
                   r"k_axpy|k_absmax|k_softmax_diff_v4|k_edge_fwd_march4|k_consistency_bwd_march4|k_affine_box_fwd|k_affine_box_gtheta|"
                   r"k_scatter_march3d_wide|k_march_rowmax64|k_sample_ring")   # 16 B / lane
 MIXED = {r"k_sample_march<1, false": 1.41, r"k_sample_march<4, false": 1.7,
@@ -93,6 +107,22 @@ def load(path):
     return rows
 
 
+def load_stats(path):
+    """rocprofv3 --kernel-trace --stats summary (tools/profile_bench.sh): kernel -> (calls, total ns)"""
+    rows = {}
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
+    return rows
+
+
+def entry_launches(entry, table, main_pat):
+    """launches of an entry in a {kernel: (calls, ...)} table; chain entries per squaring (see CHAIN_CALLS)"""
+    if entry in CHAIN_CALLS and any(re.search(r"k_expo_fused_fwd2d|k_adjoint_fused2d", k) for k in table):
+        return CHAIN_N * sum(c for k, (c, _) in table.items() if re.search(CHAIN_CALLS[entry], k))
+    return sum(c for k, (c, _) in table.items() if re.search(main_pat, k))
+
+
 def main(root, out):
     res = {"_doc": __doc__.strip().split("\n\n")[1]}
     for wl in ("cfg2", "cfg3", "cfg4", "cfg5"):
@@ -103,7 +133,6 @@ def main(root, out):
         res[wl] = {}
         for entry, (pats, main_pat) in ENTRIES.items():
             rb = wb = 0.0
-            launches = 0
             parts = {}
             for k, (calls, kb) in fetch.items():
                 if any(re.search(p, k) for p in pats):
@@ -111,14 +140,32 @@ def main(root, out):
                     rb += calls * kb * 1024 * f
                     parts[k] = {"calls": calls, "FETCH_SIZE_KB": round(kb, 1), "read_factor": round(f, 2),
                                 "WRITE_SIZE_KB": round(write.get(k, (0, 0.0))[1], 1)}
-                    if re.search(main_pat, k):
-                        launches += calls
             for k, (calls, kb) in write.items():
                 if any(re.search(p, k) for p in pats):
                     wb += calls * kb * 1024
+            launches = entry_launches(entry, fetch, main_pat)
             if launches:
                 res[wl][entry] = {"traffic_bytes_per_launch": int((rb + wb) / launches), "read_bytes_per_launch": int(rb / launches),
                                   "write_bytes_per_launch": int(wb / launches), "entry_launches_profiled": launches, "kernels": parts}
+        # durations of the same entries from the kernel trace of the same command (profile_bench.sh), so that the roofline
+        # fraction can be recomputed from committed files alone: algorithmic bytes / mean duration per launch / 8 TB/s
+        stats = load_stats(os.path.join(root, "%s_kernel_stats.csv" % wl))
+        for entry, (pats, main_pat) in ENTRIES.items():
+            if entry not in res[wl] or not stats:
+                continue
+            ns_total = sum(t for k, (c, t) in stats.items() if any(re.search(p, k) for p in pats))
+            n_l = entry_launches(entry, stats, main_pat)
+            if not n_l:
+                continue
+            rec = res[wl][entry]
+            rec["rocprof_us_per_launch"] = round(ns_total / n_l / 1e3, 2)
+            rec["rocprof_launches"] = n_l
+            if entry in CHAIN_CALLS and wl in PAIRED_VOXELS:
+                d, nv = PAIRED_VOXELS[wl]
+                alg = (8 if entry.endswith("fwd") else 12) * d * nv
+                rec["algorithmic_bytes_per_launch"] = alg
+                rec["frac_from_rocprof"] = round(alg / (ns_total / n_l * 1e-9) / HBM_PEAK, 4)
+                rec["traffic_over_algorithmic"] = round(rec["traffic_bytes_per_launch"] / alg, 3)
     # the north-star pair on its own (tools/north_star_pair.py): every kernel of the run belongs to the pair
     ns = {}
     for level in ("init_field", "after_cfg3_ascent"):
@@ -145,9 +192,15 @@ def main(root, out):
         if wl.startswith("_") or wl == "north_star":
             continue
         for e, v in res[wl].items():
-            print("%s %-28s traffic %.1f MB/launch (read %.1f, write %.1f) over %d launches" % (
+            extra = ""
+            if "rocprof_us_per_launch" in v:
+                extra = "; %.1f us/launch" % v["rocprof_us_per_launch"]
+            if "frac_from_rocprof" in v:
+                extra += " = %.3f of peak on %.1f MB algorithmic, traffic %.2fx" % (v["frac_from_rocprof"], v["algorithmic_bytes_per_launch"] / 1e6,
+                                                                                  v["traffic_over_algorithmic"])
+            print("%s %-28s traffic %.1f MB/launch (read %.1f, write %.1f) over %d launches%s" % (
                 wl, e, v["traffic_bytes_per_launch"] / 1e6, v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6,
-                v["entry_launches_profiled"]))
+                v["entry_launches_profiled"], extra))
 
 
     for level, v in res.get("north_star", {}).items():
