@@ -137,3 +137,27 @@ def test_caller_utilities_match_the_reference_golden():
     img = U.load_image_label(path, slice_id=0, crop_size=(192, 192))
     assert img.shape == (192, 192) and abs(float(img.astype(np.float64).sum()) - m["loaded_sum"]) < 1e-6 * m["loaded_sum"]
     assert np.allclose(img[::16, ::16], fx.arr("nrrd_loaded_sample"), atol=1e-7)
+
+
+def test_profile_tooling_recomputes_the_committed_numbers(tmp_path):
+    """The evidence tooling on the committed round-4 profiles: tools/traffic_from_pmc.py rebuilds traffic.json (HBM bytes per
+    launch from the PMC passes, duration and roofline fraction from the kernel trace of the same command) and
+    tools/ns_pair_summary.py the north-star pair's fraction -- the numbers DESIGN.md quotes must come out of the CSVs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles", "r04")
+    out = str(tmp_path / "traffic.json")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "traffic_from_pmc.py"), prof, out], check=True, stdout=subprocess.DEVNULL)
+    t = json.load(open(out))
+    committed = json.load(open(os.path.join(prof, "traffic.json")))
+    for wl in ("cfg2", "cfg3", "cfg5"):
+        rec = t[wl]["advchain_compose_self_bwd"]
+        assert rec == committed[wl]["advchain_compose_self_bwd"]
+        assert 0.2 < rec["frac_from_rocprof"] < 0.45 and 1.0 < rec["traffic_over_algorithmic"] < 1.6
+    assert abs(t["cfg2"]["advchain_compose_self_bwd"]["frac_from_rocprof"] - 0.286) < 0.002
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ns_pair_summary.py"), prof], check=True, capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("level")]
+    assert len(lines) == 2 and "0.593 of" in lines[0] and "0.313 of" in lines[1], r.stdout
