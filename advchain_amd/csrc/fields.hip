@@ -91,8 +91,31 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
   const int ROWS = kBlock / XT;
   const int tx = threadIdx.x % XT, ry = threadIdx.x / XT;
   const int g2 = A2.g;
+  // Every table value this workgroup needs is requested up front, together (round 4): the row tables of its i1 chunk go to
+  // LDS, the plane's and the thread's first column group's stay in registers.  Before, the blend phase loaded start[i1] and
+  // then the coefficients it addresses, and the output phase start[x] / w[x] behind the barrier -- four dependent L2 round
+  // trips per 8 KB written (56 us for a 100 MB write at 8 x 3 x 128 x 128 x 64); now one for the tables, one for the
+  // coefficients.  Same values, same sums.
+  __shared__ int s1_s[kTpChunk];
+  __shared__ float w1_s[kTpChunk * kBandMax];
+  const int nrow = i1_end - i1_begin;                      // <= kTpChunk
+  for (int e = threadIdx.x; e < nrow * (A1.B + 1); e += kBlock) {
+    const int r = e / (A1.B + 1), b = e - r * (A1.B + 1);
+    if (b == 0) s1_s[r] = A1.start[i1_begin + r];
+    else w1_s[r * kBandMax + b - 1] = A1.w[(i1_begin + r) * A1.B + b - 1];
+  }
   const int s0 = A0.start[i0];
   const float* w0 = A0.w + i0 * A0.B;
+  int s2f[VEC];
+  float w2f[VEC][kBandMax];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    const int col = min(tx * VEC + q, full.s2 - 1);
+    s2f[q] = A2.start[col];
+#pragma unroll
+    for (int c = 0; c < kBandMax; ++c) w2f[q][c] = c < A2.B ? A2.w[col * A2.B + c] : 0.f;
+  }
+  __syncthreads();
   // rows blended per phase: as many as the LDS buffer holds (with 4 rows per phase a workgroup paid two barriers and a
   // dependent start[] -> coef[] load chain per 4 rows: 52 us for a 50 MB write at 4x3x128x128x64)
   const int RPP = max(1, min(kTpChunk, kTpMaxLds / max(g2, 1)));
@@ -102,8 +125,8 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
       const int i1 = base + r;
       float acc = 0.f;
       if (i1 < i1_end) {
-        const int s1 = A1.start[i1];
-        const float* w1 = A1.w + i1 * A1.B;
+        const int s1 = s1_s[i1 - i1_begin];
+        const float* w1 = w1_s + (i1 - i1_begin) * kBandMax;
         if (A0.B == 2 && A1.B == 2) {   // linear upsampling (uniform): the four terms' loads in flight together
           const float* cb = coef + ((int64_t)s0 * A1.g + s1) * g2 + k;
           const float c00 = cb[0], c01 = cb[g2], c10 = cb[(int64_t)A1.g * g2], c11 = cb[(int64_t)A1.g * g2 + g2];
@@ -128,9 +151,15 @@ __device__ __forceinline__ void tp_rows(const float* __restrict__ coef, const Ba
       float w2[VEC][kBandMax];
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
-        s2[q] = A2.start[xg * VEC + q];
+        if (xg == tx) {           // (requested before the first barrier)
+          s2[q] = s2f[q];
 #pragma unroll
-        for (int c = 0; c < kBandMax; ++c) w2[q][c] = c < A2.B ? A2.w[(xg * VEC + q) * A2.B + c] : 0.f;
+          for (int c = 0; c < kBandMax; ++c) w2[q][c] = w2f[q][c];
+        } else {
+          s2[q] = A2.start[xg * VEC + q];
+#pragma unroll
+          for (int c = 0; c < kBandMax; ++c) w2[q][c] = c < A2.B ? A2.w[(xg * VEC + q) * A2.B + c] : 0.f;
+        }
       }
       for (int r = ry; r < RPP; r += ROWS) {
         const int i1 = base + r;
@@ -180,6 +209,140 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
     if (out) store_vec<VEC>(out + (int64_t)plane * V + ((int64_t)i0 * full.s1 + i1) * full.s2 + x, o);
   });
   if (disp_out) wave_max_to_slots(fminf(dmax * to_vox, 1.0e9f), disp_out);   // displacement of base + scale * val, in voxels
+  if (sumsq) {
+    block_sum<1>(sq, smem);
+    if (threadIdx.x == 0) atomic_add_f32(sumsq + (blockIdx.x + blockIdx.y * 3u + blockIdx.z * 7u) % kSumSlots, sq[0]);
+  }
+}
+
+// The 3D linear upsampling (bands of 2 on every axis), ZB consecutive i0 planes per workgroup, software-pipelined (round 4).
+// One plane per workgroup meant: tables, coefficients, barrier, 10 outputs per thread, barrier -- 19200 workgroups of ~4 us for
+// a 196 MB write at cfg-5 (1.9 TB/s), and hoisting the table loads alone changed nothing (104 us either way: the chain is per
+// WORKGROUP, and a workgroup had too little to do behind it).  Here the tables of the i1 chunk, the columns and the ZB planes
+// are requested once; the four coefficients of every blend element of plane i0 + 1 are requested BEFORE the outputs of plane
+// i0 are formed and blended after them, into the other half of a double LDS buffer: one barrier per plane, the coefficient
+// round trip under the stores.  Same sums in the same order as tp_rows: bit-identical.
+constexpr int kTpZB = 4;
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_tp_interp_fwd_planes(const float* __restrict__ coef, float* __restrict__ out, BandTables T, Dims full, int C, int add_identity,
+                       float scale, float* __restrict__ sumsq, float* __restrict__ disp_out) {
+  __shared__ float lds[2][kTpMaxLds];
+  __shared__ int s1_s[kTpChunk], s0_s[kTpZB];
+  __shared__ float w1_s[kTpChunk * 2], w0_s[kTpZB * 2];
+  __shared__ float smem[4];
+  const BandAxis& A0 = T.a[0];
+  const BandAxis& A1 = T.a[1];
+  const BandAxis& A2 = T.a[2];
+  const int plane = blockIdx.z;
+  const int z0 = blockIdx.y * kTpZB, z1 = min(z0 + kTpZB, full.s0);
+  const int i1b = blockIdx.x * kTpChunk, i1e = min(i1b + kTpChunk, full.s1);
+  const int64_t G = (int64_t)A0.g * A1.g * A2.g;
+  const int V = (int)full.voxels();
+  const int c = plane % C;
+  const float* cf = coef + (int64_t)plane * G;
+  const int g2 = A2.g, nrow = i1e - i1b, NE = nrow * g2;          // NE <= kTpMaxLds (launcher)
+  constexpr int EPT = kTpMaxLds / kBlock;                          // blend elements per thread at most
+  const int ncol = full.s2 / VEC;
+  int XT = 64;
+  if (VEC > 1) { XT = 1; while (XT < ncol && XT < 64) XT *= 2; }
+  const int ROWS = kBlock / XT;
+  const int tx = threadIdx.x % XT, ry = threadIdx.x / XT;
+  // ---- every table value, requested together
+  for (int e = threadIdx.x; e < nrow * 3; e += kBlock) {
+    const int r = e / 3, b = e - r * 3;
+    if (b == 0) s1_s[r] = A1.start[i1b + r];
+    else w1_s[r * 2 + b - 1] = A1.w[(i1b + r) * 2 + b - 1];
+  }
+  if (threadIdx.x < (z1 - z0) * 3) {
+    const int r = threadIdx.x / 3, b = threadIdx.x - r * 3;
+    if (b == 0) s0_s[r] = A0.start[z0 + r];
+    else w0_s[r * 2 + b - 1] = A0.w[(z0 + r) * 2 + b - 1];
+  }
+  int s2f[VEC];
+  float w2f[VEC][2];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    const int col = min(tx * VEC + q, full.s2 - 1);
+    s2f[q] = A2.start[col];
+    w2f[q][0] = A2.w[col * 2];
+    w2f[q][1] = A2.w[col * 2 + 1];
+  }
+  __syncthreads();
+  float cc[EPT][4];
+  auto request = [&](int zi) {          // the four coefficients of each blend element of plane z0 + zi
+    const int s0 = s0_s[zi];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      if (j * kBlock >= NE) break;                                    // block-uniform
+      const int e = min(threadIdx.x + j * kBlock, NE - 1);           // (unconditional loads from a clamped element)
+      const int r = e / g2, k = e - r * g2;
+      const float* cb = cf + ((int64_t)s0 * A1.g + s1_s[r]) * g2 + k;
+      cc[j][0] = cb[0]; cc[j][1] = cb[g2]; cc[j][2] = cb[(int64_t)A1.g * g2]; cc[j][3] = cb[(int64_t)A1.g * g2 + g2];
+    }
+  };
+  auto blend = [&](int zi, float* dst) {
+    const float v0 = w0_s[zi * 2], v1 = w0_s[zi * 2 + 1];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int e = threadIdx.x + j * kBlock;
+      if (e >= NE) continue;
+      const int r = e / g2;
+      const float u0 = w1_s[r * 2], u1 = w1_s[r * 2 + 1];
+      float acc = 0.f;
+      acc += v0 * (0.f + u0 * cc[j][0] + u1 * cc[j][1]);
+      acc += v1 * (0.f + u0 * cc[j][2] + u1 * cc[j][3]);
+      dst[e] = acc;
+    }
+  };
+  float sq[1] = {0.f};
+  float dmax = 0.f;
+  const bool track = sumsq != nullptr || disp_out != nullptr;
+  const float to_vox = fabsf(scale) * 0.5f * (float)((c == 0 ? full.s2 : (c == 1 ? full.s1 : full.s0)) - 1);
+  request(0);
+  blend(0, lds[0]);
+  __syncthreads();
+  for (int zi = 0; zi < z1 - z0; ++zi) {
+    const int i0 = z0 + zi;
+    const float* cur = lds[zi & 1];
+    const bool more = zi + 1 < z1 - z0;
+    if (more) request(zi + 1);
+    for (int xg = tx; xg < ncol; xg += XT) {
+      int s2[VEC];
+      float w2[VEC][2];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        if (xg == tx) { s2[q] = s2f[q]; w2[q][0] = w2f[q][0]; w2[q][1] = w2f[q][1]; }
+        else { s2[q] = A2.start[xg * VEC + q]; w2[q][0] = A2.w[(xg * VEC + q) * 2]; w2[q][1] = A2.w[(xg * VEC + q) * 2 + 1]; }
+      }
+      // the identity part of an output is a column constant (channel 0), a row constant (1) or a plane constant (2)
+      float basex[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) basex[q] = (add_identity && c == 0) ? lin_coord(xg * VEC + q, full.s2) : 0.f;
+      const float basez = (add_identity && c == 2) ? lin_coord(i0, full.s0) : 0.f;
+      float* orow = out ? out + (int64_t)plane * V + ((int64_t)i0 * full.s1 + i1b) * full.s2 + xg * VEC : nullptr;
+      for (int r = ry; r < nrow; r += ROWS) {
+        const float basey = (add_identity && c == 1) ? lin_coord(i1b + r, full.s1) : basez;
+        const float* lr = cur + r * g2;
+        float o[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          float v = 0.f;
+          v += w2[q][0] * lr[s2[q]];
+          v += w2[q][1] * lr[s2[q] + 1];
+          if (track) {
+            sq[0] += v * v;
+            dmax = fmaxf(dmax, fabsf(v));
+          }
+          o[q] = (c == 0 ? basex[q] : basey) + scale * v;
+        }
+        if (out) store_vec<VEC>(orow + r * full.s2, o);
+      }
+    }
+    if (more) blend(zi + 1, lds[(zi + 1) & 1]);
+    __syncthreads();
+  }
+  if (disp_out) wave_max_to_slots(fminf(dmax * to_vox, 1.0e9f), disp_out);
   if (sumsq) {
     block_sum<1>(sq, smem);
     if (threadIdx.x == 0) atomic_add_f32(sumsq + (blockIdx.x + blockIdx.y * 3u + blockIdx.z * 7u) % kSumSlots, sq[0]);
@@ -1084,6 +1247,21 @@ int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, c
   ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "tp_interp_fwd: volume too large");
   ADVCHAIN_CHECK_ARG(T.a[2].g <= kTpMaxLds, "tp_interp_fwd: coefficient row too long");
   dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), (unsigned)full.s0, (unsigned)planes);
+  static const bool no_planes = getenv("ADVCHAIN_NO_TP_PLANES") != nullptr;   // A/B knob
+  if (!no_planes && full.s0 >= 2 * kTpZB && T.a[0].B == 2 && T.a[1].B == 2 && T.a[2].B == 2 && kTpChunk * T.a[2].g <= kTpMaxLds) {
+    // 3D linear upsampling: kTpZB planes per workgroup, pipelined
+    dim3 gp(grid.x, (unsigned)((full.s0 + kTpZB - 1) / kTpZB), (unsigned)planes);
+    // 16 bytes per lane for long rows and for rows that do not fill whole waves one voxel per lane (cfg-5's rows of 80: 90
+    // against 107 us); rows of exactly 64 time the same either way
+    if (full.s2 % 4 == 0 && (full.s2 >= 128 || full.s2 % 64 != 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+      hipLaunchKernelGGL(k_tp_interp_fwd_planes<4>, gp, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C, add_identity,
+                         scale, sumsq, disp_out);
+    else
+      hipLaunchKernelGGL(k_tp_interp_fwd_planes<1>, gp, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C, add_identity,
+                         scale, sumsq, disp_out);
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   // short rows (S2 < 128) leave a thread only two rows to amortise the bands of its 4 columns: measured slower (3D 53 -> 61 us)
   if (full.s2 % 4 == 0 && full.s2 >= 128 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
     hipLaunchKernelGGL(k_tp_interp_fwd<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
