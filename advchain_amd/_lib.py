@@ -17,11 +17,13 @@ PROTOTYPES = {
     "advchain_version": (_I, []),
     "advchain_last_error": (c_char_p, []),
     "advchain_grid_sample_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P]),
+    "advchain_grid_sample_fwd_ride": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _I, _P]),
     "advchain_scatter_workspace": (_L, [_L, _I, _P]),
     "advchain_grid_sample_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _I, _P]),
     "advchain_compose_self_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
     "advchain_compose_self_bwd": (_I, [_P, _P, _P, _P, _I, _I, _L, _I, _P, _P]),
     "advchain_affine_warp_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _I, _I, _P]),
+    "advchain_affine_warp_fwd_ride": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _P]),
     "advchain_affine_warp_bwd_workspace": (_L, [_L, _I, _P]),
     "advchain_affine_warp_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _P]),
     "advchain_affine_theta_fwd": (_I, [_P, _P, _F, _P, _P, _L, _I, _P]),

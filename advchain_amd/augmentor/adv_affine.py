@@ -92,12 +92,14 @@ class AdvAffine(AdvTransformBase):
         homo[:, :d] = affine_matrix
         return homo.inverse()[:, :d, :]
 
-    def transform(self, data, affine_matrix, interp=None, padding_mode=None):
+    def transform(self, data, affine_matrix, interp=None, padding_mode=None, _ride=None, _ride_nonzero=False):
         # adv_affine.py:289-314 (Q9: a caller-supplied padding_mode is replaced by the constructor's)
         if padding_mode is not None:
             padding_mode = self.image_padding_mode
         if interp is None:
             interp = self.forward_interp
+        if _ride is not None:    # (solver-internal, see _ride_ok: the validity mask through the same launch)
+            return ops.affine_warp(data, affine_matrix, interp, padding_mode, ride=_ride, ride_nonzero=_ride_nonzero)
         if padding_mode == "lowest":
             flat = data.reshape(data.size(0), -1)
             self.padding_values = torch.min(flat, dim=1, keepdim=True).values.detach().clone()
@@ -107,7 +109,13 @@ class AdvAffine(AdvTransformBase):
             return ops.affine_warp(data - padding_mode, affine_matrix, interp, 'zeros') + padding_mode
         return ops.affine_warp(data, affine_matrix, interp, padding_mode)
 
-    def forward(self, data, interp=None, padding_mode=None):
+    def _ride_ok(self, interp=None, padding_mode=None):
+        """See AdvMorph._ride_ok."""
+        pad = self.image_padding_mode
+        return (interp is None and padding_mode is None and isinstance(pad, str) and pad != 'lowest'
+                and self.forward_interp in ops.RIDE_INTERPS and self.backward_interp in ops.RIDE_INTERPS)
+
+    def forward(self, data, interp=None, padding_mode=None, _ride=None):
         # adv_affine.py:121-146
         if padding_mode is None:
             padding_mode = self.image_padding_mode
@@ -119,11 +127,15 @@ class AdvAffine(AdvTransformBase):
         theta, theta_inv = ops.affine_theta(self.param, self._cfg_vector(), pscale, self.spatial_dims)
         self.affine_matrix = theta
         self._inverse_of = (theta, theta_inv)
-        out = self.transform(data, theta, interp=interp, padding_mode=padding_mode)
+        out = self.transform(data, theta, interp=interp, padding_mode=padding_mode, _ride=_ride)
+        if _ride is not None:    # (the reference's last forward() of a step is the mask's: adv_compose_solver.py:262-264)
+            out, rout = out
+            self.diff = _LazyDiff(lambda o=rout, d=_ride: d - o)
+            return out, rout
         self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): d - o)
         return out
 
-    def backward(self, data, interp=None, padding_mode=None):
+    def backward(self, data, interp=None, padding_mode=None, _ride=None, _ride_nonzero=False):
         # adv_affine.py:154-164
         assert self.param is not None, 'play forward before backward'
         inverse_matrix = self.get_inverse_matrix(self.affine_matrix)
@@ -131,13 +143,14 @@ class AdvAffine(AdvTransformBase):
             interp = self.backward_interp
         if padding_mode is None:
             padding_mode = self.image_padding_mode
-        return self.transform(data, inverse_matrix, interp=interp, padding_mode=padding_mode)
+        return self.transform(data, inverse_matrix, interp=interp, padding_mode=padding_mode, _ride=_ride,
+                              _ride_nonzero=_ride_nonzero)
 
     def predict_forward(self, data, interp=None, padding_mode=None):
         return self.forward(data, interp=interp, padding_mode=padding_mode)
 
-    def predict_backward(self, data, interp=None, padding_mode=None):
-        return self.backward(data, interp=interp, padding_mode=padding_mode)
+    def predict_backward(self, data, interp=None, padding_mode=None, _ride=None, _ride_nonzero=False):
+        return self.backward(data, interp=interp, padding_mode=padding_mode, _ride=_ride, _ride_nonzero=_ride_nonzero)
 
     def train(self):
         # adv_affine.py:204-208

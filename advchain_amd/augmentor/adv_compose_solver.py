@@ -148,7 +148,7 @@ class ComposeAdversarialTransformSolver(object):
     def diffs(self):
         return [t.diff for t in self._last_chain]
 
-    def forward(self, data, chain_of_transforms=None, interp=None, padding_mode=None):
+    def forward(self, data, chain_of_transforms=None, interp=None, padding_mode=None, _ride=False):
         """Apply the chain in order (adv_compose_solver.py:148-176)."""
         data.requires_grad = False
         if chain_of_transforms is None:
@@ -158,8 +158,20 @@ class ComposeAdversarialTransformSolver(object):
         native = len(chain_of_transforms) > 0 and all(isinstance(t, _NATIVE) for t in chain_of_transforms)
         t_data = data.detach() if native else data.detach().clone()
         self._last_chain = list(chain_of_transforms)
-        for transform in chain_of_transforms:
-            t_data = transform.forward(t_data, interp=interp, padding_mode=padding_mode)
+        self._ride = None
+        if _ride:       # the validity mask rides along: every geometric transform warps (data, mask) in one call
+            ride = None
+            for transform in chain_of_transforms:
+                if transform.is_geometric():
+                    if ride is None:
+                        ride = ops.cached_ones((t_data.shape[0], 1) + tuple(t_data.shape[2:]), t_data.device)
+                    t_data, ride = transform.forward(t_data, _ride=ride)
+                else:
+                    t_data = transform.forward(t_data)
+            self._ride = ride
+        else:
+            for transform in chain_of_transforms:
+                t_data = transform.forward(t_data, interp=interp, padding_mode=padding_mode)
         if self.if_norm_image:
             lo = self.min_intensity
             hi = self.max_intensity
@@ -194,6 +206,26 @@ class ComposeAdversarialTransformSolver(object):
         for transform in reversed(chain_of_transforms):
             data = transform.predict_backward(data, interp=interp, padding_mode=padding_mode)
         return data
+
+    def _ride_ok(self, chain):
+        """The validity mask (ones -> forward chain -> backward chain -> != 0, adv_compose_solver.py:262-268) can ride
+        through the warps of the data and of the prediction instead of being warped by four launches of its own: the
+        built-in transforms only (exact types: a subclass may override forward), default interpolation / padding, and loss
+        terms whose gradient w.r.t. the mask is not needed."""
+        return (ops.RIDE_MASK and len(chain) > 0 and all(type(t) in _NATIVE for t in chain)
+                and all(t in ('mse', 'contour') for t in self.divergence_types)
+                and all(t._ride_ok() for t in chain if t.is_geometric()))
+
+    def _predict_backward_with_mask(self, data, chain, init_output):
+        """predict_backward(data) and the validity mask in the same launches (self._ride: the mask after forward())."""
+        ride, self._ride = self._ride, None
+        geo = [t for t in chain if t.is_geometric()]
+        for transform in reversed(chain):
+            if transform.is_geometric():        # (the mask is a second, non-differentiable output of the warp)
+                data, ride = transform.predict_backward(data, _ride=ride, _ride_nonzero=transform is geo[0])
+            else:
+                data = transform.predict_backward(data)
+        return data, ride.expand(init_output.shape)
 
     def loss_fn(self, pred, reference, mask=None):
         """Inconsistency of two predictions in the same coordinates (adv_compose_solver.py:221-234).  Under
@@ -240,14 +272,19 @@ class ComposeAdversarialTransformSolver(object):
         ops.HINT_SLOT = 0           # (kernel-selection hints are kept per position in the call: 0 = the final pass)
         self._shared_fields(chain_of_transforms, True)
         try:
-            adv_data = self.forward(data, chain_of_transforms)
+            geo = self.if_contains_geo_transform(chain_of_transforms)
+            ride = geo and self._ride_ok(chain_of_transforms)
+            adv_data = self.forward(data, chain_of_transforms, _ride=ride)
             old_state = model.training
             model.train()
             with _fix_dropout(model):
                 adv_output = self.get_net_output(model, adv_data.detach().clone())
-            if self.if_contains_geo_transform(chain_of_transforms):
-                mask = self._validity_mask(init_output, chain_of_transforms)
-                warped_back_adv_output = self.predict_backward(adv_output, chain_of_transforms)
+            if geo:
+                if ride:
+                    warped_back_adv_output, mask = self._predict_backward_with_mask(adv_output, chain_of_transforms, init_output)
+                else:
+                    mask = self._validity_mask(init_output, chain_of_transforms)
+                    warped_back_adv_output = self.predict_backward(adv_output, chain_of_transforms)
                 dist = self.loss_fn(pred=warped_back_adv_output, reference=init_output.detach(), mask=mask)
             else:
                 warped_back_adv_output = adv_output
@@ -289,12 +326,18 @@ class ComposeAdversarialTransformSolver(object):
                                                chain_of_transforms=self.chain_of_transforms)
             self._shared_fields(self.chain_of_transforms, True)
             try:
-                augmented_data = self.forward(data.detach())     # (a new tensor object: forward() clears ITS requires_grad flag)
+                geo = self.if_contains_geo_transform(self.chain_of_transforms)
+                ride = geo and self._ride_ok(self.chain_of_transforms)
+                augmented_data = self.forward(data.detach(), _ride=ride)     # (a new tensor object: forward() clears ITS requires_grad flag)
                 with _disable_tracking_bn_stats(model):
                     perturbed_output = self.get_net_output(model, augmented_data)
-                if self.if_contains_geo_transform(self.chain_of_transforms):
-                    warped_back_prediction = self.predict_backward(perturbed_output)
-                    mask = self._validity_mask(init_output, self.chain_of_transforms)
+                if geo:
+                    if ride:
+                        warped_back_prediction, mask = self._predict_backward_with_mask(perturbed_output, self.chain_of_transforms,
+                                                                                        init_output)
+                    else:
+                        warped_back_prediction = self.predict_backward(perturbed_output)
+                        mask = self._validity_mask(init_output, self.chain_of_transforms)
                     dist = self.loss_fn(pred=warped_back_prediction, reference=init_output, mask=mask)
                     if use_anatomy:
                         assert anatomy_mask_images.size() == data.size(), \

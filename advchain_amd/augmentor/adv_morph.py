@@ -231,12 +231,15 @@ class AdvMorph(AdvTransformBase):
         return d.get() if isinstance(d, _LazyDiff) else d
 
     # ------------------------------------------------------------------------------------ warps
-    def transform(self, data, deformation_dxy, interp=None, padding_mode=None, _clamp=False):
-        """Warp with a dense sampling grid (N,d,...) (adv_morph.py:524-558)."""
+    def transform(self, data, deformation_dxy, interp=None, padding_mode=None, _clamp=False, _ride=None, _ride_nonzero=False):
+        """Warp with a dense sampling grid (N,d,...) (adv_morph.py:524-558).  _ride (solver-internal, see _ride_ok): a
+        one-channel tensor warped through the same grid by the same launch -> (out, ride_out)."""
         if padding_mode is None:
             padding_mode = self.image_padding_mode
         if interp is None:
             interp = self.forward_interp
+        if _ride is not None:
+            return ops.grid_sample(data, deformation_dxy, interp, padding_mode, _clamp, ride=_ride, ride_nonzero=_ride_nonzero)
         if padding_mode == "lowest":
             flat = data.reshape(data.size(0), -1)
             self.padding_values = torch.min(flat, dim=1, keepdim=True).values.detach().clone()
@@ -248,34 +251,49 @@ class AdvMorph(AdvTransformBase):
             return out + padding_mode
         return ops.grid_sample(data, deformation_dxy, interp, padding_mode, _clamp)
 
-    def forward(self, data, interp=None, padding_mode=None):
+    def _ride_ok(self, interp=None, padding_mode=None):
+        """Can the solver's validity mask ride along with the data through this transform's warps (one launch for both)?
+        The reference warps the mask by calling forward / backward a second time with the defaults
+        (adv_compose_solver.py:262-268): same field, the transform's own interpolation and padding."""
+        pad = self.image_padding_mode
+        return (interp is None and padding_mode is None and isinstance(pad, str) and pad != 'lowest'
+                and self.forward_interp in ops.RIDE_INTERPS and self.backward_interp in ops.RIDE_INTERPS)
+
+    def forward(self, data, interp=None, padding_mode=None, _ride=None):
         # adv_morph.py:285-311
         if self.param is None:
             self.param = self.init_parameters()
         if interp is None:
             interp = self.forward_interp
         q = self._field(+1.0)
-        out = self.transform(data, q, interp=interp, padding_mode=padding_mode, _clamp=True)
+        out = self.transform(data, q, interp=interp, padding_mode=padding_mode, _clamp=True, _ride=_ride)
+        rout = None
+        if _ride is not None:
+            out, rout = out
         # detached captures: a closure over `out` / `q` themselves would keep the whole DemonsCompose graph (n+1
         # full-resolution fields) alive until the next forward
-        self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): o - d)
+        if _ride is not None:   # (the reference's last forward() of a step is the mask's: adv_compose_solver.py:262-264)
+            self.diff = _LazyDiff(lambda o=rout, d=_ride: o - d)
+        else:
+            self.diff = _LazyDiff(lambda o=out.detach(), d=data.detach(): o - d)
         perm = (0, 2, 3, 1) if self.spatial_dims == 2 else (0, 2, 3, 4, 1)
         self._displacement = _LazyDiff(
             lambda q=q.detach(): torch.clamp(q, -1, 1).permute(*perm) - self.base_grid.permute(*perm))
-        return out
+        return out if _ride is None else (out, rout)
 
-    def backward(self, data, interp=None, padding_mode=None):
+    def backward(self, data, interp=None, padding_mode=None, _ride=None, _ride_nonzero=False):
         # adv_morph.py:313-331
         if interp is None:
             interp = self.backward_interp
         q = self._field(-1.0)
-        return self.transform(data, q, interp=interp, padding_mode=padding_mode, _clamp=True)
+        return self.transform(data, q, interp=interp, padding_mode=padding_mode, _clamp=True, _ride=_ride,
+                              _ride_nonzero=_ride_nonzero)
 
     def predict_forward(self, data, interp=None, padding_mode=None):
         return self.forward(data, interp=interp, padding_mode=padding_mode)
 
-    def predict_backward(self, data, interp=None, padding_mode=None):
-        return self.backward(data, interp=interp, padding_mode=padding_mode)
+    def predict_backward(self, data, interp=None, padding_mode=None, _ride=None, _ride_nonzero=False):
+        return self.backward(data, interp=interp, padding_mode=padding_mode, _ride=_ride, _ride_nonzero=_ride_nonzero)
 
     # ------------------------------------------------------------------------------------ lifecycle
     def train(self):

@@ -191,7 +191,8 @@ __device__ __forceinline__ Taps<DIM, PAD_ZEROS> rebuild_taps(const Theta<DIM>& t
 // ---------------------------------------------------------------------------------------------
 template <int DIM, int TZ>
 __global__ void __launch_bounds__(kBlock, (BoxGeom<DIM, TZ>::WGS))     // as many workgroups a CU as the LDS allows
-k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, int C, Dims d) {
+k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, float* __restrict__ out, int C, Dims d,
+                 const float* __restrict__ ride_in, float* __restrict__ ride_out, int ride_nonzero) {
   using G = BoxGeom<DIM, TZ>;
   constexpr int VPT = G::TX * G::TY * G::TZ / kBlock;
   __shared__ __attribute__((aligned(16))) float box[G::CAP];
@@ -229,6 +230,10 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
   b.x0 = lox; b.ex = hix; b.y0 = loy; b.ey = hiy; b.z0 = loz; b.ez = hiz; b.fits = hix != 0;
   const float* inn = in + (int64_t)n * C * V;
   float* on = out + (int64_t)n * C * V;
+  // the rider (advchain_affine_warp_fwd_ride): channel C of the walk is one channel of another tensor
+  const int CT = ride_out ? C + 1 : C;
+  const float* rin = ride_out ? ride_in + (int64_t)n * V : nullptr;
+  float* ron = ride_out ? ride_out + (int64_t)n * V : nullptr;
   if (!b.fits) {      // block-uniform: direct gathers (the arithmetic of k_affine_warp_fwd); no register array is
 #pragma unroll 1      // indexed by the run-time k here (that would move the arrays to scratch for the fast path too)
     for (int k = 0; k < VPT; ++k) {
@@ -239,13 +244,19 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
       const Taps<DIM, PAD_ZEROS> t = rebuild_taps<DIM>(th, ox, oy, oz, d);
       const int o = (oz * d.s1 + oy) * d.s2 + ox;
       for (int c = 0; c < C; ++c) on[(int64_t)c * V + o] = sample_linear<DIM, PAD_ZEROS>(inn + (int64_t)c * V, t, d);
+      if (ride_out) {
+        const float r = sample_linear<DIM, PAD_ZEROS>(rin, t, d);
+        ron[o] = ride_nonzero ? (r != 0.f ? 1.f : 0.f) : r;
+      }
     }
     return;
   }
   const int sy = b.ex, sz = b.ex * b.ey;
-  for (int c = 0; c < C; ++c) {
+  for (int c = 0; c < CT; ++c) {
     if (c > 0) __syncthreads();            // everyone is done reading the previous channel's box
-    stage_box<DIM, TZ>(inn + (int64_t)c * V, b, d, box);
+    const bool rider = c == C;             // (block-uniform)
+    stage_box<DIM, TZ>(rider ? rin : inn + (int64_t)c * V, b, d, box);
+    float* oc = rider ? ron : on + (int64_t)c * V;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
@@ -264,7 +275,8 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
       int lx, ly, lz;
       local_voxel<DIM>(k, lx, ly, lz);
       const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
-      if (ox < d.s2 && oy < d.s1 && oz < d.s0) on[(int64_t)c * V + (oz * d.s1 + oy) * d.s2 + ox] = acc;
+      if (rider && ride_nonzero) acc = acc != 0.f ? 1.f : 0.f;
+      if (ox < d.s2 && oy < d.s1 && oz < d.s0) oc[(oz * d.s1 + oy) * d.s2 + ox] = acc;
       // two voxels' LDS reads in flight at a time: left alone the scheduler hoists all 8 x 2^d reads (64 live
       // registers on top of the taps) and the kernel no longer fits three workgroups a CU
       if (k & 1) __builtin_amdgcn_sched_barrier(0);
@@ -588,12 +600,12 @@ static const int g_box_tz = 8;   // measured optimum (was a tuning knob until ro
 
 // Returns true when the box kernel took the launch (linear, zeros padding).
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
-                                    hipStream_t st) {
-  if (!box_shape_ok(d, in, out, nullptr)) return false;
+                                    hipStream_t st, const float* ride_in, float* ride_out, int ride_nonzero) {
+  if (!box_shape_ok(d, in, out, ride_in) || (reinterpret_cast<uintptr_t>(ride_out) & 15) != 0) return false;
   dim3 b(kBlock);
-  if (ndim == 3 && g_box_tz == 4) hipLaunchKernelGGL((k_affine_box_fwd<3, 4>), dim3(box_tiles<3, 4>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
-  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_fwd<3, 8>), dim3(box_tiles<3, 8>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
-  else hipLaunchKernelGGL((k_affine_box_fwd<2, 1>), dim3(box_tiles<2, 1>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d);
+  if (ndim == 3 && g_box_tz == 4) hipLaunchKernelGGL((k_affine_box_fwd<3, 4>), dim3(box_tiles<3, 4>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
+  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_fwd<3, 8>), dim3(box_tiles<3, 8>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
+  else hipLaunchKernelGGL((k_affine_box_fwd<2, 1>), dim3(box_tiles<2, 1>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
   return true;
 }
 

@@ -47,7 +47,8 @@ __device__ __forceinline__ int active_count(int64_t v0, int64_t total, int unr) 
 template <int DIM, int INTERP, int PAD, int VEC>
 __global__ void __launch_bounds__(kBlock)
 k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out, int C,
-                  Dims id, Dims od, int clamp_grid) {
+                  Dims id, Dims od, int clamp_grid, const float* __restrict__ ride_in, float* __restrict__ ride_out,
+                  int ride_nonzero) {
   const int64_t IV = id.voxels(), OV = od.voxels();
   const int n = blockIdx.y;
   const int64_t v = (int64_t)blockIdx.x * (kBlock * VEC) + threadIdx.x;
@@ -73,6 +74,15 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
       for (int k = 0; k < VEC; ++k) r[k] = sample_linear<DIM, PAD>(inn + (int64_t)c * IV, t[k], id);
       store_str<VEC>(outn + (int64_t)c * OV, na, r);
     }
+    if (ride_out) {     // the rider: one more channel of another tensor through the same taps (advchain_grid_sample_fwd_ride)
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        r[k] = sample_linear<DIM, PAD>(ride_in + (int64_t)n * IV, t[k], id);
+        if (ride_nonzero) r[k] = r[k] != 0.f ? 1.f : 0.f;
+      }
+      store_str<VEC>(ride_out + (int64_t)n * OV + v, na, r);
+    }
   } else {
     int off[VEC];
     bool ok[VEC];
@@ -91,6 +101,15 @@ k_grid_sample_fwd(const float* __restrict__ in, const float* __restrict__ grid, 
 #pragma unroll
       for (int k = 0; k < VEC; ++k) r[k] = ok[k] ? inn[(int64_t)c * IV + off[k]] : 0.f;
       store_str<VEC>(outn + (int64_t)c * OV, na, r);
+    }
+    if (ride_out) {
+      float r[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        r[k] = ok[k] ? ride_in[(int64_t)n * IV + off[k]] : 0.f;
+        if (ride_nonzero) r[k] = r[k] != 0.f ? 1.f : 0.f;
+      }
+      store_str<VEC>(ride_out + (int64_t)n * OV + v, na, r);
     }
   }
 }
@@ -765,7 +784,8 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
 
 // affine_box.hip: LDS-staged source box (linear, zeros padding, rows of 4k voxels)
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
-                                    hipStream_t st);
+                                    hipStream_t st, const float* ride_in = nullptr, float* ride_out = nullptr,
+                                    int ride_nonzero = 0);
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
                                       int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st);
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
@@ -803,18 +823,19 @@ static inline bool use_unroll(int64_t voxels, int ndim) {
 
 template <int DIM>
 static int launch_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, Dims id, Dims od,
-                                  int interp, int padding, int clamp_grid, hipStream_t st) {
+                                  int interp, int padding, int clamp_grid, hipStream_t st, const float* ride_in = nullptr,
+                                  float* ride_out = nullptr, int ride_nonzero = 0) {
   const int64_t OV = od.voxels();
   const bool vec4 = use_unroll(OV, DIM);
   const int vec = vec4 ? 4 : 1;
   dim3 g(advchain_blocks(OV, kBlock * vec), (unsigned)N), b(kBlock);
   DISPATCH_PAD(padding, {
     if (interp == INTERP_LINEAR) {
-      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
-      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, ride_in, ride_out, ride_nonzero);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_LINEAR, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, ride_in, ride_out, ride_nonzero);
     } else {
-      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
-      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid);
+      if (vec4) hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 4>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, ride_in, ride_out, ride_nonzero);
+      else hipLaunchKernelGGL((k_grid_sample_fwd<DIM, INTERP_NEAREST, PAD, 1>), g, b, 0, st, in, grid, out, (int)C, id, od, clamp_grid, ride_in, ride_out, ride_nonzero);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();
@@ -881,6 +902,8 @@ static void launch_affine_bwd(dim3 g, dim3 b, hipStream_t st, const float* gout,
 
 extern "C" {
 
+int advchain_nonzero_mask(const float* x, float* out, int64_t n, void* stream);   // fields.hip
+
 int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,
                              void* stream) {
@@ -901,6 +924,30 @@ int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int
   }
   return ndim == 3 ? launch_grid_sample_fwd<3>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_fwd<2>(in, grid, out, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
+}
+
+// out = warp(in) and ride_out = warp(ride_in) (one channel) through the same grid.  2D: ONE launch of the direct-gather
+// kernel (the taps of a sample are built once); 3D: the two launches advchain_grid_sample_fwd would make.  Either way
+// every value is what two calls of advchain_grid_sample_fwd return.  flags bit 0: ride_out = (warp(ride_in) != 0).
+int advchain_grid_sample_fwd_ride(const float* in, const float* grid, float* out, const float* ride_in, float* ride_out,
+                                  int64_t N, int64_t C, int ndim, const int64_t* in_dims, const int64_t* out_dims, int interp,
+                                  int padding, int clamp_grid, int flags, void* stream) {
+  ADVCHAIN_CHECK_ARG(ride_in && ride_out && ride_out != out, "grid_sample_fwd_ride: null/aliased rider");
+  ADVCHAIN_CHECK_ARG((flags & ~1) == 0, "grid_sample_fwd_ride: unknown flags");
+  if (ndim == 2 && in && grid && out && dims_ok(ndim, in_dims) && dims_ok(ndim, out_dims, 1) && N > 0 && N < 65536 && C >= 1 &&
+      (interp == INTERP_LINEAR || interp == INTERP_NEAREST) && padding >= 0 && padding <= 2) {
+    const Dims id = make_dims(ndim, in_dims), od = make_dims(ndim, out_dims);
+    ADVCHAIN_CHECK_ARG(id.voxels() < (1ll << 31) && od.voxels() < (1ll << 31), "grid_sample_fwd_ride: per-sample volume too large");
+    return launch_grid_sample_fwd<2>(in, grid, out, N, C, id, od, interp, padding, clamp_grid & 1, (hipStream_t)stream, ride_in,
+                                     ride_out, flags & 1);
+  }
+  int rc = advchain_grid_sample_fwd(in, grid, out, N, C, ndim, in_dims, out_dims, interp, padding, clamp_grid, stream);
+  if (rc != ADVCHAIN_OK) return rc;
+  rc = advchain_grid_sample_fwd(ride_in, grid, ride_out, N, 1, ndim, in_dims, out_dims, interp, padding, clamp_grid, stream);
+  if (rc != ADVCHAIN_OK || !(flags & 1) || N == 0) return rc;
+  int64_t total = N;
+  for (int a = 0; a < ndim; ++a) total *= out_dims[a];
+  return advchain_nonzero_mask(ride_out, ride_out, total, stream);
 }
 
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
@@ -1071,6 +1118,33 @@ int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, in
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
+
+// out = warp(in) and ride_out = warp(ride_in) (one channel) under the same theta.  Linear / zeros on 16-byte rows: ONE
+// launch of the box kernel (taps and box geometry once, the rider is one more channel of the walk); otherwise the two
+// launches advchain_affine_warp_fwd would make.  Every value is what two calls of advchain_affine_warp_fwd return.
+// flags bit 0: ride_out = (warp(ride_in) != 0).
+int advchain_affine_warp_fwd_ride(const float* in, const float* theta, float* out, const float* ride_in, float* ride_out,
+                                  int64_t N, int64_t C, int ndim, const int64_t* dims, int interp, int padding, int flags,
+                                  void* stream) {
+  ADVCHAIN_CHECK_ARG(ride_in && ride_out && ride_out != out, "affine_warp_fwd_ride: null/aliased rider");
+  ADVCHAIN_CHECK_ARG((flags & ~1) == 0, "affine_warp_fwd_ride: unknown flags");
+  if (in && theta && out && dims_ok(ndim, dims) && N > 0 && N < 65536 && C >= 1 && interp == INTERP_LINEAR && padding == PAD_ZEROS) {
+    const Dims d = make_dims(ndim, dims);
+    if (d.voxels() < (1ll << 31) &&
+        advchain_affine_box_fwd_launch(in, theta, out, N, C, ndim, d, (hipStream_t)stream, ride_in, ride_out, flags & 1)) {
+      ADVCHAIN_LAUNCH_CHECK();
+      return ADVCHAIN_OK;
+    }
+  }
+  int rc = advchain_affine_warp_fwd(in, theta, out, N, C, ndim, dims, interp, padding, stream);
+  if (rc != ADVCHAIN_OK) return rc;
+  rc = advchain_affine_warp_fwd(ride_in, theta, ride_out, N, 1, ndim, dims, interp, padding, stream);
+  if (rc != ADVCHAIN_OK || !(flags & 1) || N == 0) return rc;
+  int64_t total = N;
+  for (int a = 0; a < ndim; ++a) total *= dims[a];
+  return advchain_nonzero_mask(ride_out, ride_out, total, stream);
+}
+
 
 // ---- the whole scaling-and-squaring chain in one call (the same launches as n calls of the two entries above; the host
 // side of a solver step is as long as its GPU side, and a chain is 2 x n of its ~700 launches)

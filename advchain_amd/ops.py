@@ -149,12 +149,28 @@ def raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, disp_hint=None):
     return out
 
 
+def raw_grid_sample_fwd_ride(inp, grid, ride, interp, padding, clamp_grid, nonzero, disp_hint=None):
+    """raw_grid_sample_fwd for `inp` and a one-channel rider through the same grid (one launch in 2D)."""
+    N, C = inp.shape[:2]
+    nd = inp.dim() - 2
+    odims = tuple(grid.shape[2:])
+    out = torch.empty((N, C) + odims, device=inp.device, dtype=torch.float32)
+    rout = torch.empty((N, 1) + odims, device=inp.device, dtype=torch.float32)
+    _lib.check(_lib.load().advchain_grid_sample_fwd_ride(_ptr(inp), _ptr(grid), _ptr(out), _ptr(ride), _ptr(rout), N, C, nd,
+                                                         _lib.dims_array(inp.shape[2:]), _lib.dims_array(odims), interp, padding,
+                                                         int(clamp_grid) | _hint_bits(disp_hint), int(bool(nonzero)), _stream()),
+               "grid_sample_fwd_ride")
+    return out, rout
+
+
 DISP_SLOTS = 4096     # ADVCHAIN_DISP_SLOTS of include/advchain_hip.h
 ADAPTIVE_HALO = os.environ.get("ADVCHAIN_NO_ADAPTIVE_HALO") is None   # measure the displacement in forward and size the backward halos from it
 PAIR_FIELDS = os.environ.get("ADVCHAIN_NO_PAIR_FIELDS") is None       # a solver step integrates field(+v) and field(-v) as one batch
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 FUSED_LOSS = True     # the consistency loss straight from the logits (no P / D intermediates); False: A/B tests
 FUSE_2D = True        # the leading sub-pixel squarings of a 2D chain in one launch (expo_fused2d.hip); False: A/B tests
+RIDE_MASK = True      # the solver's validity mask rides through the data's warps (one launch for both); False: A/B tests
+RIDE_INTERPS = ("bilinear", "trilinear", "linear", "nearest")
 
 
 def _scatter_workspace(N, dims, device):
@@ -545,29 +561,36 @@ def warp_halo(entry, d):
 
 class _GridSample(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, grid, interp, padding, clamp_grid, disp, hint=None):
+    def forward(ctx, inp, grid, interp, padding, clamp_grid, disp, hint=None, ride=None, ride_nonzero=False):
         inp, grid = _dev(inp, "input"), _dev(grid, "grid")
         ctx.save_for_backward(inp, grid)
         ctx.cfg = (interp, padding, clamp_grid)
         ctx.disp = disp
-        return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, hint)
+        if ride is None:
+            return raw_grid_sample_fwd(inp, grid, interp, padding, clamp_grid, hint)
+        # a one-channel rider (the solver's validity mask) through the same grid: second output, no gradient
+        out, rout = raw_grid_sample_fwd_ride(inp, grid, _dev(ride, "rider"), interp, padding, clamp_grid, ride_nonzero, hint)
+        ctx.mark_non_differentiable(rout)
+        return out, rout
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _grider=None):
         inp, grid = ctx.saved_tensors
         interp, padding, clamp_grid = ctx.cfg
         need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_in or need_grid):
-            return None, None, None, None, None, None, None
+            return (None,) * 9
         halo = warp_halo(ctx.disp, inp.dim() - 2) if (ctx.disp is not None and need_in) else 0
         gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid,
                                          halo)
-        return gin, ggrid, None, None, None, None, None
+        return (gin, ggrid) + (None,) * 7
 
 
 @_on_tensor_device
-def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
-    """F.grid_sample(inp, grid^T, mode, padding_mode, align_corners=True) with a PLANAR grid (N,d,...)."""
+def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False, ride=None, ride_nonzero=False):
+    """F.grid_sample(inp, grid^T, mode, padding_mode, align_corners=True) with a PLANAR grid (N,d,...).
+    ride: a one-channel tensor (N,1,...) warped through the same grid in the same call (linear / nearest only) -> returns
+    (out, ride_out); ride_out carries no gradient; ride_nonzero: ride_out = (warp(ride) != 0) as 0 / 1."""
     code = interp_code(interp)
     nd = inp.dim() - 2
     if nd not in (2, 3) or grid.dim() != inp.dim() or grid.shape[1] != nd:
@@ -580,12 +603,20 @@ def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=F
     if code == 2:
         if nd != 2:      # F.grid_sample's own message for 5-D input
             raise RuntimeError("grid_sampler(): bicubic interpolation only supports 4D input")
+        if ride is not None:
+            raise NotImplementedError("grid_sample(): no rider with bicubic interpolation")
         return _GridSampleBicubic.apply(inp, torch.clamp(grid, -1, 1) if clamp_grid else grid, pad_code(padding_mode))
     disp = None
     if (ADAPTIVE_HALO and code == 0 and torch.is_grad_enabled() and inp.requires_grad and grid.is_cuda
             and inp.shape[2:] == grid.shape[2:] and grid.dtype == torch.float32 and grid.is_contiguous()):
         disp = grid_displacement(grid)       # the backward sizes its halo / picks the gather form from it
     hint = forward_hint(grid) if (code == 0 and nd == 3 and grid.is_cuda) else None
+    if ride is not None:
+        if tuple(ride.shape) != (inp.shape[0], 1) + tuple(inp.shape[2:]):
+            raise RuntimeError("grid_sample(): the rider must be (N, 1, ...) of the input's size, got %s" % (tuple(ride.shape),))
+        _same_device(inp, ride)
+        return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp, hint, ride.detach(),
+                                 bool(ride_nonzero))
     return _GridSample.apply(inp, grid, code, pad_code(padding_mode), bool(clamp_grid), disp, hint)
 
 
@@ -649,25 +680,33 @@ class _AffineGrid2D(torch.autograd.Function):
 
 class _AffineWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inp, theta, interp, padding):
+    def forward(ctx, inp, theta, interp, padding, ride=None, ride_nonzero=False):
         inp, theta = _dev(inp, "input"), _dev(theta, "theta")
         N, C = inp.shape[:2]
         nd = inp.dim() - 2
         out = torch.empty_like(inp)
+        ctx.save_for_backward(inp, theta)
+        ctx.cfg = (interp, padding)
+        if ride is not None:     # a one-channel rider (the solver's validity mask) under the same theta: no gradient
+            ride = _dev(ride, "rider")
+            rout = torch.empty_like(ride)
+            _lib.check(_lib.load().advchain_affine_warp_fwd_ride(_ptr(inp), _ptr(theta), _ptr(out), _ptr(ride), _ptr(rout), N, C,
+                                                                 nd, _lib.dims_array(inp.shape[2:]), interp, padding,
+                                                                 int(bool(ride_nonzero)), _stream()), "affine_warp_fwd_ride")
+            ctx.mark_non_differentiable(rout)
+            return out, rout
         _lib.check(_lib.load().advchain_affine_warp_fwd(_ptr(inp), _ptr(theta), _ptr(out), N, C, nd,
                                                         _lib.dims_array(inp.shape[2:]), interp, padding, _stream()),
                    "affine_warp_fwd")
-        ctx.save_for_backward(inp, theta)
-        ctx.cfg = (interp, padding)
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _grider=None):
         inp, theta = ctx.saved_tensors
         interp, padding = ctx.cfg
         need_in, need_th = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         if not (need_in or need_th):
-            return None, None, None, None
+            return (None,) * 6
         lib = _lib.load()
         N, C = inp.shape[:2]
         nd = inp.dim() - 2
@@ -678,12 +717,13 @@ class _AffineWarp(torch.autograd.Function):
                          dtype=torch.float32)
         _lib.check(lib.advchain_affine_warp_bwd(_ptr(_dev(gout, "grad")), _ptr(inp), _ptr(theta), _ptr(gin), _ptr(gth),
                                                 _ptr(ws), N, C, nd, dims, interp, padding, _stream()), "affine_warp_bwd")
-        return gin, gth, None, None
+        return gin, gth, None, None, None, None
 
 
 @_on_tensor_device
-def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
-    """F.grid_sample(inp, F.affine_grid(theta, inp.size(), align_corners=True), ..., align_corners=True)."""
+def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros", ride=None, ride_nonzero=False):
+    """F.grid_sample(inp, F.affine_grid(theta, inp.size(), align_corners=True), ..., align_corners=True).
+    ride / ride_nonzero: as for grid_sample -> returns (out, ride_out)."""
     nd = inp.dim() - 2
     if tuple(theta.shape) != (inp.shape[0], nd, nd + 1):
         raise RuntimeError("Expected a batch of %dD affine matrices of shape Nx%dx%d for size %s. Got %s."
@@ -693,8 +733,15 @@ def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
     if code == 2:
         if nd != 2:
             raise RuntimeError("grid_sampler(): bicubic interpolation only supports 4D input")
+        if ride is not None:
+            raise NotImplementedError("affine_warp(): no rider with bicubic interpolation")
         grid = _AffineGrid2D.apply(theta, int(inp.shape[2]), int(inp.shape[3]))
         return _GridSampleBicubic.apply(inp, grid, pad_code(padding_mode))
+    if ride is not None:
+        if tuple(ride.shape) != (inp.shape[0], 1) + tuple(inp.shape[2:]):
+            raise RuntimeError("affine_warp(): the rider must be (N, 1, ...) of the input's size, got %s" % (tuple(ride.shape),))
+        _same_device(inp, ride)
+        return _AffineWarp.apply(inp, theta, code, pad_code(padding_mode), ride.detach(), bool(ride_nonzero))
     return _AffineWarp.apply(inp, theta, code, pad_code(padding_mode))
 
 

@@ -126,6 +126,12 @@ def algorithmic_bytes(name, a):
     if name == "advchain_grid_sample_fwd":
         N, C, nd = a[3], a[4], a[5]
         return 4 * N * (C * _prod(_arr(a[6], nd)) + (C + nd) * _prod(_arr(a[7], nd)))
+    if name == "advchain_grid_sample_fwd_ride":              # + one rider channel in and out
+        N, C, nd = a[5], a[6], a[7]
+        return 4 * N * ((C + 1) * _prod(_arr(a[8], nd)) + (C + 1 + nd) * _prod(_arr(a[9], nd)))
+    if name == "advchain_affine_warp_fwd_ride":
+        N, C, nd = a[5], a[6], a[7]
+        return 8 * N * (C + 1) * _prod(_arr(a[8], nd))
     if name == "advchain_grid_sample_bwd":
         N, C, nd = a[6], a[7], a[8]
         IV, OV = _prod(_arr(a[9], nd)), _prod(_arr(a[10], nd))

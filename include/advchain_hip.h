@@ -55,6 +55,17 @@ const char* advchain_last_error(void);
 int advchain_grid_sample_fwd(const float* in, const float* grid, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding,
                              int clamp_grid, void* stream);
+/* The call above for two tensors through ONE grid: out = warp(in) (C channels) and ride_out = warp(ride_in) (one channel,
+ * (N,1,in_dims) -> (N,1,out_dims)).
+ * replaces: the pair of F.grid_sample calls the reference's solver makes with one deformation -- the data warp
+ *           (adv_compose_solver.py:148-176 forward / 199-219 backward -> adv_morph.py:546-557) and the warp of the all-ones
+ *           validity mask through the same transform (adv_compose_solver.py:262-268, 321-325).  2D: one launch (the taps of
+ *           a sample are built once); 3D: the two launches of advchain_grid_sample_fwd.  Values are those of two separate
+ *           calls, bit for bit.  flags bit 0: ride_out = (warp(ride_in) != 0) as 0 / 1 (the `masks[masks != 0] = 1` of
+ *           adv_compose_solver.py:266-268 after the last warp of the round trip).                                      */
+int advchain_grid_sample_fwd_ride(const float* in, const float* grid, float* out, const float* ride_in, float* ride_out,
+                                  int64_t N, int64_t C, int ndim, const int64_t* in_dims, const int64_t* out_dims,
+                                  int interp, int padding, int clamp_grid, int flags, void* stream);
 /* replaces: autograd grid_sampler_{2,3}d_backward for the call above.
  * grad_in (N,C,in_dims) and grad_grid (N,ndim,out_dims); either may be NULL.  grad_grid is overwritten.
  * With `workspace` (int32[advchain_scatter_workspace(N,ndim,dims)]) grad_in is simply overwritten: the
@@ -143,6 +154,12 @@ int advchain_slot_rows_max(float* slots, float* out, int64_t rows, int64_t cols,
  *           adv_affine.py:297-313.  theta (N, ndim, ndim+1); the grid is never materialised.    */
 int advchain_affine_warp_fwd(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim,
                              const int64_t* dims, int interp, int padding, void* stream);
+/* advchain_affine_warp_fwd for two tensors under ONE theta: out = warp(in), ride_out = warp(ride_in) (one channel); see
+ * advchain_grid_sample_fwd_ride (adv_affine.py:297-313 called for the data and for the validity mask,
+ * adv_compose_solver.py:262-268).  Linear / zeros / rows of 16 bytes: one launch in 2D and 3D; otherwise two.         */
+int advchain_affine_warp_fwd_ride(const float* in, const float* theta, float* out, const float* ride_in, float* ride_out,
+                                  int64_t N, int64_t C, int ndim, const int64_t* dims, int interp, int padding, int flags,
+                                  void* stream);
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims); /* floats */
 /* grad_in (N,C,dims) and grad_theta (N, ndim, ndim+1) are overwritten; either may be NULL.  grad_theta uses a
  * deterministic two-stage reduction.  grad_in: for linear interpolation with zeros padding it is computed as a

@@ -16,17 +16,26 @@ def _planar_to_last(grid):
     return grid.permute(0, *range(2, 2 + d), 1)
 
 
-def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False):
+def _rider(ride, g, mode, padding_mode, nonzero):
+    with torch.no_grad():
+        r = F.grid_sample(ride, g.detach(), mode=mode, padding_mode=padding_mode, align_corners=True)
+        return (r != 0).to(r.dtype) if nonzero else r
+
+
+def grid_sample(inp, grid, interp="bilinear", padding_mode="zeros", clamp_grid=False, ride=None, ride_nonzero=False):
     if clamp_grid:
         grid = torch.clamp(grid, -1, 1)
     mode = interp if interp in ("nearest", "bicubic") else "bilinear"
-    return F.grid_sample(inp, _planar_to_last(grid), mode=mode, padding_mode=padding_mode, align_corners=True)
+    g = _planar_to_last(grid)
+    out = F.grid_sample(inp, g, mode=mode, padding_mode=padding_mode, align_corners=True)
+    return out if ride is None else (out, _rider(ride, g, mode, padding_mode, ride_nonzero))
 
 
-def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros"):
+def affine_warp(inp, theta, interp="bilinear", padding_mode="zeros", ride=None, ride_nonzero=False):
     mode = interp if interp in ("nearest", "bicubic") else "bilinear"
     g = F.affine_grid(theta, inp.size(), align_corners=True)
-    return F.grid_sample(inp, g, mode=mode, padding_mode=padding_mode, align_corners=True)
+    out = F.grid_sample(inp, g, mode=mode, padding_mode=padding_mode, align_corners=True)
+    return out if ride is None else (out, _rider(ride, g, mode, padding_mode, ride_nonzero))
 
 
 def affine_theta(param, cfg, param_scale, nd):
