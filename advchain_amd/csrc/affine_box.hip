@@ -20,11 +20,10 @@
 
 namespace advchain {
 
-// Tile geometry.  TZ (3D) is a template parameter: 8 planes = 8 voxels a thread, least box inflation, 52 KiB and ~150
-// VGPRs (3 workgroups a CU); 4 planes = 38 KiB, ~100 VGPRs (4 workgroups a CU), 1.4x the staged bytes.
+// Tile geometry.  3D: 8 planes = 8 voxels a thread, least box inflation, 52 KiB and ~150 VGPRs (3 workgroups a CU);
+// 4 planes (38 KiB, ~100 VGPRs, 4 workgroups a CU, 1.4x the staged bytes) measured slower and was removed.
 template <int DIM, int TZ_> struct BoxGeom;
 template <> struct BoxGeom<3, 8> { static constexpr int TX = 16, TY = 16, TZ = 8, CAP = 13312, LPR = 8, WGS = 3; };
-template <> struct BoxGeom<3, 4> { static constexpr int TX = 16, TY = 16, TZ = 4, CAP = 9728, LPR = 8, WGS = 4; };
 template <> struct BoxGeom<2, 1> { static constexpr int TX = 32, TY = 32, TZ = 1, CAP = 4096, LPR = 16, WGS = 4; };   // 16 KiB
 
 template <int DIM, int TZ>
@@ -112,9 +111,19 @@ __device__ __forceinline__ BoxDesc reduce_box(int lox, int hix, int loy, int hiy
 }
 
 // Stage the box of one channel: rows of ex / 4 float4s, LPR lanes a row, loads unconditional from clamped addresses and
-// zeroed by selects on the way to LDS (a conditional load is a serial load: DESIGN lessons 15, 20).
-template <int DIM, int TZ>
-__device__ __forceinline__ void stage_box(const float* __restrict__ src, const BoxDesc& b, const Dims& d, float* box) {
+// zeroed by selects on the way to LDS (a conditional load is a serial load: DESIGN lessons 15, 20).  In two halves, so that
+// the loads of the NEXT channel's box are in flight under the arithmetic of the current one (a workgroup is two or three
+// to a CU here: nobody else hides the round trip): box_request() asks for the first NP passes of U rows into registers,
+// box_commit() writes them to LDS and stages whatever the box has beyond them the plain way.
+constexpr int kBoxU = 4;     // 16-byte loads in flight per lane and pass
+template <int NP>
+struct BoxRegs {
+  float4 v[NP][kBoxU];
+  unsigned in;               // bit (p * kBoxU + u): the row lies inside the volume
+};
+
+template <int DIM, int TZ, int NP>
+__device__ __forceinline__ void box_request(const float* __restrict__ src, const BoxDesc& b, const Dims& d, BoxRegs<NP>& pf) {
   using G = BoxGeom<DIM, TZ>;
   constexpr int RPP = kBlock / G::LPR;               // rows per pass
   const int qx = threadIdx.x % G::LPR;
@@ -123,14 +132,51 @@ __device__ __forceinline__ void stage_box(const float* __restrict__ src, const B
   const int gx = b.x0 + 4 * qx;
   const bool xin = gx >= 0 && gx + 4 <= d.s2;
   const int cx = min(max(gx, 0), d.s2 - 4);
-  const bool lane_on = 4 * qx < b.ex;
   const float inv_ey = 1.f / (float)b.ey;
-  constexpr int U = 4;     // 8 x 16 bytes in flight per lane: a box is 9-15 row passes, i.e. two memory round trips per channel
-  for (int rb = r0; rb < rows; rb += RPP * U) {
-    float4 v[U];
-    bool in[U];
+  pf.in = 0u;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int u = 0; u < kBoxU; ++u) {
+      const int r = min(r0 + (p * kBoxU + u) * RPP, rows - 1);
+      const int rz = DIM == 3 ? (int)(((float)r + 0.5f) * inv_ey) : 0;
+      const int ry = r - rz * b.ey;
+      const int gy = b.y0 + ry, gz = b.z0 + rz;
+      if (xin && gy >= 0 && gy < d.s1 && gz >= 0 && gz < d.s0) pf.in |= 1u << (p * kBoxU + u);
+      const int cy = min(max(gy, 0), d.s1 - 1), cz = min(max(gz, 0), d.s0 - 1);
+      pf.v[p][u] = *reinterpret_cast<const float4*>(src + ((int64_t)cz * d.s1 + cy) * d.s2 + cx);
+    }
+}
+
+template <int DIM, int TZ, int NP>
+__device__ __forceinline__ void box_commit(const float* __restrict__ src, const BoxDesc& b, const Dims& d, float* box,
+                                           const BoxRegs<NP>& pf) {
+  using G = BoxGeom<DIM, TZ>;
+  constexpr int RPP = kBlock / G::LPR;
+  const int qx = threadIdx.x % G::LPR;
+  const int r0 = threadIdx.x / G::LPR;
+  const int rows = b.ey * b.ez;
+  const bool lane_on = 4 * qx < b.ex;
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int u = 0; u < kBoxU; ++u) {
+      const int r = r0 + (p * kBoxU + u) * RPP;
+      const bool in = (pf.in >> (p * kBoxU + u)) & 1u;
+      const float4 v = pf.v[p][u];
+      if (lane_on && r < rows)     // component selects (a select between two float4 OBJECTS goes through scratch memory)
+        *reinterpret_cast<float4*>(box + r * b.ex + 4 * qx) = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+    }
+  // ---- rows beyond the requested passes (large boxes: strong rotation / minification)
+  const int gx = b.x0 + 4 * qx;
+  const bool xin = gx >= 0 && gx + 4 <= d.s2;
+  const int cx = min(max(gx, 0), d.s2 - 4);
+  const float inv_ey = 1.f / (float)b.ey;
+  for (int rb = r0 + NP * kBoxU * RPP; rb < rows; rb += RPP * kBoxU) {
+    float4 v[kBoxU];
+    bool in[kBoxU];
+#pragma unroll
+    for (int u = 0; u < kBoxU; ++u) {
       const int r = min(rb + u * RPP, rows - 1);
       const int rz = DIM == 3 ? (int)(((float)r + 0.5f) * inv_ey) : 0;
       const int ry = r - rz * b.ey;
@@ -140,9 +186,9 @@ __device__ __forceinline__ void stage_box(const float* __restrict__ src, const B
       v[u] = *reinterpret_cast<const float4*>(src + ((int64_t)cz * d.s1 + cy) * d.s2 + cx);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < kBoxU; ++u) {
       const int r = rb + u * RPP;
-      if (lane_on && r < rows)     // component selects (a select between two float4 OBJECTS goes through scratch memory)
+      if (lane_on && r < rows)
         *reinterpret_cast<float4*>(box + r * b.ex + 4 * qx) =
             make_float4(in[u] ? v[u].x : 0.f, in[u] ? v[u].y : 0.f, in[u] ? v[u].z : 0.f, in[u] ? v[u].w : 0.f);
     }
@@ -252,12 +298,17 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
     return;
   }
   const int sy = b.ex, sz = b.ex * b.ey;
+  constexpr int NP = 1;                    // passes of the next box held in registers (two would cost the third workgroup a CU)
+  auto chan = [&](int c) { return c == C ? rin : inn + (int64_t)c * V; };     // (block-uniform)
+  BoxRegs<NP> pf;
+  box_request<DIM, TZ, NP>(chan(0), b, d, pf);
   for (int c = 0; c < CT; ++c) {
     if (c > 0) __syncthreads();            // everyone is done reading the previous channel's box
-    const bool rider = c == C;             // (block-uniform)
-    stage_box<DIM, TZ>(rider ? rin : inn + (int64_t)c * V, b, d, box);
+    const bool rider = c == C;
+    box_commit<DIM, TZ, NP>(chan(c), b, d, box, pf);
     float* oc = rider ? ron : on + (int64_t)c * V;
     __syncthreads();
+    if (c + 1 < CT) box_request<DIM, TZ, NP>(chan(c + 1), b, d, pf);   // in flight under this channel's lerps
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
       const float* p = box + cell[k];
@@ -288,9 +339,9 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
 // theta gradient: gtheta_partial (N, gridDim.x, DIM*(DIM+1)) block partial sums (k_reduce_partials of sampler.hip)
 // ---------------------------------------------------------------------------------------------
 template <int DIM, int TZ>
-__global__ void __launch_bounds__(kBlock, (BoxGeom<DIM, TZ>::WGS - (DIM == 3 ? 1 : 0)))
+__global__ void __launch_bounds__(kBlock, (DIM == 3 ? 2 : 4))   // (2D at 3 waves a SIMD, no spills: 27.7 against 25.8 us)
 k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
-                    float* __restrict__ gtheta_partial, int C, Dims d) {
+                    float* __restrict__ gtheta_partial, int C, Dims d, float* __restrict__ tilemax) {
   using G = BoxGeom<DIM, TZ>;
   constexpr int VPT = G::TX * G::TY * G::TZ / kBlock;
   constexpr int NT = DIM * (DIM + 1);
@@ -331,6 +382,7 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
   float acc[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) acc[q] = 0.f;
+  float gm = 0.f;     // max |grad_out| over the tile: the fixed-point scale of k_affine_box_gin (tilemax); inf stays, NaN drops
   // d loss / d theta[r][c] += (d loss / d grid_r of this voxel) * base_c ; zeros padding: d(unnormalised coordinate) /
   // d(grid value) = (S - 1) / 2 everywhere
   auto add_theta = [&](int ox, int oy, int oz, float sx, float sy_, float sz_) {
@@ -356,8 +408,11 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
       const Taps<DIM, PAD_ZEROS> t = rebuild_taps<DIM>(th, ox, oy, oz, d);
       const int o = (oz * d.s1 + oy) * d.s2 + ox;
       float sx = 0.f, sy_ = 0.f, sz_ = 0.f;
-      for (int c = 0; c < C; ++c)
-        sample_linear_bwd<DIM, PAD_ZEROS, false, true>(inn + (int64_t)c * V, nullptr, gon[(int64_t)c * V + o], t, d, sx, sy_, sz_);
+      for (int c = 0; c < C; ++c) {
+        const float g = gon[(int64_t)c * V + o];
+        gm = fmaxf(gm, fabsf(g));
+        sample_linear_bwd<DIM, PAD_ZEROS, false, true>(inn + (int64_t)c * V, nullptr, g, t, d, sx, sy_, sz_);
+      }
       add_theta(ox, oy, oz, sx, sy_, sz_);
     }
   } else {
@@ -365,18 +420,31 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
 #pragma unroll
     for (int k = 0; k < VPT; ++k) { ax[k] = 0.f; ay[k] = 0.f; az[k] = 0.f; }
     const int sy = b.ex, sz = b.ex * b.ey;
+    constexpr int NP = DIM == 3 ? 2 : 1;     // (3D: two workgroups a CU whatever it holds; one pass: 75.6 against 72.2 us)
+    BoxRegs<NP> pf;
+    box_request<DIM, TZ, NP>(inn, b, d, pf);
     for (int c = 0; c < C; ++c) {
+      // this channel's grad_out of the own voxels: requested before the box, in flight under its two staging round trips
+      float gv[VPT];
+#pragma unroll
+      for (int k = 0; k < VPT; ++k) {
+        int lx, ly, lz;
+        local_voxel<DIM>(k, lx, ly, lz);
+        const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
+        gv[k] = gon[(int64_t)c * V + (min(oz, d.s0 - 1) * d.s1 + min(oy, d.s1 - 1)) * d.s2 + min(ox, d.s2 - 1)];
+      }
       if (c > 0) __syncthreads();
-      stage_box<DIM, TZ>(inn + (int64_t)c * V, b, d, box);
+      box_commit<DIM, TZ, NP>(inn + (int64_t)c * V, b, d, box, pf);
       __syncthreads();
+      if (c + 1 < C) box_request<DIM, TZ, NP>(inn + (int64_t)(c + 1) * V, b, d, pf);   // in flight under this channel's taps
 #pragma unroll
       for (int k = 0; k < VPT; ++k) {
         int lx, ly, lz;
         local_voxel<DIM>(k, lx, ly, lz);
         const int ox = tx0 + lx, oy = ty0 + ly, oz = tz0 + lz;
         const bool ok = ox < d.s2 && oy < d.s1 && oz < d.s0;
-        const float gl = gon[(int64_t)c * V + (min(oz, d.s0 - 1) * d.s1 + min(oy, d.s1 - 1)) * d.s2 + min(ox, d.s2 - 1)];
-        const float g = ok ? gl : 0.f;
+        const float g = ok ? gv[k] : 0.f;
+        gm = fmaxf(gm, fabsf(g));
         const float* p = box + cell[k];
         // d(sample)/d(x, y, z) in difference form: x-lerps a and x-differences dx of the 2^(d-1) corner pairs, then
         // lerps / differences along y and z (~35 VALU operations per voxel and channel; the corner-sum form of
@@ -417,6 +485,15 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
 #pragma unroll
     for (int q = 0; q < NT; ++q) dst[q] = acc[q];
   }
+  if (tilemax) {      // (uniform) indexed by the TILE, not by the block: k_affine_box_gin looks tiles up by position
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      tilemax[(int64_t)n * gridDim.x + xcd_contiguous(blockIdx.x, gridDim.x)] = fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,7 +515,7 @@ constexpr int kGeoFloatsBox = 24;   // = kGeoFloats of sampler.hip
 template <int DIM, int CMAX>
 __global__ void __launch_bounds__(kBlock)
 k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta, const float* __restrict__ geo,
-                 const int* __restrict__ mode, float* __restrict__ gin, int C, Dims d) {
+                 const int* __restrict__ mode, float* __restrict__ gin, int C, Dims d, const float* __restrict__ tilemax) {
   constexpr int TZ = DIM == 3 ? 8 : 1;
   using G = BoxGeom<DIM, TZ>;
   constexpr int TILE = G::TX * G::TY * G::TZ;
@@ -503,7 +580,18 @@ k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta
   // ---- pass 1: max |grad_out| over the box (the fixed-point scale), accumulators to zero
   for (int i = threadIdx.x; i < CMAX * TILE; i += kBlock) acc[i] = 0;
   float m = 0.f;
-  for (int i = threadIdx.x; i < ncell; i += kBlock) {
+  if (tilemax) {      // (uniform) the maxima k_affine_box_gtheta left per output tile: the tiles that cover the box
+    const int T[3] = {G::TX, G::TY, G::TZ};
+    const int ntx = (d.s2 + G::TX - 1) / G::TX, nty = (d.s1 + G::TY - 1) / G::TY;
+    const int t0x = blo[0] / T[0], t0y = blo[1] / T[1], t0z = blo[2] / T[2];
+    const int cx = ncell > 0 ? bhi[0] / T[0] - t0x + 1 : 0, cy = bhi[1] / T[1] - t0y + 1, cz = bhi[2] / T[2] - t0z + 1;
+    const float* tm = tilemax + (int64_t)n * gridDim.x;
+    for (int i = threadIdx.x; i < cx * cy * cz; i += kBlock) {
+      const int iz = i / (cx * cy), r = i - iz * (cx * cy), iy = r / cx, ix = r - iy * cx;
+      m = fmaxf(m, tm[((t0z + iz) * nty + t0y + iy) * ntx + t0x + ix]);
+    }
+  }
+  for (int i = threadIdx.x; i < (tilemax ? 0 : ncell); i += kBlock) {
     int vx, vy, vz;
     cell_voxel(i, vx, vy, vz);
     const int v = (vz * d.s1 + vy) * d.s2 + vx;
@@ -523,49 +611,60 @@ k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta
   const bool finite = gmax < 3.0e38f;
   const float scale = (gmax > 0.f && finite) ? 1073741824.f / (cnt * gmax) : 0.f;
   const float inv = (gmax > 0.f && finite) ? (cnt * gmax) / 1073741824.f : 0.f;
-  // ---- pass 2: deposits
+  // ---- pass 2: deposits.  GU candidates of the box per thread and round, their grad_out requested together.  The loop is
+  // VALU-bound (profiles/r04/sq_issue_summary.txt: 21 % of the wave-cycles at 4 waves a SIMD = the VALU busy 85 % of the
+  // time): a position, three taps and the reach test per CANDIDATE, 2.3x as many as samples at 5 degrees.  Positions
+  // cannot be stepped along a row: every tile must see the same taps for a sample, so each comes from scratch.
   bool bad = false;
-  for (int i = threadIdx.x; i < ncell; i += kBlock) {
-    int vx, vy, vz;
-    cell_voxel(i, vx, vy, vz);
-    const int v = (vz * d.s1 + vy) * d.s2 + vx;
-    float go[CMAX];
+  constexpr int GU = DIM == 3 ? 4 : 2;     // (2 .. 8 measured within 3 %: the loop is VALU-bound, see below)
+  for (int i0 = threadIdx.x; i0 < ncell; i0 += kBlock * GU) {
+    float go[GU][CMAX];
+    int vxs[GU], vys[GU], vzs[GU];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) go[c] = gon[(int64_t)(c < C ? c : 0) * V + v];
-    float bx, by, bz, gx, gy, gz;
-    affine_position_xyz<DIM>(th, vx, vy, vz, d, bx, by, bz, gx, gy, gz);
-    const AxisTap tx = make_tap<PAD_ZEROS>(gx, d.s2), ty = make_tap<PAD_ZEROS>(gy, d.s1);
-    AxisTap tz;
-    if (DIM == 3) tz = make_tap<PAD_ZEROS>(gz, d.s0);
-    else { tz.i0 = 0; tz.w0 = 1.f; tz.w1 = 0.f; }
-    const int px = tx.i0 - ux0, py = ty.i0 - uy0, pz = DIM == 3 ? tz.i0 - uz0 : 0;
-    const bool reach = px >= -1 && px < G::TX && py >= -1 && py < G::TY && (DIM == 2 || (pz >= -1 && pz < G::TZ));
-    if (!reach) continue;
+    for (int u = 0; u < GU; ++u) {
+      cell_voxel(min(i0 + u * kBlock, ncell - 1), vxs[u], vys[u], vzs[u]);
+      const int v = (vzs[u] * d.s1 + vys[u]) * d.s2 + vxs[u];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) bad = bad || (c < C && !(go[c] == go[c]));
-    // (the kernel is bound by this loop -- 2^d corners x C deposits per reaching sample: a row-interval compaction of the
-    // box, which cut the visited cells 2-3x, changed its time by < 10 % and was dropped.)  Per-axis validity and the
-    // scaled x weights once per sample; a corner is one product, a channel one product + convert + LDS add.
-    const float wsx[2] = {tx.w0 * scale, tx.w1 * scale};
-    const bool okx[2] = {(unsigned)px < (unsigned)G::TX, (unsigned)(px + 1) < (unsigned)G::TX};
-    const bool oky[2] = {(unsigned)py < (unsigned)G::TY, (unsigned)(py + 1) < (unsigned)G::TY};
-    const bool okz[2] = {(unsigned)pz < (unsigned)G::TZ, DIM == 3 && (unsigned)(pz + 1) < (unsigned)G::TZ};
-    int* cell0 = acc + (pz * G::TY + py) * G::TX + px;
+      for (int c = 0; c < CMAX; ++c) go[u][c] = gon[(int64_t)(c < C ? c : 0) * V + v];
+    }
 #pragma unroll
-    for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
+    for (int u = 0; u < GU; ++u) {
+      if (i0 + u * kBlock >= ncell) continue;
+      float bx, by, bz, gx, gy, gz;
+      affine_position_xyz<DIM>(th, vxs[u], vys[u], vzs[u], d, bx, by, bz, gx, gy, gz);
+      const AxisTap tx = make_tap<PAD_ZEROS>(gx, d.s2), ty = make_tap<PAD_ZEROS>(gy, d.s1);
+      AxisTap tz;
+      if (DIM == 3) tz = make_tap<PAD_ZEROS>(gz, d.s0);
+      else { tz.i0 = 0; tz.w0 = 1.f; tz.w1 = 0.f; }
+      const int px = tx.i0 - ux0, py = ty.i0 - uy0, pz = DIM == 3 ? tz.i0 - uz0 : 0;
+      const bool reach = px >= -1 && px < G::TX && py >= -1 && py < G::TY && (DIM == 2 || (pz >= -1 && pz < G::TZ));
+      if (!reach) continue;
 #pragma unroll
-      for (int cy = 0; cy < 2; ++cy) {
-        const float wyz = DIM == 3 ? (cy ? ty.w1 : ty.w0) * (cz ? tz.w1 : tz.w0) : (cy ? ty.w1 : ty.w0);
+      for (int c = 0; c < CMAX; ++c) bad = bad || (c < C && !(go[u][c] == go[u][c]));
+      // 2^d corners x C deposits per reaching sample (a row-interval compaction of the box, which cut the visited cells
+      // 2-3x, changed the time by < 10 % and was dropped).  Per-axis validity and the scaled x weights once per sample; a
+      // corner is one product, a channel one product + convert + LDS add.
+      const float wsx[2] = {tx.w0 * scale, tx.w1 * scale};
+      const bool okx[2] = {(unsigned)px < (unsigned)G::TX, (unsigned)(px + 1) < (unsigned)G::TX};
+      const bool oky[2] = {(unsigned)py < (unsigned)G::TY, (unsigned)(py + 1) < (unsigned)G::TY};
+      const bool okz[2] = {(unsigned)pz < (unsigned)G::TZ, DIM == 3 && (unsigned)(pz + 1) < (unsigned)G::TZ};
+      int* cell0 = acc + (pz * G::TY + py) * G::TX + px;
 #pragma unroll
-        for (int cx = 0; cx < 2; ++cx) {
-          if (!(okx[cx] && oky[cy] && okz[cz])) continue;
-          const float ws = wsx[cx] * wyz;
-          int* cell = cell0 + (cz * G::TY + cy) * G::TX + cx;
+      for (int cz = 0; cz < (DIM == 3 ? 2 : 1); ++cz)
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c)
-            if (c < C) atomicAdd(cell + c * TILE, __float2int_rn(ws * go[c]));
+        for (int cy = 0; cy < 2; ++cy) {
+          const float wyz = DIM == 3 ? (cy ? ty.w1 : ty.w0) * (cz ? tz.w1 : tz.w0) : (cy ? ty.w1 : ty.w0);
+#pragma unroll
+          for (int cx = 0; cx < 2; ++cx) {
+            if (!(okx[cx] && oky[cy] && okz[cz])) continue;
+            const float ws = wsx[cx] * wyz;
+            int* cell = cell0 + (cz * G::TY + cy) * G::TX + cx;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+              if (c < C) atomicAdd(cell + c * TILE, __float2int_rn(ws * go[u][c]));
+          }
         }
-      }
+    }
   }
   // non-finite gradients must not come out as finite numbers: the whole tile turns NaN
   const bool poison = __syncthreads_or((int)(bad || !finite)) != 0;
@@ -596,49 +695,49 @@ static inline bool box_shape_ok(const Dims& d, const void* a, const void* b, con
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
-static const int g_box_tz = 8;   // measured optimum (was a tuning knob until round 4): 8 | 4
-
 // Returns true when the box kernel took the launch (linear, zeros padding).
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
                                     hipStream_t st, const float* ride_in, float* ride_out, int ride_nonzero) {
   if (!box_shape_ok(d, in, out, ride_in) || (reinterpret_cast<uintptr_t>(ride_out) & 15) != 0) return false;
   dim3 b(kBlock);
-  if (ndim == 3 && g_box_tz == 4) hipLaunchKernelGGL((k_affine_box_fwd<3, 4>), dim3(box_tiles<3, 4>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
-  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_fwd<3, 8>), dim3(box_tiles<3, 8>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
+  if (ndim == 3) hipLaunchKernelGGL((k_affine_box_fwd<3, 8>), dim3(box_tiles<3, 8>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
   else hipLaunchKernelGGL((k_affine_box_fwd<2, 1>), dim3(box_tiles<2, 1>(d), (unsigned)N), b, 0, st, in, theta, out, (int)C, d, ride_in, ride_out, ride_nonzero);
   return true;
 }
 
+int advchain_affine_box_tiles(int ndim, Dims d) { return ndim == 3 ? box_tiles<3, 8>(d) : box_tiles<2, 1>(d); }
+
 // Block partial sums of grad_theta -> gpart[(n * nblocks + block) * ndim * (ndim + 1)]; returns the number of blocks per
-// sample, 0 when the shape is not taken.
+// sample, 0 when the shape is not taken.  tilemax (optional, N x nblocks floats): max |grad_out| of every output tile, by
+// tile position -- the fixed-point scale of advchain_affine_box_gin_launch when it runs AFTER this launch.
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
-                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st) {
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax) {
   if (!box_shape_ok(d, in, gout, nullptr)) return 0;
-  const bool tz4 = ndim == 3 && g_box_tz == 4;
-  const int nb = ndim == 3 ? (tz4 ? box_tiles<3, 4>(d) : box_tiles<3, 8>(d)) : box_tiles<2, 1>(d);
+  const int nb = ndim == 3 ? box_tiles<3, 8>(d) : box_tiles<2, 1>(d);     // (the tiles of k_affine_box_gin: tilemax)
   if (nb > max_blocks) return 0;
   dim3 b(kBlock), g(nb, (unsigned)N);
-  if (tz4) hipLaunchKernelGGL((k_affine_box_gtheta<3, 4>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
-  else if (ndim == 3) hipLaunchKernelGGL((k_affine_box_gtheta<3, 8>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
-  else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d);
+  if (ndim == 3) hipLaunchKernelGGL((k_affine_box_gtheta<3, 8>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax);
+  else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax);
   return nb;
 }
 
 
 // grad_in through the owner-computes LDS scatter (after k_affine_geometry filled geo / mode); false = shape not taken.
+// tilemax: the per-tile maxima of advchain_affine_box_gtheta_launch on the same grad_out, or nullptr (the kernel then reads
+// its box of grad_out once more for the maximum: 15 of 112 us at 4 x 4 x 128 x 128 x 64).
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
-                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st) {
+                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st, const float* tilemax) {
   static const bool no_gin = getenv("ADVCHAIN_NO_AFFINE_BOX_GIN") != nullptr;   // A/B knob: the lattice gather of sampler.hip
   if (no_gin || g_no_affine_box || C > 4) return false;
   dim3 b(kBlock);
   if (ndim == 3) {
     dim3 g(box_tiles<3, 8>(d), (unsigned)N);
-    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<3, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
-    else hipLaunchKernelGGL((k_affine_box_gin<3, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<3, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d, tilemax);
+    else hipLaunchKernelGGL((k_affine_box_gin<3, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d, tilemax);
   } else {
     dim3 g(box_tiles<2, 1>(d), (unsigned)N);
-    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<2, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
-    else hipLaunchKernelGGL((k_affine_box_gin<2, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d);
+    if (C <= 1) hipLaunchKernelGGL((k_affine_box_gin<2, 1>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d, tilemax);
+    else hipLaunchKernelGGL((k_affine_box_gin<2, 4>), g, b, 0, st, gout, theta, geo, mode, gin, (int)C, d, tilemax);
   }
   return true;
 }

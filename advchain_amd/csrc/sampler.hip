@@ -786,10 +786,11 @@ int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
                                     hipStream_t st, const float* ride_in = nullptr, float* ride_out = nullptr,
                                     int ride_nonzero = 0);
+int advchain_affine_box_tiles(int ndim, Dims d);
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
-                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st);
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax);
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
-                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st);
+                                    int64_t N, int64_t C, int ndim, Dims d, hipStream_t st, const float* tilemax);
 
 // expo_fused2d.hip / adjoint_fused2d.hip: the sub-pixel squarings of a 2D chain in one launch (forward / backward)
 int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, float* disp_rows,
@@ -1254,7 +1255,7 @@ int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const floa
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims) {
   if (!dims_ok(ndim, dims)) return -1;
   const Dims d = make_dims(ndim, dims);
-  return N * (int64_t)affine_grid_blocks(d) * ndim * (ndim + 1) + N * (kGeoFloats + 1);  // floats
+  return N * (int64_t)affine_grid_blocks(d) * ndim * (ndim + 1) + N * (kGeoFloats + 1) + N * (int64_t)advchain_affine_box_tiles(ndim, d);  // floats
 }
 
 int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
@@ -1280,20 +1281,29 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     return ADVCHAIN_OK;
   }
   const int* mode = nullptr;
+  int nbx_theta = -1;     // >= 0: the box kernel was asked for the theta gradient already (0 = it declined the shape)
   static const bool no_gather = getenv("ADVCHAIN_AFFINE_ATOMIC") != nullptr;  // A/B knob
   if (grad_in && workspace && interp == INTERP_LINEAR && padding == PAD_ZEROS && C <= 8 && !no_gather) {
     // gather formulation of grad_in (no atomics); samples it cannot handle are flagged and scattered below
     float* geo = workspace + N * (int64_t)nb * ndim * (ndim + 1);
     int* md = reinterpret_cast<int*>(geo + N * kGeoFloats);
+    // the theta gradient FIRST when it is asked for: its walk over grad_out leaves max |grad_out| per output tile, the
+    // fixed-point scale of the grad_in kernel (which otherwise reads its box of grad_out twice)
+    float* tilemax = nullptr;
+    if (gpart) {
+      float* tm = reinterpret_cast<float*>(md + N);
+      nbx_theta = advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st, tm);
+      if (nbx_theta > 0) tilemax = tm;
+    }
     if (ndim == 3) {
       hipLaunchKernelGGL(k_affine_geometry<3>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
-      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st)) {}
+      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st, tilemax)) {}
       else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<3, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<3, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else hipLaunchKernelGGL((k_affine_gather_bwd<3, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
     } else {
       hipLaunchKernelGGL(k_affine_geometry<2>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
-      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st)) {}
+      if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st, tilemax)) {}
       else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<2, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<2, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else hipLaunchKernelGGL((k_affine_gather_bwd<2, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
@@ -1306,7 +1316,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
   if (gpart && interp == INTERP_LINEAR && padding == PAD_ZEROS && (!grad_in || mode)) {
     // theta gradient through the LDS-staged source box; grad_in (when asked for) comes from the lattice gather above,
     // and only the samples it flagged still need the scatter kernel -- without its theta part
-    const int nbx = advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st);
+    const int nbx = nbx_theta >= 0 ? nbx_theta : advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st, nullptr);
     if (nbx > 0) { nb_theta = nbx; gpart = nullptr; }
   }
   if (gpart || grad_in)

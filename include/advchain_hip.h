@@ -162,9 +162,11 @@ int advchain_affine_warp_fwd_ride(const float* in, const float* theta, float* ou
                                   void* stream);
 int64_t advchain_affine_warp_bwd_workspace(int64_t N, int ndim, const int64_t* dims); /* floats */
 /* grad_in (N,C,dims) and grad_theta (N, ndim, ndim+1) are overwritten; either may be NULL.  grad_theta uses a
- * deterministic two-stage reduction.  grad_in: for linear interpolation with zeros padding it is computed as a
- * GATHER over the affine lattice (no atomics, deterministic); otherwise it is zero-filled here and scattered
- * with atomics.  `workspace` (advchain_affine_warp_bwd_workspace floats) is always required.                */
+ * deterministic two-stage reduction.  grad_in: for linear interpolation with zeros padding and C <= 4 it is an
+ * owner-computes scatter into LDS fixed-point accumulators (no global atomics, deterministic; scaled by the largest
+ * |grad_out| around the tile -- taken from the theta-gradient walk, which runs first when both are asked for), for
+ * C <= 8 a gather over the affine lattice; otherwise it is zero-filled here and scattered with atomics.
+ * `workspace` (advchain_affine_warp_bwd_workspace floats) is always required.                                   */
 int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float* theta, float* grad_in,
                              float* grad_theta, float* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* dims, int interp, int padding, void* stream);
