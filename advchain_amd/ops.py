@@ -571,6 +571,7 @@ class _GridSample(torch.autograd.Function):
         # a one-channel rider (the solver's validity mask) through the same grid: second output, no gradient
         out, rout = raw_grid_sample_fwd_ride(inp, grid, _dev(ride, "rider"), interp, padding, clamp_grid, ride_nonzero, hint)
         ctx.mark_non_differentiable(rout)
+        ctx.set_materialize_grads(False)     # (or the engine fills a zero gradient for the rider on every backward)
         return out, rout
 
     @staticmethod
@@ -578,7 +579,7 @@ class _GridSample(torch.autograd.Function):
         inp, grid = ctx.saved_tensors
         interp, padding, clamp_grid = ctx.cfg
         need_in, need_grid = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if not (need_in or need_grid):
+        if gout is None or not (need_in or need_grid):
             return (None,) * 9
         halo = warp_halo(ctx.disp, inp.dim() - 2) if (ctx.disp is not None and need_in) else 0
         gin, ggrid = raw_grid_sample_bwd(_dev(gout, "grad"), inp, grid, interp, padding, clamp_grid, need_in, need_grid,
@@ -694,6 +695,7 @@ class _AffineWarp(torch.autograd.Function):
                                                                  nd, _lib.dims_array(inp.shape[2:]), interp, padding,
                                                                  int(bool(ride_nonzero)), _stream()), "affine_warp_fwd_ride")
             ctx.mark_non_differentiable(rout)
+            ctx.set_materialize_grads(False)     # (or the engine fills a zero gradient for the rider on every backward)
             return out, rout
         _lib.check(_lib.load().advchain_affine_warp_fwd(_ptr(inp), _ptr(theta), _ptr(out), N, C, nd,
                                                         _lib.dims_array(inp.shape[2:]), interp, padding, _stream()),
@@ -705,7 +707,7 @@ class _AffineWarp(torch.autograd.Function):
         inp, theta = ctx.saved_tensors
         interp, padding = ctx.cfg
         need_in, need_th = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if not (need_in or need_th):
+        if gout is None or not (need_in or need_th):
             return (None,) * 6
         lib = _lib.load()
         N, C = inp.shape[:2]
