@@ -419,6 +419,72 @@ k_band_reduce_axis(const float* __restrict__ in, const float* __restrict__ in2, 
   out[t] = acc * scale;
 }
 
+// Outer-axis variant through an LDS slab (inner % 4 == 0): a workgroup takes one `o` and a chunk of IC inner columns,
+// requests its (S x IC) slab with 16-byte loads BEFORE it densifies the band table (the table walk is three dependent
+// global loads; the per-thread kernel above then walks its band with one dependent strided load per tap -- 16 us for a
+// 2 MB input at cfg-2, 128 workgroups).  Same sums in the same order as k_band_reduce_axis.
+constexpr int kBrSlabFloats = 12288;      // 48 KiB
+__global__ void __launch_bounds__(kBlock)
+k_band_reduce_axis_slab(const float* __restrict__ in, const float* __restrict__ in2, float* __restrict__ out, int inner, int IC,
+                        BandAxis A, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];      // [S][IC + 1]
+  __shared__ float Wd[kBrMaxW];
+  __shared__ int lo_s[64];
+  const int64_t o = blockIdx.x;
+  const int c0 = blockIdx.y * IC, cols = min(IC, inner - c0);
+  const int q = cols >> 2, n4 = A.S * q, pitch = IC + 1;
+  const float* p = in + o * (int64_t)A.S * inner + c0;
+  const float* p2 = in2 ? in2 + o * (int64_t)A.S * inner + c0 : nullptr;
+  constexpr int U = 4;
+  float4 v[U];
+  auto fetch = [&](int idx) -> float4 {
+    const int e = min(idx, n4 - 1);
+    const int sr = e / q, x4 = e - sr * q;
+    float4 a = *reinterpret_cast<const float4*>(p + (int64_t)sr * inner + 4 * x4);
+    if (p2) {
+      const float4 b = *reinterpret_cast<const float4*>(p2 + (int64_t)sr * inner + 4 * x4);
+      a.x -= b.x; a.y -= b.y; a.z -= b.z; a.w -= b.w;
+    }
+    return a;
+  };
+  auto put = [&](int idx, const float4& a) {
+    if (idx >= n4) return;
+    const int sr = idx / q, x4 = idx - sr * q;
+    float* dst = slab + sr * pitch + 4 * x4;
+    dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = fetch(threadIdx.x + u * kBlock);
+  const int WB = stage_band(A, Wd, lo_s);       // (ends with a barrier)
+#pragma unroll
+  for (int u = 0; u < U; ++u) put(threadIdx.x + u * kBlock, v[u]);
+  for (int i0 = threadIdx.x + U * kBlock; i0 < n4; i0 += U * kBlock) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = fetch(i0 + u * kBlock);
+#pragma unroll
+    for (int u = 0; u < U; ++u) put(i0 + u * kBlock, v[u]);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < A.g * cols; t += kBlock) {
+    const int k = t / cols, i = t - k * cols;
+    float acc = 0.f;
+    if (WB > 0) {
+      const int lo = lo_s[k];
+      const int len = min(WB, A.S - lo);
+      const float* w = Wd + k * WB;
+      const float* x = slab + lo * pitch + i;
+      for (int j = 0; j < len; ++j) acc = fmaf(x[j * pitch], w[j], acc);
+    } else {
+      const int lo = A.lo[k], hi = A.hi[k];
+      for (int sr = lo; sr < hi; ++sr) {
+        const int b = k - A.start[sr];
+        if (b >= 0 && b < A.B) acc += slab[sr * pitch + i] * A.w[sr * A.B + b];
+      }
+    }
+    out[(o * A.g + k) * (int64_t)inner + c0 + i] = acc * scale;
+  }
+}
+
 // Innermost-axis variant (inner == 1, S % 4 == 0): the full-resolution pass, which reads the whole gradient once.
 // A wave stages RW consecutive rows in its LDS slab with 16-byte loads (fusing (in - in2)); lane (r, kg) then takes the
 // banded dot products of coefficients kg, kg + KG, kg + 2 KG, ... of row r from LDS.  The band of coefficient k is
@@ -1307,6 +1373,21 @@ int advchain_band_reduce_axis(const float* in, const float* in2, float* out, con
     }
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
+  }
+  static const bool no_slab = getenv("ADVCHAIN_NO_BAND_SLAB") != nullptr;   // A/B knob: one thread per output, taps from global memory
+  // (small problems only -- one thread per output leaves cfg-2's y pass with 128 workgroups walking 40 dependent taps:
+  // 14.4 -> 8.3 us; with 3 k+ workgroups, the 3D passes, the per-thread kernel is 2-4 % faster)
+  if (!no_slab && total <= 131072 && inner > 1 && inner % 4 == 0 && aligned && outer < (1ll << 31) && (int64_t)A.S * 5 <= kBrSlabFloats) {
+    int IC = (int)inner;                       // inner columns per workgroup: the slab S x (IC + 1) within 48 KiB
+    while ((int64_t)A.S * (IC + 1) > kBrSlabFloats) IC = (IC / 2 + 3) / 4 * 4;
+    const int chunks = (int)((inner + IC - 1) / IC);
+    if (chunks <= 65535) {
+      const size_t lds = (size_t)A.S * (IC + 1) * sizeof(float);
+      hipLaunchKernelGGL(k_band_reduce_axis_slab, dim3((unsigned)outer, (unsigned)chunks), dim3(kBlock), lds, (hipStream_t)stream, in, in2,
+                         out, (int)inner, IC, A, scale);
+      ADVCHAIN_LAUNCH_CHECK();
+      return ADVCHAIN_OK;
+    }
   }
   hipLaunchKernelGGL(k_band_reduce_axis, dim3(advchain_blocks(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, in,
                      in2, out, outer, (int)inner, T.a[axis], scale);
