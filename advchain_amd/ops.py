@@ -65,6 +65,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_STREAM_OBJ = {}
+
+
+def _stream_obj():
+    """The current stream of the current device as a torch Stream object (Event.record() without an argument builds one
+    through five Python layers on every call): cached per device, rebuilt when the raw handle has changed."""
+    if _raw_stream is None or _raw_device is None:
+        return torch.cuda.current_stream()
+    dev = _raw_device()
+    s = _STREAM_OBJ.get(dev)
+    if s is None or s.cuda_stream != _raw_stream(dev):
+        s = _STREAM_OBJ[dev] = torch.cuda.current_stream()
+    return s
+
+
 def _dev(t, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.AdvchainHipError("%s must be a CUDA/ROCm tensor: the advchain_amd kernels have no CPU path" % name)
@@ -508,7 +523,7 @@ class _Readback:
         self.host = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
         self.host.copy_(dev_tensor, non_blocking=True)
         self.event = torch.cuda.Event()
-        self.event.record()
+        self.event.record(_stream_obj())
         self._vals = None
 
     def values(self):

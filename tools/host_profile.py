@@ -18,8 +18,12 @@ def main():
     ap.add_argument("--workload", default="cfg1")
     ap.add_argument("--calls", type=int, default=50)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--sort", default="tottime")
+    ap.add_argument("--inline-backward", action="store_true", help="run the autograd engine on the calling thread, so that the backward functions are profiled too")
     args = ap.parse_args()
     import bench
+    if args.inline_backward:
+        torch.autograd.set_multithreading_enabled(False)
     wl = dict(bench.WORKLOADS[args.workload])
     dev = torch.device("cuda")
     solver = bench.build_solver(wl, dev)
@@ -37,7 +41,7 @@ def main():
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime")
+    st.sort_stats(args.sort)
     print("per call: %.3f ms host (profiled)" % (st.total_tt / args.calls * 1e3))
     st.print_stats(args.top)
 
