@@ -780,7 +780,8 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
                                    int halo, int32_t* workspace, hipStream_t st);
 int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
-                                   hipStream_t st);
+                                   hipStream_t st, int rm_flags = 0);
+bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H);
 
 // affine_box.hip: LDS-staged source box (linear, zeros padding, rows of 4k voxels)
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
@@ -1031,8 +1032,17 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
   return ADVCHAIN_OK;
 }
 
+static int compose_self_bwd_impl(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
+                                 int halo, int64_t N, int ndim, const int64_t* dims, void* stream, int rm_flags);
+
 int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
                               int halo, int64_t N, int ndim, const int64_t* dims, void* stream) {
+  return compose_self_bwd_impl(grad_out, phi, grad_phi, workspace, chain, halo, N, ndim, dims, stream, 0);
+}
+
+// rm_flags: see advchain_scatter_rows2d_launch (consecutive whole-row launches of a chain hand their row maxima on)
+static int compose_self_bwd_impl(const float* grad_out, const float* phi, float* grad_phi, int32_t* workspace, int chain,
+                                 int halo, int64_t N, int ndim, const int64_t* dims, void* stream, int rm_flags) {
   ADVCHAIN_CHECK_ARG(grad_out && phi && grad_phi, "compose_self_bwd: null pointer");
   ADVCHAIN_CHECK_ARG(dims_ok(ndim, dims), "compose_self_bwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "compose_self_bwd: bad N");
@@ -1043,7 +1053,7 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
   if (workspace) {
     if (ndim == 2 && halo <= -2) {   // exact bound of a few pixels: whole-row owner-computes scatter (scatter_march.hip)
       const int rr = advchain_scatter_rows2d_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, d, PAD_BORDER, 0, -halo,
-                                                    workspace, (hipStream_t)stream);
+                                                    workspace, (hipStream_t)stream, rm_flags);
       if (rr != ADVCHAIN_ERR_UNSUPPORTED) return rr;
     }
     // sub-voxel steps of the squaring chain: gather form (adjoint_gather.hip); otherwise the LDS-tiled scatter
@@ -1219,11 +1229,19 @@ int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const floa
     if (kf < 2) kf = 0;
   }
   const float* g = grad_pos;
+  // 2D: consecutive whole-row scatters hand the row maxima of their output to the next one (its fixed-point scale): no
+  // k_march_rowmax pre-pass between them
+  const Dims dd = make_dims(ndim, dims);
+  static const bool no_handover = getenv("ADVCHAIN_NO_ROWMAX_HANDOVER") != nullptr;   // A/B knob: a k_march_rowmax pre-pass per launch
+  auto rows = [&](int i) {
+    return !no_handover && ndim == 2 && workspace && i >= 0 && i < n - kf && halos[i] <= -2 && advchain_scatter_rows2d_takes(true, 2, dd, PAD_BORDER, -halos[i]);
+  };
   for (int i = 0; i < n - kf; ++i) {                 // squaring m = n-1 .. kf; the last step of the call writes grad_phi0
     const int m = n - 1 - i;
     const float* phi = m == 0 ? phi0 : fields + (int64_t)(m - 1) * F;
     float* out = ((m - kf) % 2 == 0) ? (kf ? scratch : grad_phi0) : (kf ? grad_phi0 : scratch);
-    const int rc = advchain_compose_self_bwd(g, phi, out, workspace, i > 0 ? 1 : 0, halos[i], N, ndim, dims, stream);
+    const int rm = rows(i) ? ((rows(i - 1) ? 1 : 0) | (rows(i + 1) ? 2 : 0) | ((i & 1) ? 4 : 0)) : 0;
+    const int rc = compose_self_bwd_impl(g, phi, out, workspace, i > 0 ? 1 : 0, halos[i], N, ndim, dims, stream, rm);
     if (rc != ADVCHAIN_OK) return rc;
     g = out;
   }

@@ -1035,15 +1035,16 @@ k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__
 // on both axes and need an overflow list; the window scatter pays 1.7 global float atomics per sample and channel).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float rows2d_fix_scale(int H) {   // (2H+2)^2 deposits of weight <= 1 stay below 2^31
-  return H <= 2 ? 33554432.f : (H <= 4 ? 16777216.f : (H <= 8 ? 4194304.f : 1048576.f));
+  return H <= 2 ? 33554432.f : (H <= 4 ? 16777216.f : (H <= 8 ? 4194304.f : (H <= 16 ? 1048576.f : 262144.f)));
 }
 
 template <int PAD, int C, bool SELF, bool GG>
 __global__ void __launch_bounds__(512)
 k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                  float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int TY, int H, int clamp_grid,
-                 int32_t* __restrict__ ws) {
+                 int32_t* __restrict__ ws, const float* __restrict__ rowmax_in, float* __restrict__ rowmax_next) {
   extern __shared__ int acc[];                   // [C][TY][W]
+  __shared__ int rmax[64];                       // max |output| of the owned rows (float bits), for rowmax_next
   constexpr int NWV = 8;
   const int W = d.s2, V = d.s1 * d.s2;
   const int n = blockIdx.y;
@@ -1057,9 +1058,10 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
   const int ya = max(y0 - H, 0), yb = min(y0 + TY + H, d.s1);
   __shared__ float wmax[NWV];
   {
-    const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s1;
+    const float* rowmax = rowmax_in + (int64_t)n * d.s1;
     float m = 0.f;
     for (int y = ya + (int)threadIdx.x; y < yb; y += NWV * 64) m = fmaxf(m, rowmax[y]);
+    if (threadIdx.x < 64) rmax[threadIdx.x] = 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) wmax[wave] = m;
@@ -1147,28 +1149,48 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
     }
   }
   __syncthreads();
-  // ---- every owned output: convert, add / store the coordinate path, plain stores
+  // ---- every owned output: convert, add / store the coordinate path, plain stores.  rowmax_next: the row maxima of what
+  // is written here -- the next squaring's backward reads this tensor as ITS grad_out and would otherwise launch
+  // k_march_rowmax over it first (the values and the non-finite rule of that kernel)
 #pragma unroll
   for (int k = 0; k < MAXO; ++k) {
     const int it = wave + k * NWV;
     if (it >= oitems) continue;                                       // wave-uniform
     const int r = it / nseg;
     const int x = (it - r * nseg) * 64 + lane;
-    if (x >= W) continue;
-    const int s = (y0 + r) * W + x;
+    const bool on = x < W;
+    const int s = (y0 + r) * W + min(x, W - 1);
     float v[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = (float)acc[(c * TY + r) * W + x] * inv;
+    for (int c = 0; c < C; ++c) v[c] = (float)acc[(c * TY + r) * W + min(x, W - 1)] * inv;
     if (SELF) {
 #pragma unroll
       for (int c = 0; c < C; ++c) v[c] += ggv[k][c < 2 ? c : 0];
     } else if (GG) {
       float* gq = ggrid + (int64_t)n * 2 * V + s;
-      gq[0] = ggv[k][0];
-      gq[V] = ggv[k][1];
+      if (on) { gq[0] = ggv[k][0]; gq[V] = ggv[k][1]; }
     }
+    if (on) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
+      for (int c = 0; c < C; ++c) ginn[(int64_t)c * V + s] = v[c];
+    }
+    if (rowmax_next) {                                                // (uniform)
+      float m = 0.f;
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        m = fmaxf(m, on ? fabsf(v[c]) : 0.f);
+        bad = bad || (on && !(fabsf(v[c]) <= 3.0e38f));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      if (__ballot(bad) != 0) m = __int_as_float(0x7f800000);
+      if (lane == 0) atomicMax(&rmax[r], __float_as_int(m));
+    }
+  }
+  if (rowmax_next) {
+    __syncthreads();
+    if ((int)threadIdx.x < yend - y0) rowmax_next[(int64_t)n * d.s1 + y0 + threadIdx.x] = __int_as_float(rmax[threadIdx.x]);
   }
 }
 
@@ -1176,34 +1198,46 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
 
 using namespace advchain;
 
-// 2D, exact bound of H = 2..16 pixels.  ADVCHAIN_ERR_UNSUPPORTED: use the gather form / the window scatter.
-int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
-                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
-                                   hipStream_t st) {
+// The shapes / bounds the whole-row scatter takes; TY = owned rows per workgroup (0: not taken).
+static int rows2d_tile(bool self, int64_t C, const Dims& d, int padding, int H) {
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_ROWS2D") != nullptr;   // A/B knob
   static const int hmin = 3;   // measured optimum (was a tuning knob until round 4)
-  if (off || !workspace || !gin || padding == PAD_REFLECTION || H < hmin || H > 16 || d.s0 != 1) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (d.s2 < 16 || d.s2 > 512 || d.voxels() * 4 >= (1ll << 31)) return ADVCHAIN_ERR_UNSUPPORTED;
-  if (self ? C != 2 : (C != 1 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
-  static const int ty_forced = 0;
+  if (off || padding == PAD_REFLECTION || H < hmin || H > (self ? 32 : 16) || d.s0 != 1) return 0;
+  if (d.s2 < 16 || d.s2 > 512 || d.voxels() * 4 >= (1ll << 31)) return 0;
+  if (self ? C != 2 : (C != 1 && C != 4)) return 0;
   const int nseg = (d.s2 + 63) / 64;
   int TY = H >= 8 ? 32 : 16;
-  if (ty_forced > 0) TY = ty_forced;
   static const size_t lds_cap = 49152;   // measured optimum (was a tuning knob until round 4)
   while (TY > 4 && ((size_t)C * TY * d.s2 * 4 > lds_cap || TY * nseg > 64)) TY >>= 1;   // 48 KiB of cells, 8 own items a wave
+  if ((size_t)C * TY * d.s2 * sizeof(int) > 65536 - 64 || TY * nseg > 64) return 0;
+  return TY;
+}
+bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H) { return rows2d_tile(self, C, d, padding, H) > 0; }
+
+// 2D, exact bound of H = 3..16 pixels (squarings: ..32).  ADVCHAIN_ERR_UNSUPPORTED: use the gather form / the window scatter.
+// rm_flags (the chain's consecutive launches; 0 = a launch on its own): bit 0 = the row maxima of `gout` are already in
+// this launch's buffer (left by the launch that wrote gout) -- no k_march_rowmax pre-pass; bit 1 = leave the row maxima
+// of `gin` for the next launch; bit 2 = which of the two buffers in `workspace` this launch reads (it writes the other).
+int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
+                                   int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
+                                   hipStream_t st, int rm_flags) {
+  const int TY = (workspace && gin) ? rows2d_tile(self, C, d, padding, H) : 0;
+  if (TY == 0) return ADVCHAIN_ERR_UNSUPPORTED;
   const size_t lds = (size_t)C * TY * d.s2 * sizeof(int);
-  if (lds > 65536 - 64 || TY * nseg > 64) return ADVCHAIN_ERR_UNSUPPORTED;
-  {
+  float* rm_a = reinterpret_cast<float*>(workspace + 4);       // (the overflow list of the tiled kernels: unused here)
+  float* rm_b = rm_a + N * d.s1;
+  float* rm_in = (rm_flags & 4) ? rm_b : rm_a;
+  float* rm_next = (rm_flags & 2) ? ((rm_flags & 4) ? rm_a : rm_b) : nullptr;
+  if (!(rm_flags & 1)) {
     dim3 rg((unsigned)((d.s1 + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N);
-    float* rowmax = reinterpret_cast<float*>(workspace + 4);       // the overflow list of the tiled kernels: unused here
-    if (C == 1) hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
-    else if (C == 2) hipLaunchKernelGGL(k_march_rowmax<2>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
-    else hipLaunchKernelGGL(k_march_rowmax<4>, rg, dim3(kBlock), 0, st, gout, rowmax, d, d.s1);
+    if (C == 1) hipLaunchKernelGGL(k_march_rowmax<1>, rg, dim3(kBlock), 0, st, gout, rm_in, d, d.s1);
+    else if (C == 2) hipLaunchKernelGGL(k_march_rowmax<2>, rg, dim3(kBlock), 0, st, gout, rm_in, d, d.s1);
+    else hipLaunchKernelGGL(k_march_rowmax<4>, rg, dim3(kBlock), 0, st, gout, rm_in, d, d.s1);
   }
   dim3 g((unsigned)((d.s1 + TY - 1) / TY), (unsigned)N), b(512);
   const bool gg = ggrid != nullptr;
 #define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_rows2d<PAD_, C_, SELF_, GG_>), g, b, lds, st, gout, in, grid, gin, ggrid, d, TY, H, clamp_grid, workspace)
+  hipLaunchKernelGGL((k_scatter_rows2d<PAD_, C_, SELF_, GG_>), g, b, lds, st, gout, in, grid, gin, ggrid, d, TY, H, clamp_grid, workspace, rm_in, rm_next)
 #define GO_PAD(C_, GG_) do { if (padding == PAD_BORDER) GO(PAD_BORDER, C_, false, GG_); else GO(PAD_ZEROS, C_, false, GG_); } while (0)
   if (self) GO(PAD_BORDER, 2, true, false);
   else if (C == 1) { if (gg) GO_PAD(1, true); else GO_PAD(1, false); }

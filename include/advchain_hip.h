@@ -108,7 +108,7 @@ int advchain_compose_self_fwd(const float* phi, float* out, const float* phi0, i
  * 0 = default scatter tiles (halo 2 in 3D) / window scatter (2D).
  * halo < 0: |halo| is EXACT -- the caller guarantees no sample moves |halo| voxels or more on any axis (measured with
  * advchain_max_displacement / disp_out): the gather form then skips the overflow list and is a single launch; samples
- * violating the guarantee would be dropped.  Exact bounds beyond the gather form (3D: 2..4 voxels; 2D: 4, 8, 16 px; both
+ * violating the guarantee would be dropped.  Exact bounds beyond the gather form (3D: 2..4 voxels; 2D: 4, 8, 16 px, squarings also 32 px; both
  * entries) select the owner-computes scatters of scatter_march.hip: LDS 32-bit fixed-point accumulators scaled by the
  * max|grad_out| over the rows a workgroup visits, plain stores, no zero fill, bit-reproducible, relative error of the
  * accumulation <= 2^-23 / 2^-22 / 2^-21 (bounds of 2 / 3 / 4; 2^-18 for 5..8) of that local maximum per deposit; a NaN / inf in

@@ -123,15 +123,17 @@ def main():
             add("grid_sample bwd C=4 %.1f vox halo=%d (march)" % (amp, hb), lambda big=big, hb=hb: ops.raw_grid_sample_bwd(g4, x4, big, 0, 0, True, True, True, hb), 4 * NV * (12 + 2 * d))
             add("grid_sample bwd C=4 %.1f vox halo=8 (window)" % amp, lambda big=big: ops.raw_grid_sample_bwd(g4, x4, big, 0, 0, True, True, True, 8), 4 * NV * (12 + 2 * d))
     if d == 2:   # fields of 1.5 / 3.5 / 6 px: exact-bound gather form (H = 2, 4) against the window scatter
-        for amp in (1.5, 3.5, 6.0, 12.0):
+        for amp in (1.5, 3.5, 6.0, 12.0, 24.0):
             low = torch.rand(N, d, *[max(2, s // 8) for s in dims], device=dev) * 2 - 1
             up = F.interpolate(low, size=dims, mode="bilinear", align_corners=True)
             up = up / up.abs().max()
             sc = torch.tensor([2.0 * amp / (dims[d - 1 - a] - 1) for a in range(d)], device=dev).view(1, d, 1, 1)
             big = (_identity_grid(N, dims).to(dev) + up * sc).contiguous()
-            cand = [16] + [-h for h in (2, 4, 8, 16) if amp < h and h < 4 * amp]
+            cand = [16] + [-h for h in (2, 4, 8, 16, 32) if amp < h and h < 4 * amp]
             for hb in cand:
                 add("compose_self bwd %.1f px halo=%d" % (amp, hb), lambda big=big, hb=hb: ops.raw_compose_self_bwd(gq, big, ws, False, hb), 12 * d * NV)
+                if hb == -32:      # (whole-row scatter of the squarings only)
+                    continue
                 add("grid_sample bwd C=4 %.1f px halo=%d" % (amp, hb), lambda big=big, hb=hb: ops.raw_grid_sample_bwd(g4, x4, big, 0, 0, True, True, True, hb), 4 * NV * (12 + 2 * d))
                 add("grid_sample bwd C=1 %.1f px halo=%d" % (amp, hb), lambda big=big, hb=hb: ops.raw_grid_sample_bwd(g1, x1, big, 0, 0, True, True, True, hb), 4 * NV * (3 + 2 * d))
     add("compose_self bwd halo=2%s" % (" (gather form)" if d == 2 else ""), lambda: ops.raw_compose_self_bwd(gq, phi, ws, False, 2), 12 * d * NV)
