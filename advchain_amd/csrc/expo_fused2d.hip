@@ -34,7 +34,7 @@ constexpr int kFuseMaxLevels = 5;
 // s / (W / 64), columns 64 * (s % (W / 64)) ..); requires W % 64 == 0.
 template <int NT, int PPW>
 __global__ void __launch_bounds__(NT)      // (101 VGPRs, two workgroups a CU; capped at 80 for three it spills and is 4 % slower)
-k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, int64_t F, Dims d, int k, int TH,
+k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, int64_t F, Dims d, int k, int TH, int hal,
                    float* __restrict__ disp_rows, float* __restrict__ fail_flag) {
   extern __shared__ float2 win[];            // [WY][W] (x, y) of the current level
   __shared__ float red[NT / 64];
@@ -42,8 +42,12 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
   const int V = W * S1;
   const int n = blockIdx.y;
   const int y0 = blockIdx.x * TH;
-  const int wy0 = y0 - k;                    // image row of window row 0
-  const int WY = TH + 2 * k;
+  // hal: 4 bits per level, the row halo h of level lev = a bound on the displacement of ITS INPUT in pixels (1 for the
+  // sub-pixel levels); the window carries their sum either side
+  int HS = 0;
+  for (int j = 0; j < k; ++j) HS += (hal >> (4 * j)) & 15;
+  const int wy0 = y0 - HS;                   // image row of window row 0
+  const int WY = TH + 2 * HS;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int NWV = NT / 64;
   const int SPR = W >> 6;                    // segments per row
@@ -94,13 +98,16 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
   }
 
   const float topx = (float)(W - 1), topy = (float)(S1 - 1), hx = 0.5f * topx, hy = 0.5f * topy;
+  int cum = 0;                                 // rows the window has shrunk by either side
   for (int lev = 1; lev <= k; ++lev) {
-    if (!(dcur < 0.999f)) {                    // block-uniform (NaN included): this window cannot do level `lev`
+    const int h = (hal >> (4 * (lev - 1))) & 15;
+    if (!(dcur < (h == 1 ? 0.999f : (float)h - 0.001f))) {   // block-uniform (NaN included): this window cannot do level `lev`
       if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(fail_flag), __float_as_uint((float)(k - lev + 1)));
       return;
     }
-    // rows this level produces: the window shrunk by `lev` rows either side, inside the image
-    const int rlo = max(wy0 + lev, 0), rhi = min(wy0 + WY - lev, S1) - 1;
+    // rows this level produces: the window shrunk by the halos so far either side, inside the image
+    cum += h;
+    const int rlo = max(wy0 + cum, 0), rhi = min(wy0 + WY - cum, S1) - 1;
     float rx[PPW], ry[PPW];
     float dmax = 0.f, dall = 0.f;              // displacement of phi_lev over the owned rows / over every row of the level
 #pragma unroll
@@ -163,7 +170,7 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
     const int own_rows = min(TH, S1 - y0);
     for (int q = threadIdx.x; q < own_rows * QW; q += NT) {
       const int r = q / QW, qx = q - r * QW;
-      const float4* src = reinterpret_cast<const float4*>(win + (r + k) * W + 4 * qx);
+      const float4* src = reinterpret_cast<const float4*>(win + (r + HS) * W + 4 * qx);
       const float4 p0 = src[0], p1 = src[1];
       *reinterpret_cast<float4*>(on + (y0 + r) * W + 4 * qx) = make_float4(p0.x, p0.z, p1.x, p1.z);
       *reinterpret_cast<float4*>(on + V + (y0 + r) * W + 4 * qx) = make_float4(p0.y, p0.w, p1.y, p1.w);
@@ -175,28 +182,36 @@ k_expo_fused_fwd2d(const float* __restrict__ phi0, float* __restrict__ fields, i
 
 using namespace advchain;
 
-// phi_1..phi_k of a 2D chain in one launch (k >= 2).  ADVCHAIN_ERR_UNSUPPORTED when the shape does not fit (rows must be a
-// multiple of 64 pixels and at most 512, 16-byte aligned base pointers); otherwise the launch is enqueued and `fail_flag`
-// (one float, zero before the call) is raised by any workgroup whose window moves too far for k sub-pixel squarings.
-int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, Dims d, int k, float* disp_rows,
+// phi_1..phi_k of a 2D chain in one launch (k >= 1).  `halos`: 4 bits per level, a bound (pixels, 1..15) on the displacement
+// of the level's input -- 1 for the sub-pixel squarings, larger for the squarings behind them (the window then carries
+// the sum of the halos either side).  ADVCHAIN_ERR_UNSUPPORTED when the shape does not fit (rows must be a multiple of 64
+// pixels and at most 512, 16-byte aligned base pointers, a window of at most 64 KiB); otherwise the launch is enqueued and
+// `fail_flag` (one float, zero before the call) is raised by any workgroup whose window moves too far for one of its levels.
+int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, Dims d, int k, int halos, float* disp_rows,
                                      float* fail_flag, hipStream_t stream) {
-  if (d.s0 != 1 || k < 2 || k > kFuseMaxLevels || !fail_flag) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (d.s0 != 1 || k < 1 || k > kFuseMaxLevels || !fail_flag) return ADVCHAIN_ERR_UNSUPPORTED;
   const int W = d.s2;
   if (W % 64 != 0 || W > 512 || d.s1 < 8) return ADVCHAIN_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(phi0) | reinterpret_cast<uintptr_t>(fields)) & 15) return ADVCHAIN_ERR_UNSUPPORTED;
-  constexpr int NT = 512, PPW = 13;
-  // rows per workgroup: the window (TH + 2k rows of W pairs) within 56 KiB (two workgroups a CU) and within the PPW
+  int HS = 0;
+  for (int j = 0; j < k; ++j) {
+    const int h = (halos >> (4 * j)) & 15;
+    if (h < 1) return ADVCHAIN_ERR_UNSUPPORTED;
+    HS += h;
+  }
+  constexpr int NT = 512, PPW = 13;      // (16 segments a wave: 133 VGPRs, one workgroup a CU instead of two)
+  // rows per workgroup: the window (TH + 2 HS rows of W pairs) within 56 KiB (two workgroups a CU) and within the PPW
   // segments a wave can carry; 16 where that fits
   const int spr = W / 64;
   int TH = 16;
-  while (TH > 4 && ((TH + 2 * k) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * k) * W * sizeof(float2) > 56 * 1024)) TH -= 4;
-  if ((TH + 2 * k) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * k) * W * sizeof(float2) > 64 * 1024) return ADVCHAIN_ERR_UNSUPPORTED;
+  while (TH > 4 && ((TH + 2 * HS) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * HS) * W * sizeof(float2) > 56 * 1024)) TH -= 4;
+  if ((TH + 2 * HS) * spr > PPW * (NT / 64) || (size_t)(TH + 2 * HS) * W * sizeof(float2) > 64 * 1024) return ADVCHAIN_ERR_UNSUPPORTED;
   const int64_t F = N * 2 * d.voxels();
-  const size_t lds = (size_t)(TH + 2 * k) * W * sizeof(float2);
+  const size_t lds = (size_t)(TH + 2 * HS) * W * sizeof(float2);
   dim3 grid((unsigned)((d.s1 + TH - 1) / TH), (unsigned)N);
   // a workgroup walks its k levels one after the other: with fewer workgroups than CUs (cfg-1: 8 fields x 12 windows) the k
   // small launches finish sooner than one long one
   if ((int64_t)grid.x * grid.y < 256) return ADVCHAIN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((k_expo_fused_fwd2d<NT, PPW>), grid, dim3(NT), lds, stream, phi0, fields, F, d, k, TH, disp_rows, fail_flag);
+  hipLaunchKernelGGL((k_expo_fused_fwd2d<NT, PPW>), grid, dim3(NT), lds, stream, phi0, fields, F, d, k, TH, halos, disp_rows, fail_flag);
   return ADVCHAIN_OK;
 }

@@ -794,8 +794,8 @@ bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const
                                     int64_t N, int64_t C, int ndim, Dims d, hipStream_t st, const float* tilemax);
 
 // expo_fused2d.hip / adjoint_fused2d.hip: the sub-pixel squarings of a 2D chain in one launch (forward / backward)
-int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, float* disp_rows,
-                                     float* fail_flag, hipStream_t stream);
+int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, int halos,
+                                     float* disp_rows, float* fail_flag, hipStream_t stream);
 int advchain_adjoint_fused2d_launch(const float* gk, const float* phi0, const float* fields, float* g0, int64_t N, advchain::Dims d,
                                     int k, int32_t* workspace, hipStream_t st);
 // gather_tiled.hip
@@ -1175,11 +1175,20 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
     // how many: the leading squarings whose hinted input displacement (bits 8.. of a hint: 1/1024 pixel) leaves a quarter
     // of room below one pixel for the field to grow between two ascent steps; a level some window cannot do after all is
     // repeated by the launch behind the fused kernel
-    int k = 0;
-    while (k < n - 1 && k < fuse_max && ((unsigned)hints[k] >> 8) != 0 &&
-           (float)((unsigned)hints[k] >> 8) * (1.25f / 1024.f) < 1.f) ++k;
+    // ... and the squarings behind them while the window (the sum of the levels' row halos either side) stays small: a
+    // level whose input moves less than h pixels takes its corners from h rows either side
+    static const int hs_max = getenv("ADVCHAIN_FUSE2D_HS") ? atoi(getenv("ADVCHAIN_FUSE2D_HS")) : 5;   // A/B knob: rows of halo in all
+    int k = 0, halos = 0, hs = 0;
+    while (k < n - 1 && k < fuse_max && ((unsigned)hints[k] >> 8) != 0) {
+      const float e = (float)((unsigned)hints[k] >> 8) * (1.25f / 1024.f);
+      const int h = e < 1.f ? 1 : (int)e + 1;
+      if (h > 15 || hs + h > (hs_max > k + 1 ? hs_max : k + 1)) break;     // (sub-pixel levels always fit, as before)
+      halos |= h << (4 * k);
+      hs += h;
+      ++k;
+    }
     if (k >= 2) {
-      const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, disp_rows, fuse_flag,
+      const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, halos, disp_rows, fuse_flag,
                                                       (hipStream_t)stream);
       if (rf == ADVCHAIN_OK) {
         // ONE repeat launch behind it: returns at once unless some window of the fused kernel stopped early, else runs the

@@ -126,8 +126,9 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
  *      bits 8..: the same estimate in 1/1024 voxel, 0 = unknown -- read by the 2D fusing rule).
  *      fuse_flag (may be NULL; TWO 32-bit words, ZERO before the call: a float flag and the arrival counter of the repeat
  *      launch's grid barrier): 2D only -- allows the leading squarings whose hinted input
- *      displacement is below one pixel (at most 5, rows of 64k <= 512 pixels) to run as ONE launch over whole-row LDS
- *      windows (same arithmetic, bit-identical fields).  The kernel checks the premise on every window, level by level; a
+ *      displacement is below one pixel, and the squarings behind them while the row halos of all fused levels (a level whose
+ *      input moves less than h pixels needs h rows) sum to at most 5 (at most 5 levels, rows of 64k <= 512 pixels), to run as
+ *      ONE launch over whole-row LDS windows (same arithmetic, bit-identical fields).  The kernel checks the premise on every window, level by level; a
  *      window that has to stop early records how many levels it could not do (*fuse_flag = the largest such count), and ONE
  *      repeat launch enqueued behind it (a persistent grid that returns at once while the flag is down) runs exactly those
  *      levels the ordinary way -- results never depend on the hints.  The caller may read the flag back (> 0: the hints were too optimistic) and must zero it

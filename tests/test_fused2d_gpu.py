@@ -60,6 +60,44 @@ def test_fused_levels_equal_the_per_squaring_launches(dims, k):
     assert not torch.isnan(out[0][:k]).any()
 
 
+@pytest.mark.parametrize("dims", [(256, 256), (100, 128), (37, 320)])
+def test_fused_levels_above_one_pixel_ride_on_a_wider_halo(dims):
+    """Hints with the measured displacements (bits 8..: 1/1024 px): the squaring whose input moves 1 .. 1.6 px joins the fused
+    launch with a row halo of 2 (the window carries the sum of the halos, at most 5 rows either side) -- same bits, flag
+    down; a hint that promises less than the field does (halo 2 for an input that moves 2.4 px) raises a deficit of one
+    level and the repeat launch redoes it."""
+    import ctypes
+    from advchain_amd import _lib, ops
+    n = 8
+    N = max(3, -(-256 // max(1, dims[0] // 16)))
+    phi0 = _phi0(N, dims, 0.19, 17)                  # phi_j moves ~0.19 * 2^j px: 0.19 0.38 0.76 1.5 3 ...
+    ref = _chain(phi0, n, None, False)
+    dm = ref[2].tolist()
+    assert dm[2] < 0.8 and 1.0 < dm[3] < 1.6, dm[:5]
+    lib = _lib.load()
+
+    def run(hint_disp):
+        rows = torch.zeros(n + 2, ops.DISP_SLOTS, device=DEV)
+        fields = torch.full((n - 1,) + tuple(phi0.shape), float("nan"), device=DEV)
+        pos = torch.empty_like(phi0)
+        harr = (ctypes.c_int32 * n)(*[(ops._fine_bits(x) << 8) if x is not None else 0 for x in hint_disp])
+        _lib.check(lib.advchain_expo_chain_fwd(ops._ptr(phi0), ops._ptr(fields), ops._ptr(pos), phi0.shape[0], 2, _lib.dims_array(dims), n,
+                                               ops._ptr(rows), harr, ops._ptr(rows[n + 1]), ops._stream()), "expo_chain_fwd")
+        torch.cuda.synchronize()
+        return fields, pos, rows[:n + 1].max(1).values, float(rows[n + 1, 0])
+    out = run(dm[:4] + [None] * 4)                   # levels 1..4 fused: halos 1, 1, 1, 2
+    assert out[3] == 0.0
+    lying = run(dm[:3] + [dm[3] / 2.0, None, None, None, None]) if dm[3] * 1.25 / 2 < 1.0 else None
+    for res in (out, lying):
+        if res is None:
+            continue
+        assert torch.equal(res[1], ref[1]) and torch.equal(res[2], ref[2])
+        for m in range(n - 1):
+            assert torch.equal(res[0][m], ref[0][m]), (dims, m)
+    if lying is not None:
+        assert lying[3] == 1.0                       # the level promised as sub-pixel was not: one level redone
+
+
 def test_partial_deficit_repeats_only_the_missing_levels():
     """Hints promise 4 sub-pixel levels, the field allows 2 (phi_2 moves more than a pixel): the fused kernel stops after
     level 2 everywhere it must, records a deficit of 2, and the gated launches of levels 3 and 4 run -- same bits."""
