@@ -177,7 +177,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
 // Tile of 4 x 8 x 32 samples (4 per thread along z); the bounding box pass keeps no taps (they are rebuilt from the
 // L1/L2-resident grid in the deposit pass: 4 x 3 axis taps per thread would not fit the register budget).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWin3Z = 4, kWin3Y = 8, kWin3X = 32;
+// (tile shape: template parameters TX x TY (= 256 threads) x TZ samples per thread; see the launcher)
 #ifndef ADVCHAIN_WIN3_CP4
 #define ADVCHAIN_WIN3_CP4 2
 #endif
@@ -190,7 +190,7 @@ constexpr int kWin3Cells = 12288;        // 48 KiB of LDS: 3 workgroups per CU
 // per channel capped the windows of the 5-8 voxel fields, and what falls outside a window goes to global atomics
 // (8x4x128x128x64: 1449 us; with a 63-KiB window for all four channels 1057 us, but two workgroups a CU).
 
-template <int PAD, int C, bool SELF, bool GG>
+template <int PAD, int C, bool SELF, bool GG, int TX, int TZ>
 __global__ void __launch_bounds__(kBlock)
 k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                    float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid,
@@ -205,7 +205,8 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
   int b = blockIdx.x;
   const int tx = b % n2; b /= n2;
   const int ty = b % n1, tz = b / n1;
-  const int sx = tx * kWin3X + (threadIdx.x & 31), sy = ty * kWin3Y + (threadIdx.x >> 5);
+  constexpr int kWin3X = TX, kWin3Y = kBlock / TX, kWin3Z = TZ;
+  const int sx = tx * kWin3X + (threadIdx.x % TX), sy = ty * kWin3Y + (threadIdx.x / TX);
   const bool col_live = sx < d.s2 && sy < d.s1;
   const float* gn = grid + (int64_t)n * DIM * V;
   const float* gon = gout + (int64_t)n * C * V;
@@ -354,16 +355,19 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
   }
   __syncthreads();
 
-  // ---- 3. flush: a wave per window row (lane <-> x: runs of consecutive addresses, one division per row)
+  // ---- 3. flush: thread <-> cell of the window in memory order (runs of consecutive addresses; a wave per window row left
+  // the lanes beyond the row's width idle, 18-40 of 64: 13-21 % of the kernel at 8 x . x 160 x 160 x 80)
   const float inv = gmax * (1.f / 1048576.f);
-  const int lane = threadIdx.x & 63, rows = CP * wd * wh;
-  for (int r = wave; r < rows; r += kBlock / 64) {
-    if (lane >= ww) continue;
-    const int a = win[r * ww + lane];
-    if (a == 0) continue;
-    const int c = r / (wd * wh), q = r - c * (wd * wh);
-    const int wz = q / wh, wy = q - wz * wh;
-    atomic_add_f32(ginn + (int64_t)(c0 + c) * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + lane), (float)a * inv);
+  {
+    const float inv_ww = 1.f / (float)max(ww, 1), inv_wh = 1.f / (float)max(wh, 1), inv_wd = 1.f / (float)max(wd, 1);
+    for (int i = threadIdx.x; i < CP * cells; i += kBlock) {
+      const int a = win[i];
+      if (a == 0) continue;
+      const int r = (int)(((float)i + 0.5f) * inv_ww), wx = i - r * ww;          // (exact: i < 2^15)
+      const int rz = (int)(((float)r + 0.5f) * inv_wh), wy = r - rz * wh;
+      const int c = (int)(((float)rz + 0.5f) * inv_wd), wz = rz - c * wd;
+      atomic_add_f32(ginn + (int64_t)(c0 + c) * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + wx), (float)a * inv);
+    }
   }
   if (c0 + CP < C) __syncthreads();          // the window is cleared for the next channel pair
   }
@@ -408,10 +412,20 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
     GO_ALL(2);
 #undef GO
   } else {
-    const int n2 = (d.s2 + kWin3X - 1) / kWin3X, n1 = (d.s1 + kWin3Y - 1) / kWin3Y, n0 = (d.s0 + kWin3Z - 1) / kWin3Z;
+    // tile of samples: 32 x 8 x 4, or 16 x 16 x 4 for rows that 32 does not divide (cfg-5's rows of 80: a third of the x tiles
+    // would be half empty; 88.2 -> 86.9 ms per cfg-5 call from the flat flush, -> 86.1 with this shape; 16 x 16 x 8 the same
+    // on the solver's fields and worse on rough ones, whose windows outgrow the LDS budget).  Rows of 64: 32 x 8 x 4 stays
+    // (cfg-3 14.41 against 14.58 ms)
+    static const int shape = getenv("ADVCHAIN_WIN3_SHAPE") ? atoi(getenv("ADVCHAIN_WIN3_SHAPE")) : -1;   // A/B knob: 0 | 1
+    const int sh = shape >= 0 ? (shape != 0) : ((d.s2 % 32 != 0 && d.s2 % 16 == 0) ? 1 : 0);
+    const int TXs = sh == 0 ? 32 : 16, TYs = kBlock / TXs, TZs = 4;
+    const int n2 = (d.s2 + TXs - 1) / TXs, n1 = (d.s1 + TYs - 1) / TYs, n0 = (d.s0 + TZs - 1) / TZs;
     dim3 g((unsigned)(n0 * n1 * n2), (unsigned)N);
 #define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace)
+  do { \
+    if (sh == 0) hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_, 32, 4>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace); \
+    else hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_, 16, 4>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace); \
+  } while (0)
     GO_ALL(3);
 #undef GO
   }
