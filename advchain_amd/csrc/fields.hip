@@ -1117,7 +1117,10 @@ constexpr int kGaussSmallMax = 4096;   // voxels per plane: 2 x 16 KiB of LDS
 // workgroup b reads plane b % P with the scale negated for b >= P -- (-s) * v == -(s * v) exactly, so the second half is
 // bit-identical to smoothing a negated copy.  mirror 2 (its adjoint): P workgroups, out[b] = G(s in[b]) - G(s in[P + b]),
 // the two smoothings done one after the other with the arithmetic of two separate calls.
-__global__ void __launch_bounds__(kBlock)
+// NT threads: 256 for planes of up to 1024 voxels, 1024 beyond (a plane is ONE workgroup: with 4 waves a cfg-5 plane of 4000
+// voxels was a chain of 48 dependent voxel steps per thread on an otherwise idle CU, 46.6 us a launch)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int ndim, GaussW gw, float scale, int mirror,
               int P) {
   __shared__ float buf[2][kGaussSmallMax];
@@ -1125,19 +1128,19 @@ k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int
   const int S[3] = {d.s0, d.s1, d.s2};
   const int stride[3] = {d.s1 * d.s2, d.s2, 1};
   const int b = blockIdx.x;
-  float first[(kGaussSmallMax + kBlock - 1) / kBlock];
+  float first[(kGaussSmallMax + NT - 1) / NT];
   const int rounds = mirror == 2 ? 2 : 1;
   for (int round = 0; round < rounds; ++round) {
     const float* src = in + (int64_t)(mirror == 1 ? b % P : b + round * P) * V;
     const float sc = (mirror == 1 && b >= P) ? -scale : scale;
     if (round) __syncthreads();
-    for (int i = threadIdx.x; i < V; i += kBlock) buf[0][i] = src[i] * sc;
+    for (int i = threadIdx.x; i < V; i += NT) buf[0][i] = src[i] * sc;
     __syncthreads();
     int cur = 0;
     for (int pass = 0; pass < ndim; ++pass) {
       const int axis = 2 - pass;              // innermost first, like advchain_gauss_axis is called
       const int Sa = S[axis], st = stride[axis];
-      for (int i = threadIdx.x; i < V; i += kBlock) {
+      for (int i = threadIdx.x; i < V; i += NT) {
         const int ia = (i / st) % Sa;
         float acc = 0.f;
 #pragma unroll
@@ -1152,17 +1155,17 @@ k_gauss_small(const float* __restrict__ in, float* __restrict__ out, Dims d, int
     }
     float* dst = out + (int64_t)b * V;
     if (mirror != 2) {
-      for (int i = threadIdx.x; i < V; i += kBlock) dst[i] = buf[cur][i];
+      for (int i = threadIdx.x; i < V; i += NT) dst[i] = buf[cur][i];
     } else if (round == 0) {
 #pragma unroll
-      for (int q = 0; q < (kGaussSmallMax + kBlock - 1) / kBlock; ++q) {
-        const int i = threadIdx.x + q * kBlock;
+      for (int q = 0; q < (kGaussSmallMax + NT - 1) / NT; ++q) {
+        const int i = threadIdx.x + q * NT;
         first[q] = i < V ? buf[cur][i] : 0.f;
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < (kGaussSmallMax + kBlock - 1) / kBlock; ++q) {
-        const int i = threadIdx.x + q * kBlock;
+      for (int q = 0; q < (kGaussSmallMax + NT - 1) / NT; ++q) {
+        const int i = threadIdx.x + q * NT;
         if (i < V) dst[i] = first[q] - buf[cur][i];
       }
     }
@@ -1651,8 +1654,12 @@ static int gauss_small_launch(const float* in, float* out, int64_t planes, int n
   GaussW gw;
   for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
   const unsigned blocks = (unsigned)(mirror == 1 ? 2 * planes : planes);
-  hipLaunchKernelGGL(k_gauss_small, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, d, ndim, gw,
-                     pre == 1 ? scale : 1.f, mirror, (int)planes);
+  if (d.voxels() > 1024)
+    hipLaunchKernelGGL(k_gauss_small<1024>, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, in, out, d, ndim, gw,
+                       pre == 1 ? scale : 1.f, mirror, (int)planes);
+  else
+    hipLaunchKernelGGL(k_gauss_small<kBlock>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, in, out, d, ndim, gw,
+                       pre == 1 ? scale : 1.f, mirror, (int)planes);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }
