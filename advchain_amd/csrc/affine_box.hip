@@ -591,19 +591,30 @@ k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta
       m = fmaxf(m, tm[((t0z + iz) * nty + t0y + iy) * ntx + t0x + ix]);
     }
   }
-  for (int i = threadIdx.x; i < (tilemax ? 0 : ncell); i += kBlock) {
-    int vx, vy, vz;
-    cell_voxel(i, vx, vy, vz);
-    const int v = (vz * d.s1 + vy) * d.s2 + vx;
+  auto box_max = [&]() {
+    float mm = 0.f;
+    for (int i = threadIdx.x; i < ncell; i += kBlock) {
+      int vx, vy, vz;
+      cell_voxel(i, vx, vy, vz);
+      const int v = (vz * d.s1 + vy) * d.s2 + vx;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) m = fmaxf(m, fabsf(gon[(int64_t)(c < C ? c : 0) * V + v]));
-    // (a NaN gradient: fmaxf drops it here; it is re-detected below through the sum test)
-  }
+      for (int c = 0; c < CMAX; ++c) mm = fmaxf(mm, fabsf(gon[(int64_t)(c < C ? c : 0) * V + v]));
+      // (a NaN gradient: fmaxf drops it here; it is re-detected below through the sum test)
+    }
+    return mm;
+  };
+  auto block_max = [&](float mm) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-  __syncthreads();
-  const float gmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+    __syncthreads();                                   // (wmax may still be read from the previous call)
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mm;
+    __syncthreads();
+    return fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  };
+  float gmax = block_max(tilemax ? m : box_max());
+  // an inf among the covering tiles need not lie in the box: look (uniform; only then) -- a non-finite gradient poisons
+  // the tiles it reaches, not their neighbours
+  if (tilemax && !(gmax < 3.0e38f)) gmax = block_max(box_max());
   // a cell receives at most prod(2 ext + 1) corners of weight <= 1
   float cnt = 1.f;
 #pragma unroll

@@ -688,13 +688,15 @@ def test_affine_warp(dims, C, pad):
     assert float((n_out.cpu() != n_ref).float().mean()) < 2e-3  # rounding ties at .5 may differ by fp order
 
 
+@pytest.mark.parametrize("theta_grad", [False, True])
 @pytest.mark.parametrize("dims", [(64, 96), (32, 40, 64)])
-def test_affine_gin_high_dynamic_range(dims):
+def test_affine_gin_high_dynamic_range(dims, theta_grad):
     """grad_in of the affine warp through the LDS box (k_affine_box_gin, affine_box.hip) accumulates in 32-bit fixed point
     scaled by the largest |grad_out| of the tile's sample box: the ABSOLUTE error of a cell is bounded by
     n_corners * gmax / 2^30 per deposit (documented in INTEGRATION.md) whatever the dynamic range -- here a 1e-5 background
     under isolated spikes of 1 -- and the cells a spike does not share a box with keep fp32 relative precision.  Against
-    float64 autograd on the CPU."""
+    float64 autograd on the CPU.  theta_grad: the theta gradient is asked for as well -- it then runs first and its per-tile
+    maxima of |grad_out| (over the tiles that cover the box: a superset) replace the kernel's own pass over the box."""
     ops = _ops()
     d = len(dims)
     g = torch.Generator().manual_seed(11)
@@ -709,7 +711,8 @@ def test_affine_gin_high_dynamic_range(dims):
     (out * w.double()).sum().backward()
     ref = xd.grad
     xg = x.to(DEV).requires_grad_(True)
-    (ops.affine_warp(xg, theta.to(DEV)) * w.to(DEV)).sum().backward()
+    tg = theta.to(DEV).requires_grad_(theta_grad)
+    (ops.affine_warp(xg, tg) * w.to(DEV)).sum().backward()
     err = (xg.grad.cpu().double() - ref).abs()
     # worst cell: the fp32 rounding of the sampling positions under a spike (weight error ~1e-6 x gmax = 1; measured 5.8e-6
     # in 2D) -- the fixed-point quantum (n_max * gmax / 2^30 per deposit, ~1e-8) is far below it
@@ -718,6 +721,33 @@ def test_affine_gin_high_dynamic_range(dims):
     bg = ref.abs() < 1e-4
     assert float(err[bg].mean()) < 2e-7, float(err[bg].mean())
     assert float((xg.grad.cpu()[bg] != 0).float().mean()) > 0.9
+
+
+@pytest.mark.parametrize("theta_grad", [False, True])
+@pytest.mark.parametrize("dims", [(64, 96), (32, 40, 64)])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_affine_gin_non_finite_gradient_does_not_come_out_finite(dims, theta_grad, bad):
+    """A NaN / inf in grad_out must reach grad_in as a non-finite number wherever autograd would put one (the fixed-point
+    accumulators of k_affine_box_gin cannot hold it: the tile is poisoned), on both routes to the fixed-point scale."""
+    ops = _ops()
+    d = len(dims)
+    N, C = 2, 4
+    x = rand((N, C) + dims, 31)
+    w = rand((N, C) + dims, 32)
+    w[1, 2][tuple(s // 2 for s in dims)] = bad
+    theta = torch.eye(d, d + 1).repeat(N, 1, 1) + 0.05 * rand((N, d, d + 1), 33)
+    xc = x.clone().requires_grad_(True)
+    out = F.grid_sample(xc, F.affine_grid(theta, xc.size(), align_corners=True), align_corners=True)
+    out.backward(w)
+    xg = x.to(DEV).requires_grad_(True)
+    tg = theta.to(DEV).requires_grad_(theta_grad)
+    ops.affine_warp(xg, tg).backward(w.to(DEV))
+    got, ref = xg.grad.cpu(), xc.grad
+    assert bool((~torch.isfinite(got))[~torch.isfinite(ref)].all())        # every cell autograd marks is marked
+    # (a poisoned tile turns NaN as a whole, every channel of it: more cells than autograd marks, never another sample)
+    assert torch.isfinite(got[0]).all() and float((~torch.isfinite(got[1])).float().mean()) < 0.3
+    fin = torch.isfinite(got) & torch.isfinite(ref)
+    assert maxdiff(got[fin], ref[fin]) < TOL
 
 
 def test_grid_sample_onto_a_single_voxel():
