@@ -157,7 +157,7 @@ def test_profile_tooling_recomputes_the_committed_numbers(tmp_path):
         rec = t[wl]["advchain_compose_self_bwd"]
         assert rec == committed[wl]["advchain_compose_self_bwd"]
         assert 0.2 < rec["frac_from_rocprof"] < 0.45 and 1.0 < rec["traffic_over_algorithmic"] < 1.6
-    assert abs(t["cfg2"]["advchain_compose_self_bwd"]["frac_from_rocprof"] - 0.286) < 0.002
+    assert abs(t["cfg2"]["advchain_compose_self_bwd"]["frac_from_rocprof"] - 0.292) < 0.002
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ns_pair_summary.py"), prof], check=True, capture_output=True, text=True)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("level")]
-    assert len(lines) == 2 and "0.601 of" in lines[0] and "0.318 of" in lines[1], r.stdout
+    assert len(lines) == 2 and "0.586 of" in lines[0] and "0.314 of" in lines[1], r.stdout
