@@ -291,7 +291,9 @@ def test_displacement_hint_bits_and_halo_policies():
     assert ops._hint_bits(0.3) == 1 << 8 and ops._hint_bits(1.0) == 2 << 8 and ops._hint_bits(6.2) == 7 << 8
     assert ops._hint_bits(1e9) == 255 << 8
     assert [ops.squaring_halo(x, 3) for x in (0.5, 0.9995, 1.5, 2.5, 3.5, 3.9995, 7.0)] == [-1, -2, -2, -3, -4, 8, 8]
-    assert [ops.squaring_halo(x, 2) for x in (0.5, 1.5, 3.0, 7.9, 15.0, 15.9995, 40.0)] == [-1, -2, -4, -8, -16, 16, 16]
+    # (2D squarings: the whole-row scatter up to an exact 32 px; image warps stop at 16)
+    assert [ops.squaring_halo(x, 2) for x in (0.5, 1.5, 3.0, 7.9, 15.0, 15.9995, 31.0, 31.9995, 40.0)] == [-1, -2, -4, -8, -16, -32, -32, 16, 16]
+    assert [ops.warp_halo([None, x, 0, 0], 2) for x in (15.0, 15.9995, 31.0)] == [-16, 16, 16]
     assert ops.squaring_halo(float("nan"), 3) == 0
     assert ops.warp_halo([None, 0.4, 0, 0], 3) == -1 and ops.warp_halo([None, 5.0, 0, 0], 3) == 8
     assert ops.warp_halo([None, 0.4, 0, 0], 2) == -2 and ops.warp_halo([None, 20.0, 0, 0], 2) == 16
