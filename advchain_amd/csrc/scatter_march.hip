@@ -1299,7 +1299,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     const int n1f = (int)((d.s1 + TYf - 1) / TYf);
     int zcf = (int)d.s0;
     while (zcf > 8 && N * n1f * ((d.s0 + zcf - 1) / zcf) < 512) zcf = (zcf + 1) / 2;
-    static const int zcf_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+    static const int zcf_forced = 0;   // (0: the rule below; was a tuning knob until round 4)
     if (zcf_forced > 0) zcf = zcf_forced;
     const int n0f = (int)((d.s0 + zcf - 1) / zcf);
     const int rows = (int)(d.s0 * d.s1);
@@ -1325,7 +1325,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     const int n1w = (int)((d.s1 + 15) / 16);
     int zcw = (int)d.s0;
     while (zcw > 16 && N * n1w * ((d.s0 + zcw - 1) / zcw) < 256) zcw = (zcw + 1) / 2;
-    static const int zcw_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+    static const int zcw_forced = 0;   // (0: the rule below; was a tuning knob until round 4)
     if (zcw_forced > 0) zcw = zcw_forced;
     const int n0w = (int)((d.s0 + zcw - 1) / zcw);
     const int rows = (int)(d.s0 * d.s1);
@@ -1355,7 +1355,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
   const size_t lds = (size_t)NS * C * TY * 64 * sizeof(int);
   if (lds > 65536) return ADVCHAIN_ERR_UNSUPPORTED;
   const int n1 = (d.s1 + TY - 1) / TY;
-  static const int zc_forced = getenv("ADVCHAIN_SCATTER_MARCH_ZC") ? atoi(getenv("ADVCHAIN_SCATTER_MARCH_ZC")) : 0;
+  static const int zc_forced = 0;   // (0: the rule below; was a tuning knob until round 4)
   int zc = d.s0;
   while (zc > 8 && N * n1 * nseg * ((d.s0 + zc - 1) / zc) < 512) zc = (zc + 1) / 2;   // (16 planes: 1003 GB/s, 8: 942, 32: 834)
   if (zc_forced > 0) zc = zc_forced;

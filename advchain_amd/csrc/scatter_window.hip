@@ -378,7 +378,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 using namespace advchain;
 
 // grad_in (and, for SELF, the same tensor) is zero-filled here.  2D: every displacement the gather form does not take.
-// 3D: from the displacement hint |halo| >= ADVCHAIN_WINDOW3D_MIN_HALO (default 2: everything above the gather form;
+// 3D: from the displacement hint |halo| >= 2 (everything above the gather form;
 // since the corner loads are issued unconditionally it beats the owner-computes tiles from one voxel up).
 // A chained workspace is told (by the kernel itself) that this launch left no max|result| behind (header [3] = -1:
 // see scatter_tiled.hip).
@@ -387,7 +387,7 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
                                    int halo, int32_t* workspace, hipStream_t st) {
   static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
-  static const int min3 = getenv("ADVCHAIN_WINDOW3D_MIN_HALO") ? atoi(getenv("ADVCHAIN_WINDOW3D_MIN_HALO")) : 2;
+  static const int min3 = 2;   // measured optimum (was a tuning knob until round 4)
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return ADVCHAIN_ERR_UNSUPPORTED;   // 24-bit index products
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the time of the 3D march scatter goes at the north-star shape: grid_sample bwd (C = 1) on a given field with and
-without grad_grid (A/B knobs: ADVCHAIN_NO_SCATTER_MARCH_WIDE, ADVCHAIN_SCATTER_MARCH_ZC)."""
+without grad_grid (A/B knob: ADVCHAIN_NO_SCATTER_MARCH_WIDE)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
