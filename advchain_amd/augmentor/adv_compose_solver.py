@@ -39,7 +39,7 @@ class ComposeAdversarialTransformSolver(object):
 
     def __init__(self, chain_of_transforms=[], divergence_types=['mse', 'contour'],
                  divergence_weights=[1.0, 0.5], use_gpu=True, debug=False, if_norm_image=False,
-                 min_intensity=None, max_intensity=None, is_gt=False, process_group=None):
+                 min_intensity=None, max_intensity=None, is_gt=False, process_group=None, hip_graph=False):
         self.chain_of_transforms = chain_of_transforms
         self.use_gpu = use_gpu
         self.debug = debug
@@ -53,6 +53,13 @@ class ComposeAdversarialTransformSolver(object):
         self.class_weights = None
         self.process_group = process_group     # extension: batch-sharded replicas
         self.device_nan_guard = True           # NaN guard of the ascent loop on the device (False: a host read-back per step)
+        # extension: replay the ascent loop of adversarial_training (initial prediction + the n_iter ascent steps) as ONE
+        # hipGraph once its launch sequence has been recorded (see _graphed_ascent); off by default -- the user's model
+        # is captured with it, which needs a model without host-side control flow or side effects
+        self.hip_graph = hip_graph
+        self.hip_graph_record_calls = 2        # ordinary calls recorded before the capture
+        self._graphs = {}
+        self.graph_stats = {"recorded": 0, "captures": 0, "replays": 0, "violations": 0, "refused": 0}
         self._global_batch = None
 
     # ------------------------------------------------------------------------------- sharding helpers
@@ -124,17 +131,30 @@ class ComposeAdversarialTransformSolver(object):
         else:
             raise ValueError('please use scalar or a  list of scalar to set step size')
         self._resolve_global_batch(data.size(0), data.device)
-        if init_output is None:
-            init_output = self.get_init_output(data=data, model=model)
-        self.init_random_transformation(lazy_load, anatomy_mask_images=anatomy_mask_images,
-                                        volume_preserve_tolerance=volume_preserve_tolerance)
-        if n_iter >= 1:
-            self.chain_of_transforms = self.optimizing_transform(
-                data=data, model=model, init_output=init_output, n_iter=n_iter, optimize_flags=optimize_flags,
-                step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
-                anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
+        pending = None
+        if self.hip_graph and n_iter >= 1 and self._graphable(data, model, init_output, anatomy_mask_images):
+            # the ascent loop as one hipGraph replay (or one of the ordinary calls that record its launch plan)
+            init_output, pending = self._graphed_ascent(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes)
+        else:
+            if self.hip_graph and n_iter >= 1:
+                self.graph_stats["refused"] += 1
+            if init_output is None:
+                init_output = self.get_init_output(data=data, model=model)
+            self.init_random_transformation(lazy_load, anatomy_mask_images=anatomy_mask_images,
+                                            volume_preserve_tolerance=volume_preserve_tolerance)
+            if n_iter >= 1:
+                self.chain_of_transforms = self.optimizing_transform(
+                    data=data, model=model, init_output=init_output, n_iter=n_iter, optimize_flags=optimize_flags,
+                    step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
+                    anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
         dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
             data.detach(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
+        if pending is not None and not pending():
+            # the replay measured a displacement outside the interval its frozen kernel selection is exact for: this call
+            # again the ordinary way, from the same initial parameters (its measurements widen the plan)
+            init_output = self._redo_ascent()
+            dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
+                data.detach(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
         self.init_output = init_output
         self.warped_back_adv_output = warped_back_adv_output
         self.origin_data = data
@@ -143,6 +163,161 @@ class ComposeAdversarialTransformSolver(object):
         if self.debug:
             print('[outer loop] loss', dist.item())
         return dist
+
+    # ------------------------------------------------------------------------------- hipGraph replay of the ascent loop
+    def _graphable(self, data, model, init_output, anatomy_mask_images):
+        """What a capture cannot hold: host-side decisions inside the loop (the anatomy ladder, debug prints, the host NaN
+        check, third-party transforms), collectives (not captured: sharded runs stay on the ordinary path) and CPU data."""
+        chain = self.chain_of_transforms
+        return (isinstance(data, torch.Tensor) and data.is_cuda and data.dtype == torch.float32
+                and anatomy_mask_images is None and not self.debug and self.process_group is None
+                and self.device_nan_guard and not getattr(self, 'full_backward', False)
+                and ops.ADAPTIVE_HALO and len(chain) > 0 and all(type(t) in _NATIVE for t in chain)
+                and not any(getattr(t, 'debug', False) for t in chain)
+                and isinstance(model, torch.nn.Module)
+                and (init_output is None or (isinstance(init_output, torch.Tensor) and init_output.is_cuda)))
+
+    @staticmethod
+    def _plain(v):
+        if isinstance(v, (int, float, str, bool, type(None))):
+            return v
+        if isinstance(v, (list, tuple)) and all(isinstance(x, (int, float, str, bool, type(None))) for x in v):
+            return tuple(v)
+        return None
+
+    def _graph_key(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
+        """Everything the captured launch sequence depends on besides tensor CONTENTS: shapes, the model's storage, the
+        arguments of the call, every plain attribute of the solver and of its transforms."""
+        tr = tuple((type(t).__name__,) + tuple(sorted((k, self._plain(v)) for k, v in vars(t).items()
+                                                       if self._plain(v) is not None))
+                   for t in self.chain_of_transforms)
+        mod = (id(model), model.training) + tuple(p.data_ptr() for p in model.parameters()) \
+            + tuple(b.data_ptr() for b in model.buffers())
+        mine = tuple(sorted((k, self._plain(v)) for k, v in vars(self).items()
+                            if k not in ('graph_stats',) and (self._plain(v) is not None)))
+        return (tuple(data.shape), str(data.device), None if init_output is None else tuple(init_output.shape), bool(lazy_load),
+                int(n_iter), tuple(bool(f) for f in optimize_flags), tuple(step_sizes), tr, mod, mine)
+
+    def _graphed_ascent(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
+        """get_init_output + init_random_transformation + optimizing_transform with the launches of the prediction and of the
+        ascent loop replayed from a hipGraph.
+
+        The first `hip_graph_record_calls` calls with a new signature run the ordinary way while an ops.LaunchPlan records
+        what their kernel selection read back from the device (displacement bounds, the 3D step count); the next call
+        captures the loop once with the selection frozen from that record; every later call draws its initial parameters
+        the ordinary way, copies them and the data into the captured buffers and replays.  The replay checks ON THE DEVICE
+        that what it measures stays inside the intervals the frozen selection is exact for (ops.LaunchPlan.check); the
+        returned closure waits for the graph (not for the final pass queued behind it) and tells whether the check held.
+        Returns (init_output, closure or None)."""
+        self.init_random_transformation(lazy_load)
+        key = self._graph_key(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes)
+        rec = self._graphs.get(key)
+        if rec is None:
+            if len(self._graphs) >= 8:       # (each holds a memory pool of one whole call)
+                self._graphs.clear()
+            rec = self._graphs[key] = {"plan": ops.LaunchPlan(), "state": "record", "graph": None}
+        chain = list(self.chain_of_transforms)
+        init_params = [t.param.detach() for t in chain]
+        given = init_output
+
+        def ordinary(record):
+            for t, p in zip(chain, init_params):
+                t.param = p
+            self.chain_of_transforms = chain
+            if record:
+                rec["plan"].thaw()
+            ops._PLAN = rec["plan"] if record else None
+            try:
+                io = given if given is not None else self.get_init_output(data=data, model=model)
+                self.chain_of_transforms = self.optimizing_transform(
+                    data=data, model=model, init_output=io, n_iter=n_iter, optimize_flags=optimize_flags,
+                    step_sizes=step_sizes)
+            finally:
+                ops._PLAN = None
+            if record:
+                rec["plan"].end_record()
+                self.graph_stats["recorded"] += 1
+                if rec["state"] == "record" and rec["plan"].calls >= max(1, int(self.hip_graph_record_calls)):
+                    rec["state"] = "capture"
+            return io
+
+        self._redo_ascent = lambda: ordinary(True)
+        if rec["state"] == "record":
+            return ordinary(True), None
+        if rec["state"] == "off":
+            return ordinary(False), None
+        if rec["state"] == "capture":
+            try:
+                self._capture_ascent(rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes)
+                rec["state"] = "replay"
+            except Exception as exc:         # not capturable after all (the model, most likely): the ordinary path from now on
+                logging.warning('advchain_amd: hipGraph capture of the ascent loop failed (%s: %s); running it the ordinary way',
+                                type(exc).__name__, exc)
+                rec["state"], rec["graph"] = "off", None
+                return ordinary(False), None
+        # replay
+        if data.data_ptr() != rec["data"].data_ptr():
+            rec["data"].copy_(data)
+        if given is not None and given.data_ptr() != rec["init_output"].data_ptr():
+            rec["init_output"].copy_(given)
+        for sp, p in zip(rec["params"], init_params):
+            sp.copy_(p)
+        model.zero_grad()
+        rec["graph"].replay()
+        rec["flag_host"].copy_(rec["plan"].flag, non_blocking=True)
+        rec["event"].record(ops._stream_obj())
+        self.graph_stats["replays"] += 1
+        for t, state, op in zip(rec["transforms"], rec["attrs"], rec["out_params"]):
+            t.__dict__.update(state)
+            t.param = op.clone()
+        self.chain_of_transforms = list(rec["transforms"])
+        self.last_inner_dist = rec["out_last_inner"].clone()
+        io = given if given is not None else rec["out_init_output"].clone()
+
+        def held():
+            rec["event"].synchronize()
+            if int(rec["flag_host"][0]) == 0:
+                return True
+            self.graph_stats["violations"] += 1
+            rec["violations"] = rec.get("violations", 0) + 1
+            rec["plan"].margin = min(2.0, rec["plan"].margin * 1.2)
+            rec["state"], rec["graph"] = ("record" if rec["violations"] < 6 else "off"), None     # captured again after this call's record
+            return False
+        return io, held
+
+    def _capture_ascent(self, rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes):
+        plan = rec["plan"]
+        rec["data"] = data.detach().clone()
+        rec["init_output"] = None if given is None else given.detach().clone()
+        rec["params"] = [p.clone() for p in init_params]
+        rec["keep"] = [getattr(t, "_tables", None) for t in chain] + [model]      # what the graph's pointers refer to
+        rec["flag_host"] = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        rec["event"] = torch.cuda.Event()
+        for t, p in zip(chain, rec["params"]):
+            t.param = p
+        self.chain_of_transforms = chain
+        plan.freeze(data.device)
+        graph = torch.cuda.CUDAGraph()
+        ops._PLAN = plan
+        try:
+            with torch.cuda.graph(graph):
+                plan.flag.zero_()
+                io = rec["init_output"] if given is not None else self.get_init_output(data=rec["data"], model=model)
+                transforms = self.optimizing_transform(data=rec["data"], model=model, init_output=io, n_iter=n_iter,
+                                                       optimize_flags=optimize_flags, step_sizes=step_sizes)
+        finally:
+            ops._PLAN = None
+        if plan.cursor != len(plan.frozen):
+            raise ops.PlanMismatch("launch plan: the capture visited %d of %d recorded sites" % (plan.cursor, len(plan.frozen)))
+        rec["graph"] = graph
+        rec["transforms"] = list(transforms)
+        rec["out_params"] = [t.param.detach() for t in transforms]
+        # the plain attributes the loop leaves on the transforms (is_training, power_iteration, ...): restored after a replay
+        rec["attrs"] = [{k: v for k, v in vars(t).items() if self._plain(v) is not None} for t in transforms]
+        rec["out_init_output"] = io
+        rec["out_last_inner"] = self.last_inner_dist
+        self.graph_stats["captures"] += 1
+
 
     @property
     def diffs(self):

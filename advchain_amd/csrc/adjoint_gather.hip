@@ -545,6 +545,17 @@ __global__ void __launch_bounds__(kBlock) k_slot_rows_max(float* __restrict__ sl
   }
 }
 
+// flag[0] |= 1 when some v[i] is outside [lo[i], hi[i]) (a NaN is outside): the premise check of a replayed launch plan
+__global__ void __launch_bounds__(64) k_bounds_check(const float* __restrict__ v, const float* __restrict__ lo,
+                                                     const float* __restrict__ hi, int n, int* __restrict__ flag) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const float x = v[i];
+    bad = bad || !(x >= lo[i] && x < hi[i]);
+  }
+  if (__any(bad) && threadIdx.x == 0) atomicOr(flag, 1);
+}
+
 }  // namespace advchain
 
 using namespace advchain;
@@ -691,6 +702,15 @@ extern "C" int advchain_slot_rows_max(float* slots, float* out, int64_t rows, in
   ADVCHAIN_CHECK_ARG(rows >= 0 && rows < 65536 && cols >= 1 && cols < (1ll << 31), "slot_rows_max: bad shape");
   if (rows == 0) return ADVCHAIN_OK;
   hipLaunchKernelGGL(k_slot_rows_max, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols, reset);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+extern "C" int advchain_bounds_check(const float* values, const float* lo, const float* hi, int64_t n, int32_t* flag, void* stream) {
+  ADVCHAIN_CHECK_ARG(values && lo && hi && flag, "bounds_check: null pointer");
+  ADVCHAIN_CHECK_ARG(n >= 0 && n < (1ll << 20), "bounds_check: bad n");
+  if (n == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_bounds_check, dim3(1), dim3(64), 0, (hipStream_t)stream, values, lo, hi, (int)n, flag);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -285,7 +285,8 @@ k_compose_self_fwd(const float* __restrict__ phi, float* __restrict__ out, const
 // launch whatever k, because the host side of a small problem (cfg-1) pays for every launch it enqueues).  Otherwise the
 // missing levels k - deficit + 1 .. k are run here the ordinary way (compose_self_fwd_body<2, 2>: the same bits, also where
 // the fused kernel had got that far) on a small persistent grid, with a grid-wide barrier between two levels: every
-// workgroup of the grid is resident (the host asks for two per CU, eight fit), an arrival counter in device memory, and
+// workgroup of the grid is resident (the host sizes the grid per device from the occupancy of this kernel: at most half of
+// what the device holds at once, two per CU on MI355X where eight fit), an arrival counter in device memory, and
 // agent-scope fences either side so that what another XCD's L2 still holds is written back / read again.
 // `barrier`: one zero-initialised 32-bit counter per call (the word behind the flag).
 __global__ void __launch_bounds__(kBlock)
@@ -1196,14 +1197,21 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
         fused = k;
         const Dims d2 = make_dims(ndim, dims);
         const int nbx = advchain_blocks(d2.voxels(), kBlock * 2);
-        static int cus = 0;
-        if (!cus) {
-          int dev = 0;
-          (void)hipGetDevice(&dev);
+        // grid: at most HALF of what the CURRENT device holds at once (occupancy of this kernel x its CU count, cached per
+        // device) -- every workgroup of the grid is then resident together with room to spare, which the counter barrier needs
+        static int resident[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int& cap_wg = resident[dev & 63];
+        if (!cap_wg) {
+          int cus = 0, per_cu = 0;
           (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expo_repeat2d, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
           if (cus <= 0) cus = 64;
+          const int half = per_cu * cus / 2;
+          cap_wg = half > 2 * cus ? 2 * cus : (half < 1 ? 1 : half);
         }
-        const int64_t items = N * (int64_t)nbx, cap = 2 * (int64_t)cus;
+        const int64_t items = N * (int64_t)nbx, cap = cap_wg;
         hipLaunchKernelGGL(k_expo_repeat2d, dim3((unsigned)(items < cap ? items : cap)), dim3(kBlock), 0, (hipStream_t)stream,
                            phi0, fields, F, d2, k, (int)N, nbx, disp_rows, fuse_flag, reinterpret_cast<unsigned int*>(fuse_flag + 1));
         ADVCHAIN_LAUNCH_CHECK();

@@ -258,19 +258,24 @@ def _persistent_zeros(tag, shape, device):
     k runs before the producers of call k + 1 on the same stream."""
     stream = _raw_stream(_raw_device()) if (_raw_stream and _raw_device) else torch.cuda.current_stream().cuda_stream
     key = (tag, tuple(shape), str(device), stream)
-    buf = _PERSISTENT.get(key)
+    plan = _PLAN
+    # (a capture keeps its accumulators with its plan: they live in the graph's memory pool and die with it)
+    store = plan.persistent if (plan is not None and plan.is_frozen) else _PERSISTENT
+    buf = store.get(key)
     if buf is None:
-        if len(_PERSISTENT) > 64:
-            _PERSISTENT.clear()
-        buf = _PERSISTENT[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+        if len(store) > 64:
+            store.clear()
+        buf = store[key] = torch.zeros(shape, device=device, dtype=torch.float32)
     return buf
 
 
 def _forget_persistent(buf):
     """Drop a persistent accumulator whose producer ran but whose consumer did not (an exception in between): it may hold
     partial sums, and the next user must start from a fresh zero-filled buffer."""
-    for k in [k for k, v in _PERSISTENT.items() if v is buf]:
-        del _PERSISTENT[k]
+    stores = [_PERSISTENT] + ([_PLAN.persistent] if _PLAN is not None else [])
+    for store in stores:
+        for k in [k for k, v in store.items() if v is buf]:
+            del store[k]
 
 
 def raw_gauss_small_pair(x, scale, adjoint=False, weights=None):
@@ -317,11 +322,16 @@ _ONES = {}
 def cached_ones(shape, device):
     """A read-only tensor of ones (the input of the validity-mask warps): filled once per shape, never written."""
     key = (tuple(shape), str(device))
-    t = _ONES.get(key)
+    plan = _PLAN
+    store = plan.persistent if (plan is not None and plan.is_frozen) else _ONES
+    t = store.get(("ones",) + key) if store is not _ONES else _ONES.get(key)
     if t is None:
-        if len(_ONES) > 16:
-            _ONES.clear()
-        t = _ONES[key] = torch.ones(shape, device=device, dtype=torch.float32)
+        if store is _ONES:
+            if len(_ONES) > 16:
+                _ONES.clear()
+            t = _ONES[key] = torch.ones(shape, device=device, dtype=torch.float32)
+        else:       # (under capture: the fill is a node of the graph and the tensor lives in its pool)
+            t = store[("ones",) + key] = torch.ones(shape, device=device, dtype=torch.float32)
     return t
 
 
@@ -535,13 +545,192 @@ class _Readback:
         return self._vals
 
 
+
+# ------------------------------------------------------------------------------------------------
+# launch plans: the kernel selection of one solver call, recorded and then frozen (hipGraph replay)
+# ------------------------------------------------------------------------------------------------
+# The backward kernels are chosen from displacement bounds that the forward MEASURES and the host reads back (squaring_halo,
+# warp_halo); the 3D chain reads a whole-batch norm for the reference's step rule.  A captured hipGraph cannot read anything
+# back: a LaunchPlan records what those sites read during ordinary (eager) calls, freezes the values with a margin, and the
+# capture takes every selection from the frozen plan.  Each site then enqueues advchain_bounds_check on what the replay
+# measures against the interval its frozen selection is exact for; a raised flag tells the caller (the solver) to run
+# that call again the ordinary way.  Results of a replay whose flag stays down are those of the ordinary path with the
+# same selection (every formulation is tested against every other; the selection never changes values beyond that).
+_PLAN = None
+
+
+class PlanMismatch(RuntimeError):
+    """The launch sequence met during a capture is not the recorded one."""
+
+
+class _FrozenBounds(object):
+    """Stands in for a _Readback when the plan is frozen: the bounds are host numbers known before the launch."""
+
+    class _Done(object):
+        @staticmethod
+        def query():
+            return True
+
+        @staticmethod
+        def synchronize():
+            return None
+
+    event = _Done
+
+    def __init__(self, vals):
+        self._vals = [float(v) for v in vals]
+
+    def values(self):
+        return self._vals
+
+
+def _halo_threshold(h):
+    """The displacement below which the bound `h` (squaring_halo / warp_halo) is exact; inf for a hint."""
+    if h == -1:
+        return 0.999
+    if h < 0:
+        return -h - 0.001
+    return float("inf")
+
+
+def _warp_halo_of(est, d):
+    if not est == est:
+        return 0
+    if d == 3:
+        return -1 if est < 0.999 else _halo_3d(est)
+    return _halo_2d(est)
+
+
+class LaunchPlan(object):
+    """recording: sites append what they read (note); end_record() turns the read-backs into numbers and merges them with
+    the calls recorded before (element-wise max).  freeze(): numbers x margin -> per-site selections + device intervals.
+    frozen: take() hands the sites out in call order, check() enqueues the premise check."""
+
+    def __init__(self, margin=1.25):
+        self.margin = float(margin)
+        self.pending = []        # this call's sites while recording: (kind, payload)
+        self.recorded = None     # merged: list of (kind, dict of numbers)
+        self.calls = 0
+        self.unstable = False    # two recorded calls did not visit the same sites
+        self.frozen = None
+        self.cursor = 0
+        self.flag = None
+        self.persistent = {}
+
+    @property
+    def is_frozen(self):
+        return self.frozen is not None
+
+    # -- recording
+    def thaw(self):
+        """Back to recording (the frozen selection and whatever an interrupted call left pending are dropped)."""
+        self.frozen = None
+        self.pending = []
+        self.persistent = {}
+
+    def note(self, kind, **payload):
+        self.pending.append((kind, payload))
+
+    def end_record(self):
+        sites = []
+        for kind, pl in self.pending:
+            if kind == "chain":
+                sites.append((kind, {"n": pl["n"], "d": pl["d"], "vals": [float(v) for v in pl["rb"].values()]}))
+            elif kind == "nsteps":
+                sites.append((kind, {"n": pl["n"], "n_base": pl["n_base"]}))
+            elif kind == "warp":
+                sites.append((kind, {"d": pl["d"], "vals": [float(pl["rb"].values()[pl["idx"]])]}))
+        self.pending = []
+        if self.recorded is None:
+            self.recorded = sites
+        elif [(k, v.get("n"), v.get("d")) for k, v in sites] != [(k, v.get("n"), v.get("d")) for k, v in self.recorded]:
+            self.unstable = True          # (another step count, another number of sites): the latest call wins
+            self.recorded = sites
+        else:
+            for (_, old), (_, new) in zip(self.recorded, sites):
+                if "vals" in old:
+                    old["vals"] = [b if (b != b or b > a) else a for a, b in zip(old["vals"], new["vals"])]
+        self.calls += 1
+        self.frozen = None
+
+    # -- freezing
+    def freeze(self, device):
+        import numpy as np
+        los, his, sites = [], [], []
+        for kind, rec in self.recorded:
+            if kind == "chain":
+                n, d = rec["n"], rec["d"]
+                vals = [v * self.margin if v == v else v for v in rec["vals"]]
+                thr = [_halo_threshold(squaring_halo(vals[m], d)) for m in range(n)]
+                thr.append(_halo_threshold(_warp_halo_of(vals[n], d)))
+                thr += [float("inf")] * (len(vals) - n - 1)
+                site = {"kind": kind, "n": n, "d": d, "bounds": _FrozenBounds(vals), "off": len(los), "len": len(thr)}
+                los += [-float("inf")] * len(thr)
+                his += thr
+            elif kind == "nsteps":
+                n, nb = rec["n"], rec["n_base"]
+                # the rule of adv_morph.py:159-162 on sqrt(sum u^2): n is the smallest count >= n_base with norm / 2^n <= 0.5
+                # (norm in (2^(n-2), 2^(n-1)]; as the half-open interval [lo, hi) of fp32 numbers the check kernel takes)
+                up = lambda x: float(np.nextafter(np.float32(x), np.float32(np.inf)))
+                hi = up(2.0 ** (n - 1))
+                lo = up(2.0 ** (n - 2)) if n > nb else -float("inf")
+                site = {"kind": kind, "n": n, "n_base": nb, "off": len(los), "len": 1}
+                los.append(lo)
+                his.append(hi)
+            else:
+                d = rec["d"]
+                est = rec["vals"][0] * self.margin
+                site = {"kind": kind, "d": d, "bounds": _FrozenBounds([est]), "off": len(los), "len": 1}
+                los.append(-float("inf"))
+                his.append(_halo_threshold(_warp_halo_of(est, d)))
+            sites.append(site)
+        f32 = torch.float32
+        lo_t = torch.tensor(los or [0.0], dtype=f32).clamp(-3.0e38, 3.0e38).to(device)
+        hi_t = torch.tensor(his or [0.0], dtype=f32).to(device)      # (inf stays inf: x < inf holds for every finite x)
+        for sdict in sites:
+            sdict["lo"] = lo_t[sdict["off"]:sdict["off"] + sdict["len"]]
+            sdict["hi"] = hi_t[sdict["off"]:sdict["off"] + sdict["len"]]
+        self.flag = torch.zeros(1, device=device, dtype=torch.int32)
+        self.frozen = sites
+        self.cursor = 0
+        self.persistent = {}
+
+    # -- frozen
+    def rewind(self):
+        self.cursor = 0
+
+    def take(self, kind, **expect):
+        if self.cursor >= len(self.frozen):
+            raise PlanMismatch("launch plan: more %s sites than recorded" % kind)
+        site = self.frozen[self.cursor]
+        self.cursor += 1
+        if site["kind"] != kind or any(site.get(k) != v for k, v in expect.items()):
+            raise PlanMismatch("launch plan: met a %s site %r where a %s site was recorded" % (kind, expect, site["kind"]))
+        return site
+
+    def check(self, values, site):
+        if values.numel() != site["len"]:
+            raise PlanMismatch("launch plan: %d measured values for a site of %d" % (values.numel(), site["len"]))
+        _lib.check(_lib.load().advchain_bounds_check(_ptr(values), _ptr(site["lo"]), _ptr(site["hi"]), site["len"],
+                                                     ctypes.c_void_p(self.flag.data_ptr()), _stream()), "bounds_check")
+
+
 def grid_displacement(grid):
     """Max displacement (voxels) of a sampling grid, measured once per grid tensor (the entry -- a 1-float device tensor
     and, after the first read-back, its host value -- rides on the tensor object: the same deformation warps the image
     and then the prediction)."""
     hit = getattr(grid, "_advchain_disp", None)
     if hit is None or hit[2] != grid._version:
-        hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, (str(grid.device),) + tuple(grid.shape[2:])]
+        plan = _PLAN
+        key = (str(grid.device),) + tuple(grid.shape[2:])
+        if plan is not None and plan.is_frozen:        # frozen plan: the recorded bound, and the premise check on the measured one
+            site = plan.take("warp", d=grid.dim() - 2)
+            plan.check(raw_max_displacement(grid.detach()), site)
+            hit = [site["bounds"], None, grid._version, 0, None]
+        else:
+            hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, key]
+            if plan is not None:
+                plan.note("warp", rb=hit[0], idx=0, d=grid.dim() - 2)
         grid._advchain_disp = hit
     return hit
 
@@ -554,7 +743,7 @@ def forward_hint(grid):
     if hit is not None and hit[2] == grid._version:
         if hit[1] is None and hit[0].event.query():
             hit[1] = float(hit[0].values()[hit[3]])
-            if len(hit) > 4:
+            if len(hit) > 4 and hit[4] is not None:
                 _WARP_HINTS[hit[4]] = hit[1]
         if hit[1] is not None:
             return hit[1]
@@ -567,13 +756,9 @@ def warp_halo(entry, d):
     if entry[1] is None:
         entry[1] = float(entry[0].values()[entry[3]])
     est = entry[1]
-    if len(entry) > 4:
+    if len(entry) > 4 and entry[4] is not None:
         _WARP_HINTS[entry[4]] = est
-    if not est == est:
-        return 0
-    if d == 3:
-        return -1 if est < 0.999 else _halo_3d(est)
-    return _halo_2d(est)
+    return _warp_halo_of(est, d)
 
 
 class _GridSample(torch.autograd.Function):
@@ -918,6 +1103,8 @@ class _DemonsField(torch.autograd.Function):
             s1 = raw_gauss(s1, d, weights=w9)
         N = s1.shape[0]
         n = int(n_base)
+        plan = _PLAN
+        frozen = plan is not None and plan.is_frozen
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
             slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
             # pair: the batch is [v; -v] -- the rule is the reference's, over ONE field's batch (both halves agree)
@@ -925,9 +1112,16 @@ class _DemonsField(torch.autograd.Function):
             ss = slots.sum().reshape(1)
             if reduce_sumsq is not None:
                 ss = reduce_sumsq(ss)
-            norm = float(ss.sqrt().item())
-            while norm / (2.0 ** n) > 0.5:
-                n += 1
+            if frozen:       # the recorded count; the replay checks on the device that the rule still gives it
+                site = plan.take("nsteps", n_base=n)
+                n = site["n"]
+                plan.check(ss.sqrt(), site)
+            else:
+                norm = float(ss.sqrt().item())
+                while norm / (2.0 ** n) > 0.5:
+                    n += 1
+                if plan is not None:
+                    plan.note("nsteps", n=n, n_base=int(n_base))
         inv = 1.0 / (2.0 ** n)
         # row m of `disp`: max-slots for the displacement of phis[m], written by the kernel that produces it; row n: the
         # sampling positions `pos`, which bound the returned grid (clipping to [-1,1] and the normalised Gaussian only
@@ -942,25 +1136,47 @@ class _DemonsField(torch.autograd.Function):
         # of step i resembles step i of the previous call -- 0.14 / 0.20 / 0.24 / 0.32 px after steps 1..4 at cfg-2 against 0.03
         # for a fresh draw -- far better than it resembles step i - 1 of this call)
         key = (str(s1.device), tuple(s1.shape), n, HINT_SLOT)
-        pend = _PENDING_BOUNDS.pop(key, None)      # a chain whose backward never ran (the final pass): its read-back, if it has arrived
-        if pend is not None and pend.event.query():
-            _note_chain_bounds(key, pend.values(), n)
-        hints = _CHAIN_HINTS.get(key)
+        site = None
+        if frozen:           # every selection of this chain from the plan (its own recorded displacements, with the margin)
+            if disp is None:
+                raise PlanMismatch("launch plan: a frozen chain needs the measured displacements (ADVCHAIN_NO_ADAPTIVE_HALO is set)")
+            site = plan.take("chain", n=n, d=d)
+            hints = site["bounds"].values()
+        else:
+            pend = _PENDING_BOUNDS.pop(key, None)      # a chain whose backward never ran (the final pass): its read-back, if it has arrived
+            if pend is not None and pend.event.query():
+                _note_chain_bounds(key, pend.values(), n)
+            hints = _CHAIN_HINTS.get(key)
         phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
         fields = torch.empty((n - 1,) + tuple(phi0.shape), device=phi0.device, dtype=torch.float32)
         pos = torch.empty_like(phi0)
         harr = None if hints is None else (ctypes.c_int32 * n)(*[(_hint_bits(hints[m]) >> 8) | (_fine_bits(hints[m]) << 8)
                                                                  for m in range(n)])
-        _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
-                                                       _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
-                                                       None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
-                   "expo_chain_fwd")
-        q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
+        try:
+            _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
+                                                           _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
+                                                           None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
+                       "expo_chain_fwd")
+            q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
+            rows_max = None if disp is None else raw_slot_rows_max(disp, reset=True)
+        except BaseException:
+            # (the slots, the fused-chain flag and its barrier counter may hold partial state: the next chain starts from a
+            # fresh zero-filled accumulator)
+            if disp is not None:
+                _forget_persistent(disp)
+            raise
         ctx.save_for_backward(pos, phi0, fields)
-        ctx.disp = None if disp is None else _Readback(raw_slot_rows_max(disp, reset=True))
-        if ctx.disp is not None:
-            _PENDING_BOUNDS[key] = ctx.disp
+        ctx.frozen = site is not None
+        if site is not None:
+            plan.check(rows_max, site)
+            ctx.disp = site["bounds"]
+        else:
+            ctx.disp = None if rows_max is None else _Readback(rows_max)
+            if ctx.disp is not None:
+                _PENDING_BOUNDS[key] = ctx.disp
+                if plan is not None:
+                    plan.note("chain", rb=ctx.disp, n=n, d=d)
         global _LAST_FIELD_BOUND
         _LAST_FIELD_BOUND = None if ctx.disp is None else (ctx.disp, n)
         ctx.cfg = (scale, tables, inv, d)
@@ -990,8 +1206,9 @@ class _DemonsField(torch.autograd.Function):
         n = ctx.nsteps
         if ctx.disp is not None:
             dm = ctx.disp.values()
-            _PENDING_BOUNDS.pop(ctx.hint_key, None)
-            _note_chain_bounds(ctx.hint_key, dm, n)
+            if not ctx.frozen:
+                _PENDING_BOUNDS.pop(ctx.hint_key, None)
+                _note_chain_bounds(ctx.hint_key, dm, n)
             halos = [squaring_halo(dm[m], d) for m in range(n - 1, -1, -1)]
         else:
             big = 2 if d == 3 else 16
@@ -1050,6 +1267,11 @@ _CHAIN_HINTS = _HintCache()     # (device, velocity shape, n, slot) -> displacem
 _WARP_HINTS = _HintCache()      # (device, spatial dims) -> displacement of the last grid of that shape whose bound was read
 
 
+def _ride_key(rb, q):
+    """Key of the global warp-hint table for a bound riding on grid `q` (None: a frozen plan's bound is not a measurement)."""
+    return None if isinstance(rb, _FrozenBounds) else (str(q.device),) + tuple(q.shape[2:])
+
+
 @_on_tensor_device
 def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
     global _LAST_FIELD_BOUND
@@ -1060,7 +1282,7 @@ def demons_field(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=None):
         return q
     if _LAST_FIELD_BOUND is not None:      # the displacement bound rides on the grid: no second measurement by the warps
         rb, idx = _LAST_FIELD_BOUND
-        q._advchain_disp = [rb, None, q._version, idx, (str(q.device),) + tuple(q.shape[2:])]
+        q._advchain_disp = [rb, None, q._version, idx, _ride_key(rb, q)]
         _LAST_FIELD_BOUND = None
     return q
 
@@ -1118,8 +1340,8 @@ def demons_field_pair(vel, scale, tables, nsteps_rule, reduce_sumsq=None, opts=N
     qp, qm = _DemonsField.apply(vel, float(scale), tables, bool(nsteps_rule), reduce_sumsq, True, opts)
     if _LAST_FIELD_BOUND is not None:      # one bound for both halves (the max over the pair: still exact)
         rb, idx = _LAST_FIELD_BOUND
-        qp._advchain_disp = [rb, None, qp._version, idx, (str(qp.device),) + tuple(qp.shape[2:])]
-        qm._advchain_disp = [rb, None, qm._version, idx, (str(qm.device),) + tuple(qm.shape[2:])]
+        qp._advchain_disp = [rb, None, qp._version, idx, _ride_key(rb, qp)]
+        qm._advchain_disp = [rb, None, qm._version, idx, _ride_key(rb, qm)]
         _LAST_FIELD_BOUND = None
     return qp, qm
 

@@ -149,6 +149,12 @@ int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim,
 /* reset != 0: the slots are zeroed after they are read, so that one persistent accumulator serves every chain (no
  * zero-fill launch per chain). */
 int advchain_slot_rows_max(float* slots, float* out, int64_t rows, int64_t cols, int reset, void* stream);
+/* Premise check of a replayed launch plan (hipGraph replay of a solver call, INTEGRATION.md "Graph replay"): the reference
+ * has no counterpart -- its ATen call sites (adv_morph.py:116-202, 546-557) do not choose between formulations.  The backward
+ * kernels above are chosen from displacement bounds; a replayed plan froze that choice, and this entry compares what the
+ * replay measures (`values`: advchain_slot_rows_max / advchain_max_displacement output, or the 3D step-rule norm of
+ * adv_morph.py:159-162) with the frozen interval: flag[0] |= 1 when some values[i] is outside [lo[i], hi[i]) or NaN.  */
+int advchain_bounds_check(const float* values, const float* lo, const float* hi, int64_t n, int32_t* flag, void* stream);
 
 /* ---- affine warp -----------------------------------------------------------------------
  * replaces: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(...),
