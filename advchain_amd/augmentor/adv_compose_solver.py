@@ -155,6 +155,7 @@ class ComposeAdversarialTransformSolver(object):
             init_output = self._redo_ascent()
             dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
                 data.detach(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
+        self._redo_ascent = None        # (a closure over this call's tensors and over self: no cycle is left behind)
         self.init_output = init_output
         self.warped_back_adv_output = warped_back_adv_output
         self.origin_data = data
@@ -299,6 +300,12 @@ class ComposeAdversarialTransformSolver(object):
         plan.freeze(data.device)
         graph = torch.cuda.CUDAGraph()
         ops._PLAN = plan
+        # the cyclic collector stays out of the capture: it may free another CUDAGraph (an earlier solver's, kept alive by a
+        # reference cycle until now), and destroying a graph or returning its pool while a capture is open aborts the process
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             with torch.cuda.graph(graph):
                 plan.flag.zero_()
@@ -307,6 +314,8 @@ class ComposeAdversarialTransformSolver(object):
                                                        optimize_flags=optimize_flags, step_sizes=step_sizes)
         finally:
             ops._PLAN = None
+            if gc_was_on:
+                gc.enable()
         if plan.cursor != len(plan.frozen):
             raise ops.PlanMismatch("launch plan: the capture visited %d of %d recorded sites" % (plan.cursor, len(plan.frozen)))
         rec["graph"] = graph

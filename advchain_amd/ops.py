@@ -606,7 +606,7 @@ class LaunchPlan(object):
     the calls recorded before (element-wise max).  freeze(): numbers x margin -> per-site selections + device intervals.
     frozen: take() hands the sites out in call order, check() enqueues the premise check."""
 
-    def __init__(self, margin=1.25):
+    def __init__(self, margin=1.1):
         self.margin = float(margin)
         self.pending = []        # this call's sites while recording: (kind, payload)
         self.recorded = None     # merged: list of (kind, dict of numbers)

@@ -175,7 +175,8 @@ def build_solver(wl, device, process_group=None):
     chain = [cls[nm](spatial_dims=sd, config_dict=cfg, device=device)
              for nm, cfg in transform_configs(wl["dims"], wl["batch"], wl["chain"], morph_div8=wl.get("anatomy", False))]
     return ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
-                                             divergence_weights=[1.0, 0.5], process_group=process_group)
+                                             divergence_weights=[1.0, 0.5], process_group=process_group,
+                                             hip_graph=HIP_GRAPH and process_group is None)
 
 
 def solver_kwargs(wl, device):
@@ -252,26 +253,36 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         torch.cuda.synchronize()
 
     lib = _lib.load()
-    # warm-up; the first warm-up step is instrumented on every entry point to find the dominant kernel -- after one
-    # cold step of its own (first launches include code-object loading and would be booked to whichever entry runs first)
+    graphed = bool(solver.hip_graph)
+
+    @contextlib.contextmanager
+    def ordinary():
+        """The instrumented passes need the Python-side launches: a replayed graph makes no C-ABI call that could carry events."""
+        solver.hip_graph = False
+        try:
+            yield
+        finally:
+            solver.hip_graph = graphed
+    # warm-up; one warm-up step is instrumented on every entry point to find the dominant kernel -- after one cold step of
+    # its own (first launches include code-object loading and would be booked to whichever entry runs first).  With
+    # solver.hip_graph the warm-up also holds the calls that record the launch plan and the capture (at least 4 steps).
     dominant = None
-    step()
-    torch.cuda.synchronize()
-    for i in range(max(1, warmup)):
-        if i == 0:
-            lib.records = []
-            with lib.timed():
-                step()
-            torch.cuda.synchronize()
-            tot = {}
-            for name, a, e0, e1 in lib.records:
-                if algorithmic_bytes(name, a) is None:
-                    continue
-                tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
-            dominant = max(tot, key=tot.get) if tot else None
-            breakdown = {k.replace("advchain_", ""): round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-        else:
+    with ordinary():
+        step()
+        torch.cuda.synchronize()
+        lib.records = []
+        with lib.timed():
             step()
+        torch.cuda.synchronize()
+    tot, abi_calls = {}, len(lib.records)
+    for name, a, e0, e1 in lib.records:
+        if algorithmic_bytes(name, a) is None:
+            continue
+        tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
+    dominant = max(tot, key=tot.get) if tot else None
+    breakdown = {k.replace("advchain_", ""): round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+    for i in range(max(warmup - 1, 4 if graphed else 0)):
+        step()
     # timed region: exactly K steps between barrier+sync; only the dominant entry point carries events.  The cyclic
     # garbage collector is parked for it, as timeit does: one generation-2 pass (~40-60 ms with torch loaded) would
     # otherwise land inside a 20-step run at random and move the result by 15 %.
@@ -287,22 +298,56 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
             n_coll[0] += 1
             return orig_all_reduce(*a, **k)
         dist.all_reduce = counted_all_reduce
+    stats0 = dict(solver.graph_stats)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one event per step boundary (GPU-side span of a step)
     sync()
     t0 = time.perf_counter()
-    with lib.timed([dominant] if dominant else [], every=1 if dominant in CHAIN_ENTRIES else 5):   # one call in five carries an event pair (every call of a chain entry: it is 8+ launches)
-        for _ in range(steps):
+    # ordinary path: one call in five of the dominant entry carries an event pair (every call of a chain entry: it is 8+
+    # launches); replayed graphs: nothing can be instrumented inside -- the roofline comes from ordinary steps afterwards
+    with lib.timed([dominant] if (dominant and not graphed) else [], every=1 if dominant in CHAIN_ENTRIES else 5):
+        marks[0].record()
+        for i in range(steps):
             step()
+            marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
     gc.enable()
     extras = {}
+    # GPU-side span of the timed steps: first to last boundary event on the launch stream.  Host-bound steps show up as
+    # ms_per_step well above it only at the ends of the region; INSIDE it the two agree by construction, so the honest
+    # host-boundness figure is the comparison with the ordinary path below (`ordinary_ms_per_step`) and with rocprof's
+    # kernel-busy time (profiles/)
+    extras["gpu_span_ms_per_step"] = round(marks[0].elapsed_time(marks[-1]) / steps, 3)
+    extras["abi_calls_per_step"] = abi_calls
+    if graphed:
+        st = solver.graph_stats
+        extras["hip_graph"] = {"replays": st["replays"] - stats0["replays"], "violations": st["violations"] - stats0["violations"],
+                               "captures": st["captures"], "recorded_calls": st["recorded"], "refused": st["refused"] - stats0["refused"],
+                               "note": "the prediction + the ascent steps of every timed call are ONE hipGraph replay; the final "
+                                       "consistency-loss pass is dispatched the ordinary way behind it"}
+        if extras["hip_graph"]["replays"] == 0:
+            graphed = False                 # (nothing was replayed -- the anatomy ladder, a capture that failed: the ordinary path was timed)
+    if graphed and not PROFILING_RUN:
+        # the same steps dispatched launch by launch (what the product does without hip_graph), for comparison; the dominant
+        # entry carries its event pairs here
+        k_ord = max(3, min(steps, 10))
+        lib.records = []
+        with ordinary():
+            step()
+            sync()
+            t1 = time.perf_counter()
+            with lib.timed([dominant] if dominant else [], every=1 if dominant in CHAIN_ENTRIES else 5):
+                for _ in range(k_ord):
+                    step()
+            sync()
+            extras["ordinary_ms_per_step"] = round((time.perf_counter() - t1) / k_ord * 1e3, 3)
     if world > 1:
         dist.all_reduce = orig_all_reduce
         extras["all_reduces_per_step"] = round(n_coll[0] / float(steps), 2)
     # model / path split: an instrumented pass of a few steps after the timed region (events around the model's forward
     # and backward calls only; the solver's own kernels carry none)
     k_split = 0 if PROFILING_RUN else max(1, min(steps, 5))       # (a profiling run holds the timed workload and nothing else)
-    with _ModelTimer(solver) as mt:
+    with ordinary(), _ModelTimer(solver) as mt:        # (the timer wraps the Python-side model calls: ordinary steps)
         for _ in range(k_split):
             step()
     model_ms = mt.total_ms() / max(k_split, 1)
@@ -329,7 +374,9 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         dominant = CHAIN_ENTRIES.get(dominant, (dominant,))[0]
         traffic, source = profiled_traffic(workload, dominant)
         durs = [0] * nl
-        roof = {"bound": "hbm", "kernel": dominant.replace("advchain_", ""), "achieved": round(achieved, 1),
+        roof = {"timed_in": ("%d ordinary steps after the timed region (a replayed graph cannot carry events)" % k_ord) if "ordinary_ms_per_step" in extras
+                else "the timed region",
+                "bound": "hbm", "kernel": dominant.replace("advchain_", ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": source,
                 "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
@@ -551,6 +598,7 @@ def run_stub(steps, warmup, rank, world):
 
 
 PROFILING_RUN = False                   # --only-workload
+HIP_GRAPH = True                        # --no-graph: every step dispatched launch by launch from Python (the ordinary path)
 SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
 
 
@@ -573,13 +621,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="dispatch every step launch by launch from Python (solver.hip_graph off); default: the ascent loop "
+                         "of a step is one hipGraph replay")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 3D configs timed after the headline workload")
     ap.add_argument("--only-workload", action="store_true",
                     help="profiling runs: the chosen workload and nothing else (no secondary configs, no north-star "
                          "kernel pair, no CPU baseline)")
     args = ap.parse_args()
-    global PROFILING_RUN
+    global PROFILING_RUN, HIP_GRAPH
     PROFILING_RUN = bool(args.only_workload)
+    HIP_GRAPH = not args.no_graph
     stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -627,6 +679,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rec["workload"], "global_batch": rec["global_batch"],
                        "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
+                       "dispatch": "hipGraph replay of the ascent loop (solver.hip_graph)" if (HIP_GRAPH and world == 1 and not stub)
+                       else "launch by launch",
                        "segmentation_net": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},
             "roofline": roof,
             "kernel_time_ms_first_step": breakdown,
