@@ -43,6 +43,7 @@ PROTOTYPES = {
     "advchain_affine_grid2d_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
     "advchain_slot_rows_max": (_I, [_P, _P, _L, _L, _I, _P]),
     "advchain_bounds_check": (_I, [_P, _P, _P, _L, _P, _P]),
+    "advchain_expo_chain_fused_levels": (_I, [_L, _I, _P, _I, _P]),
     "advchain_expo_chain_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _P]),
     "advchain_expo_chain_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P]),
     "advchain_gauss_xy": (_I, [_P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _F, _P, _P, _L]),

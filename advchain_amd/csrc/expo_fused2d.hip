@@ -187,12 +187,13 @@ using namespace advchain;
 // the sum of the halos either side).  ADVCHAIN_ERR_UNSUPPORTED when the shape does not fit (rows must be a multiple of 64
 // pixels and at most 512, 16-byte aligned base pointers, a window of at most 64 KiB); otherwise the launch is enqueued and
 // `fail_flag` (one float, zero before the call) is raised by any workgroup whose window moves too far for one of its levels.
+// `query`: nothing is enqueued -- the return value says whether the shape would be taken (pointers are not looked at).
 int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, Dims d, int k, int halos, float* disp_rows,
-                                     float* fail_flag, hipStream_t stream) {
-  if (d.s0 != 1 || k < 1 || k > kFuseMaxLevels || !fail_flag) return ADVCHAIN_ERR_UNSUPPORTED;
+                                     float* fail_flag, hipStream_t stream, bool query) {
+  if (d.s0 != 1 || k < 1 || k > kFuseMaxLevels || (!fail_flag && !query)) return ADVCHAIN_ERR_UNSUPPORTED;
   const int W = d.s2;
   if (W % 64 != 0 || W > 512 || d.s1 < 8) return ADVCHAIN_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(phi0) | reinterpret_cast<uintptr_t>(fields)) & 15) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (!query && ((reinterpret_cast<uintptr_t>(phi0) | reinterpret_cast<uintptr_t>(fields)) & 15)) return ADVCHAIN_ERR_UNSUPPORTED;
   int HS = 0;
   for (int j = 0; j < k; ++j) {
     const int h = (halos >> (4 * j)) & 15;
@@ -212,6 +213,7 @@ int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N
   // a workgroup walks its k levels one after the other: with fewer workgroups than CUs (cfg-1: 8 fields x 12 windows) the k
   // small launches finish sooner than one long one
   if ((int64_t)grid.x * grid.y < 256) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (query) return ADVCHAIN_OK;
   hipLaunchKernelGGL((k_expo_fused_fwd2d<NT, PPW>), grid, dim3(NT), lds, stream, phi0, fields, F, d, k, TH, halos, disp_rows, fail_flag);
   return ADVCHAIN_OK;
 }

@@ -796,7 +796,7 @@ bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const
 
 // expo_fused2d.hip / adjoint_fused2d.hip: the sub-pixel squarings of a 2D chain in one launch (forward / backward)
 int advchain_expo_fused_fwd2d_launch(const float* phi0, float* fields, int64_t N, advchain::Dims d, int k, int halos,
-                                     float* disp_rows, float* fail_flag, hipStream_t stream);
+                                     float* disp_rows, float* fail_flag, hipStream_t stream, bool query = false);
 int advchain_adjoint_fused2d_launch(const float* gk, const float* phi0, const float* fields, float* g0, int64_t N, advchain::Dims d,
                                     int k, int32_t* workspace, hipStream_t st);
 // gather_tiled.hip
@@ -1160,6 +1160,38 @@ int advchain_affine_warp_fwd_ride(const float* in, const float* theta, float* ou
 
 // ---- the whole scaling-and-squaring chain in one call (the same launches as n calls of the two entries above; the host
 // side of a solver step is as long as its GPU side, and a chain is 2 x n of its ~700 launches)
+// How many leading squarings of a 2D chain the hints allow in one fused launch, and their row halos (4 bits a level): the
+// squarings whose hinted input displacement (bits 8.. of a hint: 1/1024 pixel) leaves a quarter of room below one pixel for
+// the field to grow between two ascent steps, and the squarings behind them while the window (the sum of the levels' row
+// halos either side) stays small: a level whose input moves less than h pixels takes its corners from h rows either side.
+static int fuse_rule(int n, const int32_t* hints, int fuse_max, int* halos_out) {
+  static const int hs_max = getenv("ADVCHAIN_FUSE2D_HS") ? atoi(getenv("ADVCHAIN_FUSE2D_HS")) : 5;   // A/B knob: rows of halo in all
+  int k = 0, halos = 0, hs = 0;
+  while (k < n - 1 && k < fuse_max && ((unsigned)hints[k] >> 8) != 0) {
+    const float e = (float)((unsigned)hints[k] >> 8) * (1.25f / 1024.f);
+    const int h = e < 1.f ? 1 : (int)e + 1;
+    if (h > 15 || hs + h > (hs_max > k + 1 ? hs_max : k + 1)) break;     // (sub-pixel levels always fit, as before)
+    halos |= h << (4 * k);
+    hs += h;
+    ++k;
+  }
+  *halos_out = halos;
+  return k;
+}
+
+static int fuse_max_levels() {
+  static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 5;   // A/B knob (0 = off)
+  return fuse_max;
+}
+
+int advchain_expo_chain_fused_levels(int64_t N, int ndim, const int64_t* dims, int n, const int32_t* hints) {
+  if (ndim != 2 || !hints || !dims_ok(ndim, dims) || n < 1 || n > 64 || fuse_max_levels() < 2) return 0;
+  int halos = 0;
+  const int k = fuse_rule(n, hints, fuse_max_levels(), &halos);
+  if (k < 2) return 0;
+  return advchain_expo_fused_fwd2d_launch(nullptr, nullptr, N, make_dims(ndim, dims), k, halos, nullptr, nullptr, nullptr, true) == ADVCHAIN_OK ? k : 0;
+}
+
 int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_t N, int ndim, const int64_t* dims, int n,
                             float* disp_rows, const int32_t* hints, float* fuse_flag, void* stream) {
   ADVCHAIN_CHECK_ARG(phi0 && pos && n >= 1 && n <= 64 && (n == 1 || fields), "expo_chain_fwd: null pointer / bad n");
@@ -1170,7 +1202,7 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
   // windows, bit-identical fields).  The kernel verifies the premise itself and raises *fuse_flag when a window moves too
   // far for some of its levels; ONE repeat launch behind it (k_expo_repeat2d) then runs exactly those levels the ordinary
   // way, and returns at once while the flag is down.
-  static const int fuse_max = getenv("ADVCHAIN_FUSE2D_MAX") ? atoi(getenv("ADVCHAIN_FUSE2D_MAX")) : 5;   // A/B knob (0 = off)
+  const int fuse_max = fuse_max_levels();
   int fused = 0;
   if (ndim == 2 && fuse_flag && hints && fuse_max >= 2) {
     // how many: the leading squarings whose hinted input displacement (bits 8.. of a hint: 1/1024 pixel) leaves a quarter
@@ -1178,16 +1210,8 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
     // repeated by the launch behind the fused kernel
     // ... and the squarings behind them while the window (the sum of the levels' row halos either side) stays small: a
     // level whose input moves less than h pixels takes its corners from h rows either side
-    static const int hs_max = getenv("ADVCHAIN_FUSE2D_HS") ? atoi(getenv("ADVCHAIN_FUSE2D_HS")) : 5;   // A/B knob: rows of halo in all
-    int k = 0, halos = 0, hs = 0;
-    while (k < n - 1 && k < fuse_max && ((unsigned)hints[k] >> 8) != 0) {
-      const float e = (float)((unsigned)hints[k] >> 8) * (1.25f / 1024.f);
-      const int h = e < 1.f ? 1 : (int)e + 1;
-      if (h > 15 || hs + h > (hs_max > k + 1 ? hs_max : k + 1)) break;     // (sub-pixel levels always fit, as before)
-      halos |= h << (4 * k);
-      hs += h;
-      ++k;
-    }
+    int halos = 0;
+    const int k = fuse_rule(n, hints, fuse_max, &halos);
     if (k >= 2) {
       const int rf = advchain_expo_fused_fwd2d_launch(phi0, fields, N, make_dims(ndim, dims), k, halos, disp_rows, fuse_flag,
                                                       (hipStream_t)stream);

@@ -1153,6 +1153,8 @@ class _DemonsField(torch.autograd.Function):
         pos = torch.empty_like(phi0)
         harr = None if hints is None else (ctypes.c_int32 * n)(*[(_hint_bits(hints[m]) >> 8) | (_fine_bits(hints[m]) << 8)
                                                                  for m in range(n)])
+        if COUNT_FUSED and harr is not None and disp is not None and FUSE_2D:      # (tests: which formulation the chain takes)
+            FUSE_STATS["fused_levels"] += _lib.load().advchain_expo_chain_fused_levels(phi0.shape[0], d, _lib.dims_array(phi0.shape[2:]), n, harr)
         try:
             _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
                                                            _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
@@ -1238,7 +1240,8 @@ class _DemonsField(torch.autograd.Function):
 
 _LAST_FIELD_BOUND = None
 HINT_SLOT = 0      # set by the solver: which step of its loop the next chain belongs to (keys the kernel-selection hints)
-FUSE_STATS = {"chains": 0, "refused": 0}     # chains whose backward read its bounds / whose fused forward squarings fell back
+FUSE_STATS = {"chains": 0, "refused": 0, "fused_levels": 0}     # chains whose backward read its bounds / whose fused forward squarings fell back / (COUNT_FUSED) squarings the forward chains ran fused
+COUNT_FUSED = False   # tests: ask advchain_expo_chain_fused_levels what every forward chain takes (one host call per chain)
 
 
 class _HintCache(dict):

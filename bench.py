@@ -242,8 +242,11 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     import contextlib
     import io
 
+    n_calls = [0]
+
     def step():
         # the solver prints like the reference does (anatomy ladder messages): keep stdout for the ONE JSON line
+        n_calls[0] += 1
         with contextlib.redirect_stdout(io.StringIO()):
             return solver.adversarial_training(data=data, model=model, **kw)
 
@@ -381,6 +384,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": source,
                 "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b)}
+    extras["solver_calls_in_process"] = n_calls[0]      # (per-call figures of a rocprof summary of this command divide by this)
     if world > 1:
         extras["rank_ms_per_step"] = _rank_spread(elapsed / steps * 1e3, world, device)
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

@@ -135,6 +135,11 @@ int advchain_compose_self_bwd(const float* grad_out, const float* phi, float* gr
  *      before the next call.
  * bwd: grad_pos -> grad_phi0 through the n adjoint steps; halos[i] is the bound for the i-th step in BACKWARD order
  *      (squaring n-1 first); scratch: one field-sized buffer; workspace as for advchain_compose_self_bwd.             */
+/* Query (host only, nothing is enqueued): how many leading squarings advchain_expo_chain_fwd would run as ONE fused launch for
+ * this shape and these hints (0: none -- 3D, no hints, fewer than 256 windows, rows that are not a multiple of 64 pixels ...;
+ * the pointer-alignment condition of the launch is not part of the answer).  Lets a caller / a test state which formulation
+ * a chain takes; the reference has no counterpart (adv_morph.py:132-135 is one loop).                                  */
+int advchain_expo_chain_fused_levels(int64_t N, int ndim, const int64_t* dims, int n, const int32_t* hints);
 int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_t N, int ndim, const int64_t* dims, int n,
                             float* disp_rows, const int32_t* hints, float* fuse_flag, void* stream);
 int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const float* fields, float* grad_phi0, float* scratch,

@@ -155,10 +155,12 @@ def test_demons_field_uses_the_fused_chain_and_matches():
     tabs = bands.upsample_tables(vs, list(dims), DEV)
     v = rand((N, 2) + tuple(vs), 21).to(DEV)
     v = v / v.reshape(N, -1).norm(dim=1).view(N, 1, 1, 1)
-    outs = {}
+    outs, levels = {}, {}
     for fuse in (False, True):
         ops.FUSE_2D = fuse
+        ops.COUNT_FUSED = True
         ops._CHAIN_HINTS.clear()
+        ops.FUSE_STATS["fused_levels"] = 0
         try:
             res = []
             for rep in range(2):
@@ -167,13 +169,24 @@ def test_demons_field_uses_the_fused_chain_and_matches():
                 (qp.sum() + 2 * qm.sum()).backward()          # (the backward records the hints the next forward uses)
                 res.append((qp.detach().clone(), qm.detach().clone(), vv.grad.clone()))
             outs[fuse] = res
+            levels[fuse] = ops.FUSE_STATS["fused_levels"]
         finally:
             ops.FUSE_2D = True
+            ops.COUNT_FUSED = False
     key = [k for k in ops._CHAIN_HINTS][0]
     assert ops._CHAIN_HINTS[key][-1] == 0.0          # the fuse flag rode back with the displacement rows: never raised
+    # the second evaluation really took the fused launch (advchain_expo_chain_fused_levels: the library's own answer for this
+    # shape and these hints), the first -- no hints yet -- and the FUSE_2D = False run did not
+    assert levels[True] >= 2 and levels[False] == 0, levels
     for a, b in zip(outs[False], outs[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+    # ... and the fused fields are the ORACLE's (pinned on the reference, tests/test_oracle_golden.py): DemonsCompose of
+    # +-1.5 v (adv_morph.py:454-491), un-clamped product field against the clamped one where it is inside
+    from oracle import advchain_oracle as O
+    for sign, q in ((1.0, outs[True][1][0]), (-1.0, outs[True][1][1])):
+        want = O.demons_compose(sign * 1.5 * v.cpu(), dims, final_clamp=True)
+        assert float((torch.clamp(q, -1, 1).cpu() - want).abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("dims", [(256, 256), (192, 192), (40, 64), (100, 128), (37, 320), (16, 24)])

@@ -173,7 +173,22 @@ def _teacher_forced(case, fx, solver, chain, meta, model, data, kw, n_steps, n_t
                 assert maxdiff(t.param.cpu(), p_ref) < TOL * max(1.0, float(p_ref.abs().max())), (case, k, ti, "param")
 
 
-G6L_CASES = ["2d_full_256", "3d_full_64", "3d_morph_40x40x80", "2d_cfg1_192", "3d_full_64_multivoxel", "2d_bma_256_n2"]
+G6L_CASES = ["2d_full_256", "3d_full_64", "3d_morph_40x40x80", "2d_cfg1_192", "3d_full_64_multivoxel", "2d_bma_256_n2",
+             "2d_full_256_n8"]
+
+
+def _parity_log(line):
+    """One line per g6l case and quantity: which jitter level the measured field difference selected and how much of its
+    allowance the worst coefficient used (committed per round under profiles/rNN/parity_levels.txt)."""
+    import os
+    path = os.environ.get("ADVCHAIN_PARITY_LOG",
+                          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_levels.txt"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line.rstrip() + "\n")
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("case", G6L_CASES)
@@ -211,6 +226,7 @@ def test_teacher_forced_step_at_realistic_size(case):
         levels = meta["jitter_levels"]
         lvl = min([i for i, a in enumerate(levels) if a >= fdiff] or [len(levels) - 1])
         morph_allow = lvl
+        _parity_log("%-24s field diff vs reference %.3e (normalised units) -> jitter level %d (%g)" % (case, fdiff, lvl, levels[lvl]))
     data = smooth_data(N, 1, dims, seed).to(DEV)
     model = make_model(sd, device=DEV)
     # ---- the ascent step through the product's own loop, gradients captured before the update
@@ -245,11 +261,16 @@ def test_teacher_forced_step_at_realistic_size(case):
             # gradient moves under a field difference of the size measured above (zero for most coefficients; round 3 used a
             # blanket 3e-4 of scale for the velocity gradient)
             diff = (captured[ti].cpu() - fx.t(gkey + "__full")).abs()
-            over = diff - (TOL * scale + 2.0 * fx.t(skey))
+            allow = TOL * scale + 2.0 * fx.t(skey)
+            over = diff - allow
+            _parity_log("%-24s step 0 %-6s grad: worst err / allowance %.3f; worst err %.3e of scale; %d of %d coefficients use more "
+                        "than the flat 1e-4 of scale" % (case, sp["name"], float((diff / allow).max()), float(diff.max()) / scale,
+                                                         int((diff > TOL * scale).sum()), diff.numel()))
             assert float(over.max()) < 0, (case, "%s grad: %d coefficients over, worst %.3e of scale (field diff %.2e, level %d)"
                                            % (sp["name"], int((over > 0).sum()), float(diff.max()) / scale, fdiff, lvl))
         else:
             err = compare_sampled(fx, gkey, captured[ti], 0)
+            _parity_log("%-24s step 0 %-6s grad: worst err / allowance %.3f (flat 1e-4 of scale)" % (case, sp["name"], err / (TOL * max(scale, 1e-12))))
             assert err < TOL * max(scale, 1e-12), (case, sp["name"], "grad err %.3e scale %.3e" % (err, scale))
         pkey = "param_out_%d" % ti
         if sp["name"] == "affine":      # sign(grad) is discontinuous at 0: compare where the reference gradient is clearly non-zero
@@ -302,6 +323,8 @@ def test_teacher_forced_step_at_realistic_size(case):
             diff = (captured[ti].cpu() - g_ref).abs()
             skey = "grad_spread_%d_%d" % (ti, len(meta["jitter_levels"]) - 1)     # (measured at step 0; theta_1 is close to theta_0)
             allow = TOL * scale + (2.0 * fx.t(skey) if skey in fx else 0.0)
+            _parity_log("%-24s step %d %-6s grad (teacher-forced): worst err / allowance %.3f; worst err %.3e of scale"
+                        % (case, k, sp["name"], float((diff / allow).max()), float(diff.max()) / scale))
             assert float((diff - allow).max()) < 0, (case, k, sp["name"], float(diff.max()) / scale)
             p_ref = fx.t("param_out_%d_s%d__full" % (ti, k))
             sel = g_ref.abs() > 1e-3 * scale if sp["name"] == "affine" else torch.ones_like(g_ref, dtype=torch.bool)
@@ -309,16 +332,34 @@ def test_teacher_forced_step_at_realistic_size(case):
     # ---- the whole call from the same start: final loss, adv_data, rescaled parameters
     for t, p in zip(chain, init):
         t.set_parameters(p)
-    with contextlib.redirect_stdout(io.StringIO()):
-        loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=True, step_sizes=1)
+    ops.COUNT_FUSED, ops.FUSE_STATS["fused_levels"] = True, 0
+    refused0 = ops.FUSE_STATS["refused"]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=True, step_sizes=1)
+    finally:
+        ops.COUNT_FUSED = False
+    if case == "2d_full_256_n8":
+        # 16 paired fields x 16 row windows: the chain of this run (hints: the step above) took the fused 2D squaring launch
+        # -- the default path of the headline workload against the reference's own numbers, and no window fell back
+        torch.cuda.synchronize()
+        assert ops.FUSE_STATS["fused_levels"] >= 2 and ops.FUSE_STATS["refused"] == refused0, ops.FUSE_STATS
     ref = fx.f("final_loss")
     loss_tol, data_tol, free = 1e-7 + TOL * abs(ref), TOL, meta.get("free_running_spread")
     if free is not None:
         # several free-running steps: the sign updates of the affine parameters flip under field differences of a few 1e-6
         # (chaos of the ascent, g6s_sensitivity.npz) -- the fixture holds how far the REFERENCE's own final loss and
-        # adv_data move at the field difference measured above; per-step parity is the teacher-forced part
-        loss_tol = max(loss_tol, 2.0 * free["final_loss"][lvl])
-        data_tol = max(data_tol, 2.0 * free["adv_data"][lvl])
+        # adv_data move when its fields are jittered; per-step parity is the teacher-forced part above.  Only the smallest
+        # jitter level is a usable bound (at the larger ones the reference's own adv_data moves by 0.94 on data in [0, 1]:
+        # anything would pass): with a field difference above it the free-running comparison is not made at all
+        _parity_log("%-24s free-running: jitter level %d; reference's own spread at that level: final loss %.2e, adv_data %.2e"
+                    % (case, lvl, free["final_loss"][lvl], free["adv_data"][lvl]))
+        if lvl > 0:
+            pytest.skip("%s: field difference %.2e selects jitter level %d: the reference's own free-running spread there "
+                        "(adv_data %.2e) bounds nothing -- per-step teacher-forced parity above is the test"
+                        % (case, fdiff, lvl, free["adv_data"][lvl]))
+        loss_tol = max(loss_tol, 2.0 * free["final_loss"][0])
+        data_tol = max(data_tol, 2.0 * free["adv_data"][0])
     assert abs(float(loss) - ref) < loss_tol, (float(loss), ref)
     assert compare_sampled(fx, "adv_data", solver.adv_data, 0) < data_tol
     for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):

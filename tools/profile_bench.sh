@@ -21,6 +21,16 @@ run cfg2 python $repo/bench.py --steps 10 --warmup 3 --only-workload
 run cfg3 python $repo/bench.py --workload cfg3 --steps 5 --warmup 2 --only-workload
 run cfg5 python $repo/bench.py --workload cfg5 --steps 3 --warmup 1 --only-workload
 run kb3d python $repo/tools/kernel_bench.py --shape 3d
-python $repo/tools/stats_per_call.py "$out/cfg2_kernel_stats.csv" 14 30
-python $repo/tools/stats_per_call.py "$out/cfg3_kernel_stats.csv" 8 30
-python $repo/tools/stats_per_call.py "$out/cfg5_kernel_stats.csv" 4 30
+# per-call figures: the number of adversarial_training calls the profiled command made is in ITS OWN json line
+# ("solver_calls_in_process"), not assumed here (round 4 divided cfg-5's 5 calls by 4)
+for w in cfg2 cfg3 cfg5; do
+  calls=$(python - "$out/${w}_under_rocprof.log" <<'PY'
+import json, sys
+for line in open(sys.argv[1]):
+    if line.startswith("{"):
+        print(json.loads(line)["solver_calls_in_process"])
+        break
+PY
+)
+  python $repo/tools/stats_per_call.py "$out/${w}_kernel_stats.csv" "$calls" 30
+done
