@@ -1075,33 +1075,35 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
   const float fix = rows2d_fix_scale(H);
   const float scale = gmax > 0.f ? fix / gmax : 0.f, inv = gmax / fix;
 
-  // ---- deposits: (row, segment) items, two per wave and round with their loads issued together
+  // ---- deposits: (row, 64-pixel segment) items, two per wave and round with their loads issued together.  The OWN rows
+  // first: their coordinate path (which needs nothing from the accumulator) is evaluated where the row is visited for its
+  // deposits -- taps built once, grid / grad_out loaded once (round 5: the second visit was a quarter of the vector-memory
+  // instructions of a workgroup, and this kernel is bound by their issue, lesson 4) -- then the halo rows above and below.
+  // Integer adds commute: the accumulator, and with it every output bit, is what the single loop over all rows left.
   constexpr int U = 2;
-  const int items = (yb - ya) * nseg;
-  for (int it0 = wave * U; it0 < items; it0 += NWV * U) {
-    float g[U][2], go[U][C];
-    int xs[U], ys[U];
+  constexpr int MAXO = 8;                         // own items per wave: TY * nseg / 8, capped by the launcher
+  const int oitems = (yend - y0) * nseg;
+  float ggv[MAXO][2];
+  auto visit = [&](int ys, int xs0, bool own, float (&g)[2], const float (&go)[C], float (&gg)[2]) {
+    const bool xin = xs0 < W;
+    bool pass[2] = {true, true};
+    if (clamp_grid) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int it = min(it0 + u, items - 1);
-      const int r = it / nseg;
-      ys[u] = ya + r;
-      xs[u] = (it - r * nseg) * 64 + lane;
-      const int s = ys[u] * W + min(xs[u], W - 1);
-      g[u][0] = gn[s];
-      g[u][1] = gn[V + s];
-#pragma unroll
-      for (int c = 0; c < C; ++c) go[u][c] = gon[(int64_t)c * V + s];
+      for (int a = 0; a < 2; ++a) { pass[a] = g[a] >= -1.f && g[a] <= 1.f; g[a] = clamp_unit(g[a]); }
     }
+    Taps<2, PAD> t;
+    t.y = make_tap<PAD>(g[1], d.s1);
+    const bool any = __ballot(xin && t.y.i0 + 1 >= y0 && t.y.i0 < yend) != 0;
+    if (!any && !(own && (SELF || GG))) return;
+    t.x = make_tap<PAD>(g[0], d.s2);
+    t.z.i0 = 0; t.z.w0 = 1.f; t.z.w1 = 0.f; t.z.mult = 0.f; t.z.v0 = true; t.z.v1 = false;
+    float vl[C][8];
+    if (own && (SELF || GG)) {                      // corner values requested ahead of the deposits
+      const CornerOffsets<2, PAD> o(t, d);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (it0 + u >= items) continue;                                 // wave-uniform
-      const bool xin = xs[u] < W;
-      if (clamp_grid) { g[u][0] = clamp_unit(g[u][0]); g[u][1] = clamp_unit(g[u][1]); }
-      Taps<2, PAD> t;
-      t.y = make_tap<PAD>(g[u][1], d.s1);
-      if (__ballot(xin && t.y.i0 + 1 >= y0 && t.y.i0 < yend) == 0) continue;
-      t.x = make_tap<PAD>(g[u][0], d.s2);
+      for (int c = 0; c < C; ++c) o.load(inn + (int64_t)c * V, vl[c]);
+    }
+    if (any) {
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) {
         const int py = t.y.i0 + cy;
@@ -1112,40 +1114,65 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
           const float wsc = (cx ? t.x.w1 : t.x.w0) * (cy ? t.y.w1 : t.y.w0) * scale;
           int* cell = acc + (py - y0) * W + t.x.i0 + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, __float2int_rn(wsc * go[u][c]));
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, __float2int_rn(wsc * go[c]));
         }
       }
     }
-  }
-  // ---- the coordinate path of the own samples needs nothing from the accumulator: before the barrier
-  const int oitems = (yend - y0) * nseg;
-  constexpr int MAXO = 8;                         // own items per wave: TY * nseg / 8 <= 32 * 4 / 8... capped by the launcher
-  float ggv[MAXO][2];
-  if (SELF || GG) {
-#pragma unroll
-    for (int k = 0; k < MAXO; ++k) {
-      const int it = wave + k * NWV;
-      ggv[k][0] = ggv[k][1] = 0.f;
-      if (it >= oitems) continue;                                     // wave-uniform
-      const int r = it / nseg;
-      const int x = (it - r * nseg) * 64 + lane;
-      const int s = (y0 + r) * W + min(x, W - 1);
-      float q[2] = {gn[s], gn[V + s]};
-      float o[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) o[c] = gon[(int64_t)c * V + s];
-      bool pass[2] = {true, true};
-      if (clamp_grid) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) { pass[a] = q[a] >= -1.f && q[a] <= 1.f; q[a] = clamp_unit(q[a]); }
-      }
-      Taps<2, PAD> t;
-      t.build(q[0], q[1], 0.f, d);
+    if (own && (SELF || GG)) {
       float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-      for (int c = 0; c < C; ++c) coord_path_diff<2, PAD>(inn + (int64_t)c * V, o[c], t, d, ax, ay, az);
-      ggv[k][0] = pass[0] ? t.x.mult * ax : 0.f;
-      ggv[k][1] = pass[1] ? t.y.mult * ay : 0.f;
+      for (int c = 0; c < C; ++c) coord_path_values<2, PAD>(vl[c], go[c], t, ax, ay, az);
+      gg[0] = pass[0] ? t.x.mult * ax : 0.f;
+      gg[1] = pass[1] ? t.y.mult * ay : 0.f;
+    }
+    (void)ys;
+  };
+  // own items it = wave + k * NWV (static register slots for their coordinate path), two per round
+#pragma unroll
+  for (int k0 = 0; k0 < MAXO; k0 += U) {
+    float g[U][2], go[U][C];
+    int xs[U], ys[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ggv[k0 + u][0] = ggv[k0 + u][1] = 0.f;
+      const int it = min(wave + (k0 + u) * NWV, max(oitems - 1, 0));
+      const int r = it / nseg;
+      ys[u] = y0 + r;
+      xs[u] = (it - r * nseg) * 64 + lane;
+      const int s = ys[u] * W + min(xs[u], W - 1);
+      g[u][0] = gn[s];
+      g[u][1] = gn[V + s];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[u][c] = gon[(int64_t)c * V + s];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (wave + (k0 + u) * NWV >= oitems) continue;                  // wave-uniform
+      visit(ys[u], xs[u], true, g[u], go[u], ggv[k0 + u]);
+    }
+  }
+  // halo items: rows ya .. y0-1 and yend .. yb-1
+  const int hlo = y0 - ya, hitems = (hlo + (yb - yend)) * nseg;
+  for (int it0 = wave * U; it0 < hitems; it0 += NWV * U) {
+    float g[U][2], go[U][C];
+    int xs[U], ys[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = min(it0 + u, hitems - 1);
+      const int r = it / nseg;
+      ys[u] = r < hlo ? ya + r : yend + (r - hlo);
+      xs[u] = (it - r * nseg) * 64 + lane;
+      const int s = ys[u] * W + min(xs[u], W - 1);
+      g[u][0] = gn[s];
+      g[u][1] = gn[V + s];
+#pragma unroll
+      for (int c = 0; c < C; ++c) go[u][c] = gon[(int64_t)c * V + s];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (it0 + u >= hitems) continue;                                // wave-uniform
+      float dummy[2];
+      visit(ys[u], xs[u], false, g[u], go[u], dummy);
     }
   }
   __syncthreads();

@@ -266,6 +266,10 @@ def test_teacher_forced_step_at_realistic_size(case):
             _parity_log("%-24s step 0 %-6s grad: worst err / allowance %.3f; worst err %.3e of scale; %d of %d coefficients use more "
                         "than the flat 1e-4 of scale" % (case, sp["name"], float((diff / allow).max()), float(diff.max()) / scale,
                                                          int((diff > TOL * scale).sum()), diff.numel()))
+            if float(over.max()) >= 0 and diff.numel() <= 80:      # (small parameter sets: the whole picture goes to the log)
+                for nm, m in (("err", diff), ("allowance", allow), ("reference", fx.t(gkey + "__full"))):
+                    _parity_log("%-24s FAILED %s grad, %s / scale: %s" % (case, sp["name"], nm, [["%.2e" % v for v in row] for row in
+                                                                          (m / scale).reshape(m.shape[0], -1).tolist()]))
             assert float(over.max()) < 0, (case, "%s grad: %d coefficients over, worst %.3e of scale (field diff %.2e, level %d)"
                                            % (sp["name"], int((over > 0).sum()), float(diff.max()) / scale, fdiff, lvl))
         else:
