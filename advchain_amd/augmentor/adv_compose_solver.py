@@ -606,6 +606,7 @@ class ComposeAdversarialTransformSolver(object):
                         transforms.append(transform)  # reference quirk (line 399): last transform listed twice
                 else:
                     stop_flag = True
+        ops.HINT_SLOT = 0       # (a later user-level forward() keys its kernel-selection hints to "no ascent step")
         return transforms
 
     def _backward_to_transforms(self, dist, optimize_flags):

@@ -644,6 +644,9 @@ k_band_reduce_rows_dense(const float* __restrict__ in, const float* __restrict__
         const float* w1 = Wd + (two ? k1 : k0) * WB;
         float a0 = 0.f, a1 = 0.f;
         int j = 0;
+        // (taps the banded kernel skips -- beyond a coefficient's band, or clamped to S - 1 -- enter here with weight 0: the
+        // same sums for FINITE input; an inf / NaN inside [lo, lo + WB) of a row turns its coefficient into NaN where the
+        // banded kernel would not.  The solver's NaN guard voids such a step either way.)
         for (; j + 8 <= WB; j += 8) {
           float x0[8], x1[8], c0[8], c1[8];
 #pragma unroll
