@@ -57,7 +57,7 @@ class ComposeAdversarialTransformSolver(object):
         # hipGraph once its launch sequence has been recorded (see _graphed_ascent); off by default -- the user's model
         # is captured with it, which needs a model without host-side control flow or side effects
         self.hip_graph = hip_graph
-        self.hip_graph_record_calls = 2        # ordinary calls recorded before the capture
+        self.hip_graph_record_calls = 3        # ordinary calls recorded before the capture
         self._graphs = {}
         self.graph_stats = {"recorded": 0, "captures": 0, "replays": 0, "violations": 0, "refused": 0}
         self._global_batch = None
@@ -226,7 +226,7 @@ class ComposeAdversarialTransformSolver(object):
                 t.param = p
             self.chain_of_transforms = chain
             if record:
-                rec["plan"].thaw()
+                rec["plan"].begin_record()
             ops._PLAN = rec["plan"] if record else None
             try:
                 io = given if given is not None else self.get_init_output(data=data, model=model)
@@ -277,12 +277,26 @@ class ComposeAdversarialTransformSolver(object):
 
         def held():
             rec["event"].synchronize()
-            if int(rec["flag_host"][0]) == 0:
+            recent = rec.setdefault("recent", [])
+            bad = int(rec["flag_host"][0]) != 0
+            recent.append(bad)
+            del recent[:-32]
+            if not bad:
                 return True
+            # this call runs again the ordinary way (recorded: its measurements widen the plan's record).  The graph stays: it
+            # is exact for every call inside its intervals.  Only when violations are frequent -- more than one replay in
+            # eight of the last 32 -- is the loop captured again from the widened record (a capture costs ~6 calls)
             self.graph_stats["violations"] += 1
             rec["violations"] = rec.get("violations", 0) + 1
-            rec["plan"].margin = min(2.0, rec["plan"].margin * 1.2)
-            rec["state"], rec["graph"] = ("record" if rec["violations"] < 6 else "off"), None     # captured again after this call's record
+            if len(recent) >= 8 and sum(recent) * 8 > len(recent):
+                rec["recaptures"] = rec.get("recaptures", 0) + 1
+                rec["recent"] = []
+                if rec["recaptures"] > 4:
+                    rec["state"], rec["graph"] = "off", None
+                else:
+                    rec["plan"].margin = min(2.0, rec["plan"].margin * 1.15)
+                    rec["plan"].thaw()
+                    rec["state"], rec["graph"] = "capture", None
             return False
         return io, held
 

@@ -606,8 +606,14 @@ class LaunchPlan(object):
     the calls recorded before (element-wise max).  freeze(): numbers x margin -> per-site selections + device intervals.
     frozen: take() hands the sites out in call order, check() enqueues the premise check."""
 
-    def __init__(self, margin=1.1):
+    def __init__(self, margin=1.3):
+        # margin: the recorded maxima x margin pick the frozen selection.  Displacements vary with the random initial
+        # parameters (cfg-2, second ascent step: 0.886 px over two recorded calls, 1.107 px in the third), and the levels of a
+        # chain double, so every level sits at the same relative distance from ITS power-of-two threshold: a margin that is
+        # too small is violated on all of them at once.  1.1 was (one call in five re-run the ordinary way); what a wide
+        # margin costs is one formulation up on the levels within its reach of a threshold (+0.1 ms per cfg-2 call at 1.25)
         self.margin = float(margin)
+        self.recording = True
         self.pending = []        # this call's sites while recording: (kind, payload)
         self.recorded = None     # merged: list of (kind, dict of numbers)
         self.calls = 0
@@ -616,16 +622,22 @@ class LaunchPlan(object):
         self.cursor = 0
         self.flag = None
         self.persistent = {}
+        self.violated = []       # diagnostics: which frozen bound a violated replay exceeded (filled by the recorded re-run)
 
     @property
     def is_frozen(self):
-        return self.frozen is not None
+        return self.frozen is not None and not self.recording
 
     # -- recording
-    def thaw(self):
-        """Back to recording (the frozen selection and whatever an interrupted call left pending are dropped)."""
-        self.frozen = None
+    def begin_record(self):
+        """An ordinary call is about to be recorded.  A frozen selection stays in place (a captured graph keeps replaying it
+        after this call); whatever an interrupted call left pending is dropped."""
+        self.recording = True
         self.pending = []
+
+    def thaw(self):
+        """Drop the frozen selection (a new capture will freeze the merged record again)."""
+        self.frozen = None
         self.persistent = {}
 
     def note(self, kind, **payload):
@@ -641,6 +653,17 @@ class LaunchPlan(object):
             elif kind == "warp":
                 sites.append((kind, {"d": pl["d"], "vals": [float(pl["rb"].values()[pl["idx"]])]}))
         self.pending = []
+        # a recorded call that follows a violated replay measured what that replay measured: say which bound gave way
+        last = self.frozen
+        if last is not None and len(last) == len(sites):
+            for i, (fz, (kind, rec)) in enumerate(zip(last, sites)):
+                if "vals" in rec and fz["kind"] == kind:
+                    his = fz["hi"].tolist()
+                    for j, v in enumerate(rec["vals"]):
+                        if j < len(his) and not (v < his[j]):
+                            self.violated.append({"site": i, "kind": kind, "row": j, "measured": round(v, 4), "bound": round(his[j], 4),
+                                                  "frozen_from": round(fz["bounds"].values()[j], 4)})
+            del self.violated[:-64]
         if self.recorded is None:
             self.recorded = sites
         elif [(k, v.get("n"), v.get("d")) for k, v in sites] != [(k, v.get("n"), v.get("d")) for k, v in self.recorded]:
@@ -651,7 +674,7 @@ class LaunchPlan(object):
                 if "vals" in old:
                     old["vals"] = [b if (b != b or b > a) else a for a, b in zip(old["vals"], new["vals"])]
         self.calls += 1
-        self.frozen = None
+        self.recording = False
 
     # -- freezing
     def freeze(self, device):
@@ -692,6 +715,7 @@ class LaunchPlan(object):
             sdict["hi"] = hi_t[sdict["off"]:sdict["off"] + sdict["len"]]
         self.flag = torch.zeros(1, device=device, dtype=torch.int32)
         self.frozen = sites
+        self.recording = False
         self.cursor = 0
         self.persistent = {}
 

@@ -268,7 +268,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
             solver.hip_graph = graphed
     # warm-up; one warm-up step is instrumented on every entry point to find the dominant kernel -- after one cold step of
     # its own (first launches include code-object loading and would be booked to whichever entry runs first).  With
-    # solver.hip_graph the warm-up also holds the calls that record the launch plan and the capture (at least 4 steps).
+    # solver.hip_graph the warm-up also holds the calls that record the launch plan and the capture (at least 5 steps).
     dominant = None
     with ordinary():
         step()
@@ -284,7 +284,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         tot[name] = tot.get(name, 0.0) + e0.elapsed_time(e1)
     dominant = max(tot, key=tot.get) if tot else None
     breakdown = {k.replace("advchain_", ""): round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-    for i in range(max(warmup - 1, 4 if graphed else 0)):
+    for i in range(max(warmup - 1, 5 if graphed else 0)):
         step()
     # timed region: exactly K steps between barrier+sync; only the dominant entry point carries events.  The cyclic
     # garbage collector is parked for it, as timeit does: one generation-2 pass (~40-60 ms with torch loaded) would
@@ -321,6 +321,9 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     # host-boundness figure is the comparison with the ordinary path below (`ordinary_ms_per_step`) and with rocprof's
     # kernel-busy time (profiles/)
     extras["gpu_span_ms_per_step"] = round(marks[0].elapsed_time(marks[-1]) / steps, 3)
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    extras["gpu_span_ms_by_step"] = {"min": round(per[0], 3), "median": round(per[len(per) // 2], 3), "max": round(per[-1], 3),
+                                     "first": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(min(steps, 6))]}
     extras["abi_calls_per_step"] = abi_calls
     if graphed:
         st = solver.graph_stats
@@ -328,6 +331,9 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                                "captures": st["captures"], "recorded_calls": st["recorded"], "refused": st["refused"] - stats0["refused"],
                                "note": "the prediction + the ascent steps of every timed call are ONE hipGraph replay; the final "
                                        "consistency-loss pass is dispatched the ordinary way behind it"}
+        viol = [v for rec in solver._graphs.values() for v in rec["plan"].violated]
+        if viol:
+            extras["hip_graph"]["violated_bounds"] = viol[:8]
         if extras["hip_graph"]["replays"] == 0:
             graphed = False                 # (nothing was replayed -- the anatomy ladder, a capture that failed: the ordinary path was timed)
     if graphed and not PROFILING_RUN:
@@ -385,6 +391,8 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                 "launches": len(durs), "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b)}
     extras["solver_calls_in_process"] = n_calls[0]      # (per-call figures of a rocprof summary of this command divide by this)
+    if solver.graph_stats["violations"]:              # (each ran its ascent loop a second time, the ordinary way)
+        extras["ascent_loops_run_twice"] = solver.graph_stats["violations"]
     if world > 1:
         extras["rank_ms_per_step"] = _rank_spread(elapsed / steps * 1e3, world, device)
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

@@ -67,7 +67,7 @@ def test_replay_matches_the_ordinary_path(case, steps):
         else:
             _close(got[:1], want[:1], 2e-2)
     st = graph.graph_stats
-    assert st["recorded"] == 2 + st["violations"] and st["captures"] >= 1 and st["replays"] >= 3 and st["refused"] == 0, st
+    assert st["recorded"] == 3 + st["violations"] and st["captures"] >= 1 and st["replays"] >= 2 and st["refused"] == 0, st
     assert eager.graph_stats["replays"] == 0
 
 
@@ -80,7 +80,7 @@ def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(
     model = make_model(len(dims), device=DEV)
     data = smooth_data(N, 1, dims, 7).to(DEV)
     graph = _solver(dims, names, N, True)
-    for k in range(3):
+    for k in range(4):
         _call(graph, data, model, n_iter, 300)         # (the same draw as the replays below: inside the plan's intervals)
     (rec,) = graph._graphs.values()
     assert rec["state"] == "replay"
@@ -116,22 +116,38 @@ def test_a_violated_plan_is_detected_and_the_call_runs_the_ordinary_way():
     model = make_model(2, device=DEV)
     data = smooth_data(N, 1, dims, 9).to(DEV)
     eager, graph = _solver(dims, names, N, False), _solver(dims, names, N, True)
-    for k in range(3):
-        _call(graph, data, model, n_iter, 400 + k)
+    for k in range(4):
+        _call(graph, data, model, n_iter, 400)
     (rec,) = graph._graphs.values()
     assert rec["state"] == "replay" and graph.graph_stats["violations"] == 0
+    keep = [site["hi"].clone() for site in rec["plan"].frozen]
     for site in rec["plan"].frozen:          # the graph reads its intervals from these device tensors: shrink them to nothing
         site["hi"].fill_(1e-9)
     want = _call(eager, data, model, n_iter, 500)
     got = _call(graph, data, model, n_iter, 500)
-    assert graph.graph_stats["violations"] == 1 and rec["state"] == "capture"
-    for x, y in zip(got, want):              # the ordinary path from the same initial parameters: exactly its results
+    # detected; this call ran the ordinary way from the same initial parameters -- exactly its results; the graph stays
+    assert graph.graph_stats["violations"] == 1 and rec["state"] == "replay" and graph.graph_stats["captures"] == 1
+    assert rec["plan"].violated and rec["plan"].violated[0]["bound"] < 1e-8
+    for x, y in zip(got, want):
         assert torch.equal(x, y)
-    # the next call captures again (with this call's measurements merged in) and replays from then on
-    # (several free-running steps: the loss only, loosely -- see test_replay_matches_the_ordinary_path)
-    _close(_call(graph, data, model, n_iter, 501)[:1], _call(eager, data, model, n_iter, 501)[:1], 2e-2)
-    _close(_call(graph, data, model, n_iter, 502)[:1], _call(eager, data, model, n_iter, 502)[:1], 2e-2)
-    assert graph.graph_stats["captures"] == 2 and rec["state"] == "replay"
+    for site, hi in zip(rec["plan"].frozen, keep):
+        site["hi"].copy_(hi)
+    replays = graph.graph_stats["replays"]
+    _call(graph, data, model, n_iter, 400)
+    assert graph.graph_stats["violations"] == 1 and graph.graph_stats["replays"] == replays + 1
+    # violations in more than one replay of eight: the loop is captured again from the widened record
+    for site in rec["plan"].frozen:
+        site["hi"].fill_(1e-9)
+    for k in range(8):
+        _call(graph, data, model, n_iter, 400)
+        if rec["state"] != "replay":
+            break
+    assert rec["state"] == "capture" and rec["recaptures"] == 1
+    got = _call(graph, data, model, n_iter, 400)
+    assert rec["state"] == "replay" and graph.graph_stats["captures"] == 2
+    again = _call(graph, data, model, n_iter, 400)
+    for x, y in zip(got, again):
+        assert torch.equal(x, y)
 
 
 def test_results_do_not_alias_the_captured_buffers():
@@ -147,7 +163,7 @@ def test_results_do_not_alias_the_captured_buffers():
         loss = graph.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=False, step_sizes=1)
         kept = [loss, graph.init_output, graph.adv_data] + [t.param for t in graph.chain_of_transforms]
         outs.append((kept, [x.detach().clone() for x in kept]))
-    assert graph.graph_stats["replays"] >= 2
+    assert graph.graph_stats["replays"] >= 1
     for kept, copies in outs:                # what an earlier call returned is untouched by the later replays
         for x, y in zip(kept, copies):
             assert torch.equal(x.detach(), y)
@@ -157,7 +173,7 @@ def test_results_do_not_alias_the_captured_buffers():
         p.requires_grad_(True)
     g2 = _solver(dims, names, N, True)
     data = smooth_data(N, 1, dims, 70).to(DEV)
-    for k in range(4):
+    for k in range(5):
         loss = g2.adversarial_training(data=data, model=model2, n_iter=2, lazy_load=False, step_sizes=1)
     assert g2.graph_stats["replays"] >= 1
     loss.backward()
@@ -189,7 +205,7 @@ def test_batchnorm_model_in_train_mode_is_captured():
     eager, graph = _solver(dims, names, N, False), _solver(dims, names, N, True)
     data = smooth_data(N, 1, dims, 13).to(DEV)
     stats0 = [b.clone() for b in model.buffers()]
-    for k in range(5):
+    for k in range(6):
         want = _call(eager, data, model, 1, 700 + k)
         stats1 = [b.clone() for b in model.buffers()]
         for b, s in zip(model.buffers(), stats0):
