@@ -178,24 +178,41 @@ class ComposeAdversarialTransformSolver(object):
                 and isinstance(model, torch.nn.Module)
                 and (init_output is None or (isinstance(init_output, torch.Tensor) and init_output.is_cuda)))
 
-    @staticmethod
-    def _plain(v):
-        if isinstance(v, (int, float, str, bool, type(None))):
+    _PLAIN_TYPES = (int, float, str, bool)
+
+    @classmethod
+    def _plain(cls, v):
+        """`v` as a hashable plain value (numbers, strings, flat lists / tuples of them), else None."""
+        if type(v) in cls._PLAIN_TYPES or isinstance(v, cls._PLAIN_TYPES):
             return v
-        if isinstance(v, (list, tuple)) and all(isinstance(x, (int, float, str, bool, type(None))) for x in v):
+        if type(v) in (list, tuple) and all(type(x) in cls._PLAIN_TYPES or x is None or isinstance(x, cls._PLAIN_TYPES) for x in v):
             return tuple(v)
         return None
+
+    @classmethod
+    def _plain_attrs(cls, obj, skip=()):
+        """The plain attributes of `obj` as a tuple of (name, value) in the object's own attribute order (one pass, no sort:
+        the order of an object's __dict__ only changes when attributes are added, which changes the tuple anyway)."""
+        out = []
+        plain = cls._PLAIN_TYPES
+        for k, v in obj.__dict__.items():
+            if type(v) in plain:
+                out.append((k, v))
+            elif v is None or k in skip:
+                continue
+            else:
+                p = cls._plain(v)
+                if p is not None:
+                    out.append((k, p))
+        return tuple(out)
 
     def _graph_key(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
         """Everything the captured launch sequence depends on besides tensor CONTENTS: shapes, the model's storage, the
         arguments of the call, every plain attribute of the solver and of its transforms."""
-        tr = tuple((type(t).__name__,) + tuple(sorted((k, self._plain(v)) for k, v in vars(t).items()
-                                                       if self._plain(v) is not None))
-                   for t in self.chain_of_transforms)
+        tr = tuple((type(t).__name__,) + self._plain_attrs(t) for t in self.chain_of_transforms)
         mod = (id(model), model.training) + tuple(p.data_ptr() for p in model.parameters()) \
             + tuple(b.data_ptr() for b in model.buffers())
-        mine = tuple(sorted((k, self._plain(v)) for k, v in vars(self).items()
-                            if k not in ('graph_stats',) and (self._plain(v) is not None)))
+        mine = self._plain_attrs(self, skip=('graph_stats',))
         return (tuple(data.shape), str(data.device), None if init_output is None else tuple(init_output.shape), bool(lazy_load),
                 int(n_iter), tuple(bool(f) for f in optimize_flags), tuple(step_sizes), tr, mod, mine)
 

@@ -789,18 +789,11 @@ k_consistency_bwd_march4(const float* __restrict__ P, const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // softmax of the 4 voxels at `o` (+ k V) of both logit maps: P, T (the reference itself when it already holds probabilities);
 // with LOGS also log-softmax terms for the KL sum
+// softmax of 4 voxels of both logit maps, from registers: P, T (the reference itself when it already holds probabilities); with
+// LOGS also the log-softmax terms for the KL sum
 template <int K, bool LOGS>
-__device__ __forceinline__ void softmax_pair4(const float* __restrict__ pred, const float* __restrict__ ref, int64_t o, int V,
-                                              int ref_is_prob, float (&P)[K][4], float (&T)[K][4], float (&lq)[LOGS ? K : 1][4],
-                                              float (&lt)[LOGS ? K : 1][4]) {
-  float p[K][4], r[K][4];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float4 a = *reinterpret_cast<const float4*>(pred + o + (int64_t)k * V);
-    const float4 b = *reinterpret_cast<const float4*>(ref + o + (int64_t)k * V);
-    p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w;
-    r[k][0] = b.x; r[k][1] = b.y; r[k][2] = b.z; r[k][3] = b.w;
-  }
+__device__ __forceinline__ void softmax_quads(const float (&p)[K][4], const float (&r)[K][4], int ref_is_prob, float (&P)[K][4],
+                                              float (&T)[K][4], float (&lq)[LOGS ? K : 1][4], float (&lt)[LOGS ? K : 1][4]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float mp = -INFINITY, mr = -INFINITY;
@@ -818,6 +811,22 @@ __device__ __forceinline__ void softmax_pair4(const float* __restrict__ pred, co
       if (LOGS) { lq[k][q] = zp - lsp; lt[k][q] = zr - lsr; }
     }
   }
+}
+
+// the same for the 4 voxels at `o` (+ k V) of both logit maps in memory
+template <int K, bool LOGS>
+__device__ __forceinline__ void softmax_pair4(const float* __restrict__ pred, const float* __restrict__ ref, int64_t o, int V,
+                                              int ref_is_prob, float (&P)[K][4], float (&T)[K][4], float (&lq)[LOGS ? K : 1][4],
+                                              float (&lt)[LOGS ? K : 1][4]) {
+  float p[K][4], r[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 a = *reinterpret_cast<const float4*>(pred + o + (int64_t)k * V);
+    const float4 b = *reinterpret_cast<const float4*>(ref + o + (int64_t)k * V);
+    p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w;
+    r[k][0] = b.x; r[k][1] = b.y; r[k][2] = b.z; r[k][3] = b.w;
+  }
+  softmax_quads<K, LOGS>(p, r, ref_is_prob, P, T, lq, lt);
 }
 
 template <int DIM, int K, bool KL, bool EDGES>
@@ -1018,6 +1027,342 @@ k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref,
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f2 in 3D (round 5): the fused loss marching along Z, with the y neighbours of a row exchanged through LDS.
+// k_loss_fused_fwd4 / _bwd4 march along y inside ONE plane and fold z by reading three planes per row: every voxel's softmax
+// is evaluated 3 x (mlen + 2) / mlen times and a row step issues 24 loads instead of 9 -- slower in 3D than the three-kernel
+// form it was meant to replace (lesson 48).  Here a workgroup of 4 waves owns RW = 4 x (64 / lanes-per-row) consecutive rows
+// of a chunk of planes (its first and last row are halo: they only feed their neighbours) and walks the planes za-1 .. zb:
+//   * a thread reads the logits of ITS 4 voxels of the plane once, forms the softmax difference and its x fold (DPP lane
+//     shifts) in registers,
+//   * the z fold (1, 2, 1) is two running partial sums per value -- (x[z-2] + 2 x[z-1]) + x[z], the order of the a0 loop of
+//     fold_row4, so the folded values are the bits of the y-marching kernels --,
+//   * the folded values of plane z-1 go to LDS (2 (K-1) quads per thread, double-buffered: ONE barrier per plane) and every
+//     output row takes rows y-1 / y+1 from there for the y part of the two stencils.
+// Reads per voxel: (RW / (RW - 2)) x ((zc + 2) / zc) = 1.14 x 1.25 of the logits instead of 3.75 x; nothing but R is written.
+// Backward: the same walk over R (adjoint stencils), the softmax recomputed at the own voxel of the output plane only.
+// ---------------------------------------------------------------------------------------------
+constexpr int kZ3Waves = 4;
+
+struct Z3Pos {
+  int lpr, RW, RO, rr, xq, x, y, yc, za, zb;
+  bool first, last, lane_ok, yin, own;
+};
+__device__ __forceinline__ Z3Pos z3_decode(const Dims& d, int zc) {
+  Z3Pos p;
+  p.lpr = d.s2 >> 2;
+  const int gpw = 64 / p.lpr;
+  p.RW = kZ3Waves * gpw;
+  p.RO = p.RW - 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / p.lpr;
+  p.xq = lane - grp * p.lpr;
+  p.lane_ok = grp < gpw;
+  p.rr = wave * gpw + min(grp, gpw - 1);
+  const int nyt = (d.s1 + p.RO - 1) / p.RO;
+  const int ty = blockIdx.x % nyt, tz = blockIdx.x / nyt;
+  p.y = ty * p.RO - 1 + p.rr;
+  p.yin = p.y >= 0 && p.y < d.s1;
+  p.yc = min(max(p.y, 0), d.s1 - 1);
+  p.za = tz * zc;
+  p.zb = min(p.za + zc, d.s0);
+  p.x = 4 * p.xq;
+  p.first = p.xq == 0;
+  p.last = p.xq == p.lpr - 1;
+  p.own = p.lane_ok && p.rr >= 1 && p.rr <= p.RO && p.yin;
+  return p;
+}
+
+// x fold of a quad with the neighbouring lanes' ends (zero across a row end): s = l + 2 c + r, dd = l - r
+__device__ __forceinline__ void xfold4(const float (&c)[4], bool first, bool last, Quad& sq, Quad& dq) {
+  const float pw = lane_prev_f(c[3]), nx = lane_next_f(c[0]);
+  const float l[4] = {first ? 0.f : pw, c[0], c[1], c[2]};
+  const float r[4] = {c[1], c[2], c[3], last ? 0.f : nx};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sq.v[q] = l[q] + 2.f * c[q] + r[q];
+    dq.v[q] = l[q] - r[q];
+  }
+}
+
+template <int K, bool KL>
+__global__ void __launch_bounds__(kZ3Waves * 64) __attribute__((amdgpu_waves_per_eu(3)))
+k_loss_fused_fwd3d_z(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
+                     float* __restrict__ R, float* __restrict__ sums, Dims d, int zc, int ref_is_prob) {
+  constexpr int CH = 2 * (K - 1);
+  extern __shared__ float4 xch[];                 // [2][RW][CH][lpr]
+  __shared__ float smem[16];
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  const Z3Pos t = z3_decode(d, zc);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};            // mse, edge A, edge B, kl
+  Quad xprev[CH], part[CH];                       // [2 (k-1)] = x-smoothed, [2 (k-1) + 1] = x-differenced
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xprev[i].v[q] = 0.f; part[i].v[q] = 0.f; }
+  float4 na[K], nb[K];
+  auto request = [&](int z) {
+    const int zq = min(max(z, 0), d.s0 - 1);
+    const int64_t o = (int64_t)n * K * V + ((int64_t)zq * d.s1 + t.yc) * d.s2 + t.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      na[k] = *reinterpret_cast<const float4*>(pred + o + (int64_t)k * V);
+      nb[k] = *reinterpret_cast<const float4*>(ref + o + (int64_t)k * V);
+    }
+  };
+  // (no software prefetch of the next plane here: with it the K = 4 kernel needs 184 VGPRs -- two waves a SIMD; without, 153 and
+  // three: 81 against 89 us at 4 x 4 x 128 x 128 x 64.  The backward is the other way round: 74 against 102 us.)
+  int buf = 0;
+  for (int z = t.za - 1; z <= t.zb; ++z) {
+    request(z);
+    float p[K][4], r[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      p[k][0] = na[k].x; p[k][1] = na[k].y; p[k][2] = na[k].z; p[k][3] = na[k].w;
+      r[k][0] = nb[k].x; r[k][1] = nb[k].y; r[k][2] = nb[k].z; r[k][3] = nb[k].w;
+    }
+    const bool in = z >= 0 && z < d.s0 && t.yin;
+    float P[K][4], T[K][4], lq[KL ? K : 1][4], lt[KL ? K : 1][4];
+    softmax_quads<K, KL>(p, r, ref_is_prob, P, T, lq, lt);
+    if (t.own && z >= t.za && z < t.zb) {          // the own voxels of the chunk's planes: mse / kl sums
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (mask) {
+        const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + ((int64_t)z * d.s1 + t.y) * d.s2 + t.x);
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float e = P[k][q] * m[q] - T[k][q] * m[q];
+          acc[0] += e * e;
+          if (KL) acc[3] += kl_term(T[k][q], lt[k][q], lq[k][q], m[q], ref_is_prob);
+        }
+    }
+    // x fold of D = P - T (zero outside the volume), then the z fold of plane z - 1: (x[z-2] + 2 x[z-1]) + x[z]
+    Quad fz[CH];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      float c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = in ? P[k][q] - T[k][q] : 0.f;
+      Quad xs, xd;
+      xfold4(c, t.first, t.last, xs, xd);
+      const int is = 2 * (k - 1), id = is + 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        fz[is].v[q] = part[is].v[q] + 1.f * xs.v[q];
+        fz[id].v[q] = part[id].v[q] + 1.f * xd.v[q];
+        part[is].v[q] = (0.f + 1.f * xprev[is].v[q]) + 2.f * xs.v[q];
+        part[id].v[q] = (0.f + 1.f * xprev[id].v[q]) + 2.f * xd.v[q];
+        xprev[is].v[q] = xs.v[q];
+        xprev[id].v[q] = xd.v[q];
+      }
+    }
+    const int pz = z - 1;
+    if (pz < t.za) continue;                      // (uniform: the chunk's first output plane needs one more step)
+    float4* mine = xch + ((buf * t.RW + t.rr) * CH) * t.lpr + t.xq;
+    if (t.lane_ok) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) mine[i * t.lpr] = make_float4(fz[i].v[0], fz[i].v[1], fz[i].v[2], fz[i].v[3]);
+    }
+    __syncthreads();
+    if (t.own) {
+      const float4* up = xch + ((buf * t.RW + t.rr - 1) * CH) * t.lpr + t.xq;
+      const float4* dn = xch + ((buf * t.RW + t.rr + 1) * CH) * t.lpr + t.xq;
+      const int v = (pz * d.s1 + t.y) * d.s2 + t.x;
+      float m[4] = {1.f, 1.f, 1.f, 1.f};
+      if (mask) {
+        const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
+        m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+      }
+#pragma unroll
+      for (int k = 1; k < K; ++k) {
+        const int is = 2 * (k - 1), id = is + 1;
+        const float4 su = up[is * t.lpr], sd = dn[is * t.lpr], du = up[id * t.lpr], dd = dn[id * t.lpr];
+        const float s0[4] = {su.x, su.y, su.z, su.w}, s2[4] = {sd.x, sd.y, sd.z, sd.w};
+        const float d0[4] = {du.x, du.y, du.z, du.w}, d2[4] = {dd.x, dd.y, dd.z, dd.w};
+        float ra[4], rb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ga = s0[q] - s2[q];
+          const float gb = d0[q] + 2.f * fz[id].v[q] + d2[q];
+          const float ea = ga * m[q], eb = gb * m[q];
+          acc[1] += ea * ea;
+          acc[2] += eb * eb;
+          ra[q] = 2.f * m[q] * m[q] * ga;
+          rb[q] = 2.f * m[q] * m[q] * gb;
+        }
+        if (R) {
+          *reinterpret_cast<float4*>(R + ((int64_t)n * CH + is) * V + v) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+          *reinterpret_cast<float4*>(R + ((int64_t)n * CH + id) * V + v) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  block_sum<4>(acc, smem);
+  if (threadIdx.x == 0) {
+    atomic_add_f32(sums + sum_slot(), acc[0]);
+    atomic_add_f32(sums + kSumSlots + sum_slot(), acc[1]);
+    atomic_add_f32(sums + 2 * kSumSlots + sum_slot(), acc[2]);
+    if (KL) atomic_add_f32(sums + 3 * kSumSlots + sum_slot(), acc[3]);
+  }
+}
+
+template <int K, bool KL>
+__global__ void __launch_bounds__(kZ3Waves * 64)
+k_loss_fused_bwd3d_z(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ R,
+                     const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred, float c_mse,
+                     float c_a, float c_b, Dims d, int zc, float c_kl, int ref_is_prob) {
+  constexpr int CH = 2 * (K - 1);
+  extern __shared__ float4 xch[];                 // [2][RW][CH][lpr]: a_k (x- and z-smoothed R_A), b_k (-(x-differenced, z-smoothed R_B))
+  const int n = blockIdx.y;
+  const int V = (int)d.voxels();
+  const Z3Pos t = z3_decode(d, zc);
+  const float gs = gscale ? gscale[0] : 1.f;
+  Quad xprev[CH], part[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xprev[i].v[q] = 0.f; part[i].v[q] = 0.f; }
+  float4 nr[CH], na[K], nb[K], nm = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto request_r = [&](int z) {
+    const int zq = min(max(z, 0), d.s0 - 1);
+    const int64_t o = (int64_t)n * CH * V + ((int64_t)zq * d.s1 + t.yc) * d.s2 + t.x;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) nr[i] = *reinterpret_cast<const float4*>(R + o + (int64_t)i * V);
+  };
+  auto request_own = [&](int pz) {                // logits + mask of the output plane (own rows only use them)
+    const int zq = min(max(pz, 0), d.s0 - 1);
+    const int64_t sp = ((int64_t)zq * d.s1 + t.yc) * d.s2 + t.x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      na[k] = *reinterpret_cast<const float4*>(pred + ((int64_t)n * K + k) * V + sp);
+      nb[k] = *reinterpret_cast<const float4*>(ref + ((int64_t)n * K + k) * V + sp);
+    }
+    if (mask) nm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + sp);
+  };
+  request_r(t.za - 1);
+  int buf = 0;
+  for (int z = t.za - 1; z <= t.zb; ++z) {
+    float rc[CH][4];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { rc[i][0] = nr[i].x; rc[i][1] = nr[i].y; rc[i][2] = nr[i].z; rc[i][3] = nr[i].w; }
+    const bool in = z >= 0 && z < d.s0 && t.yin;
+    const int pz = z - 1;
+    if (z < t.zb) request_r(z + 1);               // the next plane of R travels while this one is worked on
+    if (pz >= t.za && t.own) request_own(pz);
+    // x fold of R_A (smoothed) and R_B (differenced), z fold of plane z - 1
+    Quad fz[CH];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      const int ia = 2 * (k - 1), ib = ia + 1;
+      float ca[4], cb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ca[q] = in ? rc[ia][q] : 0.f; cb[q] = in ? rc[ib][q] : 0.f; }
+      Quad as, ad, bs, bd;
+      xfold4(ca, t.first, t.last, as, ad);
+      xfold4(cb, t.first, t.last, bs, bd);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        fz[ia].v[q] = part[ia].v[q] + 1.f * as.v[q];
+        fz[ib].v[q] = -(part[ib].v[q] + 1.f * bd.v[q]);
+        part[ia].v[q] = (0.f + 1.f * xprev[ia].v[q]) + 2.f * as.v[q];
+        part[ib].v[q] = (0.f + 1.f * xprev[ib].v[q]) + 2.f * bd.v[q];
+        xprev[ia].v[q] = as.v[q];
+        xprev[ib].v[q] = bd.v[q];
+      }
+      (void)ad; (void)bs;
+    }
+    if (pz < t.za) continue;                      // (uniform)
+    float4* mine = xch + ((buf * t.RW + t.rr) * CH) * t.lpr + t.xq;
+    if (t.lane_ok) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) mine[i * t.lpr] = make_float4(fz[i].v[0], fz[i].v[1], fz[i].v[2], fz[i].v[3]);
+    }
+    __syncthreads();
+    if (t.own) {
+      const float4* up = xch + ((buf * t.RW + t.rr - 1) * CH) * t.lpr + t.xq;
+      const float4* dn = xch + ((buf * t.RW + t.rr + 1) * CH) * t.lpr + t.xq;
+      const int v = (pz * d.s1 + t.y) * d.s2 + t.x;
+      float p[K][4], r[K][4];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        p[k][0] = na[k].x; p[k][1] = na[k].y; p[k][2] = na[k].z; p[k][3] = na[k].w;
+        r[k][0] = nb[k].x; r[k][1] = nb[k].y; r[k][2] = nb[k].z; r[k][3] = nb[k].w;
+      }
+      const float m[4] = {nm.x, nm.y, nm.z, nm.w};
+      float pk[K][4], tk[K][4], lq[1][4], lt[1][4];
+      softmax_quads<K, false>(p, r, ref_is_prob, pk, tk, lq, lt);
+      float gp[K][4], mt[KL ? K : 1][4];
+      float dot[4] = {0.f, 0.f, 0.f, 0.f}, klS[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float a0[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f}, b0[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k >= 1) {
+          const int ia = 2 * (k - 1), ib = ia + 1;
+          const float4 au = up[ia * t.lpr], ad = dn[ia * t.lpr], bu = up[ib * t.lpr], bd = dn[ib * t.lpr];
+          a0[0] = au.x; a0[1] = au.y; a0[2] = au.z; a0[3] = au.w;
+          a2[0] = ad.x; a2[1] = ad.y; a2[2] = ad.z; a2[3] = ad.w;
+          b0[0] = bu.x; b0[1] = bu.y; b0[2] = bu.z; b0[3] = bu.w;
+          b2[0] = bd.x; b2[1] = bd.y; b2[2] = bd.z; b2[3] = bd.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dv = pk[k][q] - tk[k][q];
+          float g = c_mse * 2.f * m[q] * m[q] * dv;
+          if (k >= 1) {
+            const float sa = a2[q] - a0[q];
+            const float sb = b0[q] + 2.f * fz[2 * (k >= 1 ? k - 1 : 0) + 1].v[q] + b2[q];
+            g += c_a * sa + c_b * sb;
+          }
+          g *= gs;
+          gp[k][q] = g;
+          dot[q] += g * pk[k][q];
+          if (KL) { mt[k][q] = m[q] * kl_prob(pk[k][q] - dv, ref_is_prob); klS[q] += mt[k][q]; }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o4[q] = pk[k][q] * (gp[k][q] - dot[q]);
+          if (KL) o4[q] += gs * c_kl * (pk[k][q] * klS[q] - mt[k][q]);
+        }
+        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+// ---- the z-marching fused 3D loss: shapes, chunk length, grid, LDS
+static inline bool z3_takes(const Dims& d, bool edges) {
+  static const bool off = getenv("ADVCHAIN_NO_FUSED_LOSS_3DZ") != nullptr;   // A/B knob
+  if (off || !edges || d.s0 < 2 || d.s2 % 4 != 0) return false;
+  const int lpr = d.s2 / 4;
+  return lpr >= 1 && lpr <= 32;        // at least two rows a wave: RW = 4 x (64 / lpr) >= 8 rows, 6 of them own
+}
+static inline int z3_rows_out(const Dims& d) { return kZ3Waves * (64 / (d.s2 / 4)) - 2; }
+// planes per chunk: every chunk re-reads 2 halo planes, so as long as possible while the launch keeps ~3 workgroups a CU
+static inline int z3_chunk(const Dims& d, int64_t N) {
+  const int64_t tiles = N * ((d.s1 + z3_rows_out(d) - 1) / z3_rows_out(d));
+  int zc = d.s0;
+  while (zc > 4 && tiles * ((d.s0 + zc - 1) / zc) < 768) zc = (zc + 1) / 2;
+  return zc;
+}
+static inline dim3 z3_grid(const Dims& d, int64_t N, int zc) {
+  const int nyt = (d.s1 + z3_rows_out(d) - 1) / z3_rows_out(d);
+  return dim3((unsigned)(nyt * ((d.s0 + zc - 1) / zc)), (unsigned)N);
+}
+static inline size_t z3_lds(const Dims& d, int64_t K) {
+  const int lpr = d.s2 / 4, RW = kZ3Waves * (64 / lpr);
+  return (size_t)2 * RW * 2 * (K - 1) * lpr * sizeof(float4);
 }
 
 static inline dim3 march_grid(const Dims& d, int64_t N) {
@@ -1232,12 +1577,28 @@ int advchain_consistency_fused_fwd(const float* pred, const float* ref, const fl
   // softmax is evaluated 3 x (mlen + 2) / mlen times and the row step issues 24 instead of 9 loads; it wins in 2D (124
   // against 141 us at 32 x 4 x 256 x 256), where a row is folded once.  3D therefore stays on the unfused entries unless
   // ADVCHAIN_FUSED_LOSS_3D is set (A/B); what 3D needs is a plane exchange through LDS, not this kernel.
+  // Round 5: what 3D needed -- the plane exchange through LDS -- is k_loss_fused_fwd3d_z (z-marching; edges wanted, rows of at
+  // most 128 voxels); ADVCHAIN_NO_FUSED_LOSS_3DZ switches it off (A/B).
   static const bool on3d = getenv("ADVCHAIN_FUSED_LOSS_3D") != nullptr;
-  if (off || (ndim == 3 && !on3d) || K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
   const Dims d = lmake_dims(ndim, dims);
+  const bool edges = want_edges && K > 1;
+  const bool zmarch = ndim == 3 && z3_takes(d, edges);
+  if (off || (ndim == 3 && !on3d && !zmarch) || K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.voxels() >= (1ll << 31) || !march4_ok(d, pred, ref, mask, R)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (N == 0) return ADVCHAIN_OK;
-  const bool edges = want_edges && K > 1;
+  if (zmarch) {
+    const int zc = z3_chunk(d, N);
+    const dim3 gz = z3_grid(d, N, zc), bz(kZ3Waves * 64);
+    const size_t lds = z3_lds(d, K);
+    hipStream_t stz = (hipStream_t)stream;
+#define FWD3DZ(K_) do { \
+      if (want_kl) hipLaunchKernelGGL((k_loss_fused_fwd3d_z<K_, true>), gz, bz, lds, stz, pred, ref, mask, R, sums, d, zc, ref_is_prob); \
+      else hipLaunchKernelGGL((k_loss_fused_fwd3d_z<K_, false>), gz, bz, lds, stz, pred, ref, mask, R, sums, d, zc, ref_is_prob); } while (0)
+    switch (K) { case 2: FWD3DZ(2); break; case 3: FWD3DZ(3); break; default: FWD3DZ(4); break; }
+#undef FWD3DZ
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   if (edges && !R) R = nullptr;                      // (no gradient wanted: the sums only)
   const int mlen = march4_len(d, N);
   const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
@@ -1266,10 +1627,23 @@ int advchain_consistency_fused_bwd(const float* pred, const float* ref, const fl
   if (d.voxels() >= (1ll << 31) || !march4_ok(d, pred, ref, R, mask) || (reinterpret_cast<uintptr_t>(grad_pred) & 15) != 0)
     return ADVCHAIN_ERR_UNSUPPORTED;
   if (N == 0) return ADVCHAIN_OK;
+  const bool kl = c_kl != 0.f;
+  if (ndim == 3 && R && z3_takes(d, true)) {          // the forward of this shape marched along z: so does its backward
+    const int zc = z3_chunk(d, N);
+    const dim3 gz = z3_grid(d, N, zc), bz(kZ3Waves * 64);
+    const size_t lds = z3_lds(d, K);
+    hipStream_t stz = (hipStream_t)stream;
+#define BWD3DZ(K_) do { \
+      if (kl) hipLaunchKernelGGL((k_loss_fused_bwd3d_z<K_, true>), gz, bz, lds, stz, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, zc, c_kl, ref_is_prob); \
+      else hipLaunchKernelGGL((k_loss_fused_bwd3d_z<K_, false>), gz, bz, lds, stz, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, zc, c_kl, ref_is_prob); } while (0)
+    switch (K) { case 2: BWD3DZ(2); break; case 3: BWD3DZ(3); break; default: BWD3DZ(4); break; }
+#undef BWD3DZ
+    ADVCHAIN_LAUNCH_CHECK();
+    return ADVCHAIN_OK;
+  }
   const int mlen = march4_len(d, N);
   const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
   hipStream_t st = (hipStream_t)stream;
-  const bool kl = c_kl != 0.f;
 #define FUSED_BWD(DIM_, K_) do { \
     if (kl) hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, true>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); \
     else hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, false>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); } while (0)

@@ -1260,6 +1260,46 @@ def test_consistency_loss_row_kernels(dims):
         assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10
 
 
+@pytest.mark.parametrize("dims", [(40, 50, 64), (37, 33, 80), (19, 40, 128), (70, 30, 16), (2, 3, 8), (33, 15, 4)])
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_fused_loss_3d_marching_along_z(dims, K):
+    """k_loss_fused_fwd3d_z / _bwd3d_z (round 5: the 3D loss from the logits, y neighbours of a row through LDS, planes in
+    chunks): several row tiles and plane chunks per volume, halo rows and planes at the volume's faces, rows of 4 .. 128
+    voxels, no mask / a one-channel mask, with and without the 'kl' term and is_gt references -- value and gradient vs the
+    CPU oracle (common/loss.py:8-87,102-220,223-249), and vs the three-kernel form (ops.FUSED_LOSS = False)."""
+    from advchain_amd import ops
+    from advchain_amd.common.loss import calc_segmentation_consistency
+    from oracle import advchain_oracle as O
+    N = 2
+    pred = rand((N, K) + dims, 321) * 3
+    ref = rand((N, K) + dims, 322) * 3
+    m1 = (rand((N, 1) + dims, 323) > -0.7).float()
+    onehot = F.one_hot(ref.argmax(1), K).movedim(-1, 1).float().contiguous()
+    for types, weights in ((["mse", "contour"], [1.0, 0.5]), (["mse", "kl", "contour"], [0.7, 1.3, 0.5])):
+        for mask, is_gt in ((None, False), (m1, False), (m1, True)):
+            r = onehot if is_gt else ref
+            a = pred.clone().requires_grad_(True)
+            v_ref = O.consistency_loss(a, r, types, weights, mask=None if mask is None else mask.expand(N, K, *dims), is_gt=is_gt)
+            v_ref.backward()
+            got = {}
+            for fused in (True, False):
+                ops.FUSED_LOSS = fused
+                try:
+                    b = pred.to(DEV).requires_grad_(True)
+                    v = calc_segmentation_consistency(b, r.to(DEV), types, weights, scales=[0],
+                                                      mask=None if mask is None else mask.to(DEV).expand(N, K, *dims), is_gt=is_gt)
+                    v.backward()
+                    got[fused] = (float(v), b.grad.cpu())
+                finally:
+                    ops.FUSED_LOSS = True
+            tag = (types, mask is not None, is_gt)
+            for fused in (True, False):
+                assert abs(got[fused][0] - float(v_ref)) < 1e-7 + 2e-5 * abs(float(v_ref)), (tag, fused)
+                assert maxdiff(got[fused][1], a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10, (tag, fused)
+            # the two forms fold in the same order: their gradients agree far below the tolerance against the oracle
+            assert maxdiff(got[True][1], got[False][1]) < 2e-6 * float(a.grad.abs().max()) + 1e-12, tag
+
+
 @pytest.mark.parametrize("dims", [(12, 64), (7, 9, 80), (11, 20), (5, 6, 64), (9, 11), (3, 5, 7)])
 @pytest.mark.parametrize("K", [2, 4, 5, 6])
 def test_kl_term_in_every_kernel_variant(dims, K):
