@@ -17,6 +17,7 @@
 // direct gathers, block-uniformly.  The theta-gradient kernel is the same walk with the derivative weights.
 #include <stdlib.h>
 #include "sampler_common.h"
+#include "affine_geo.h"
 
 namespace advchain {
 
@@ -341,7 +342,8 @@ k_affine_box_fwd(const float* __restrict__ in, const float* __restrict__ theta, 
 template <int DIM, int TZ>
 __global__ void __launch_bounds__(kBlock, (DIM == 3 ? 2 : 4))   // (2D at 3 waves a SIMD, no spills: 27.7 against 25.8 us)
 k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
-                    float* __restrict__ gtheta_partial, int C, Dims d, float* __restrict__ tilemax) {
+                    float* __restrict__ gtheta_partial, int C, Dims d, float* __restrict__ tilemax, float* __restrict__ geo,
+                    int* __restrict__ gmode) {
   using G = BoxGeom<DIM, TZ>;
   constexpr int VPT = G::TX * G::TY * G::TZ / kBlock;
   constexpr int NT = DIM * (DIM + 1);
@@ -350,6 +352,8 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
   __shared__ float smem[4 * NT];
   const int V = (int)d.voxels();
   const int n = blockIdx.y;
+  // the per-sample geometry the grad_in kernel behind this launch reads (k_affine_geometry's job, on the side)
+  if (geo && blockIdx.x == 0 && threadIdx.x == 0) affine_geometry_one<DIM>(theta, geo, gmode, n, d);
   const Theta<DIM> th = load_theta<DIM>(theta, n);
   int tx0, ty0, tz0;
   tile_origin<DIM, TZ>(d, tx0, ty0, tz0);
@@ -510,7 +514,7 @@ k_affine_box_gtheta(const float* __restrict__ gout, const float* __restrict__ in
 //   geo[n] = { M (3x3, xyz order), t (3), Minv (3x3), ext (3) }; mode[n] != 0: the sample goes through the global-atomic
 //   kernel (zero-fill here).
 // ---------------------------------------------------------------------------------------------
-constexpr int kGeoFloatsBox = 24;   // = kGeoFloats of sampler.hip
+constexpr int kGeoFloatsBox = kGeoFloats;
 
 template <int DIM, int CMAX>
 __global__ void __launch_bounds__(kBlock)
@@ -722,13 +726,14 @@ int advchain_affine_box_tiles(int ndim, Dims d) { return ndim == 3 ? box_tiles<3
 // sample, 0 when the shape is not taken.  tilemax (optional, N x nblocks floats): max |grad_out| of every output tile, by
 // tile position -- the fixed-point scale of advchain_affine_box_gin_launch when it runs AFTER this launch.
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
-                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax) {
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax, float* geo,
+                                      int* mode) {
   if (!box_shape_ok(d, in, gout, nullptr)) return 0;
   const int nb = ndim == 3 ? box_tiles<3, 8>(d) : box_tiles<2, 1>(d);     // (the tiles of k_affine_box_gin: tilemax)
   if (nb > max_blocks) return 0;
   dim3 b(kBlock), g(nb, (unsigned)N);
-  if (ndim == 3) hipLaunchKernelGGL((k_affine_box_gtheta<3, 8>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax);
-  else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax);
+  if (ndim == 3) hipLaunchKernelGGL((k_affine_box_gtheta<3, 8>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax, geo, mode);
+  else hipLaunchKernelGGL((k_affine_box_gtheta<2, 1>), g, b, 0, st, gout, in, theta, gpart, (int)C, d, tilemax, geo, mode);
   return nb;
 }
 

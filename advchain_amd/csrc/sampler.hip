@@ -16,6 +16,7 @@
 // fallback for resampling / nearest.  No MFMA: there is no contraction here.
 #include <stdlib.h>
 #include "sampler_common.h"
+#include "affine_geo.h"
 
 namespace advchain {
 
@@ -587,45 +588,12 @@ k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, 
 // arithmetic, so the weights are bit-identical to the scatter formulation -- without a single atomic.
 //   geo[n] = { M (3x3, xyz order), t (3), Minv (3x3), ext (3) }, mode[n] = 0 gather | 1 fall back to atomics
 // ---------------------------------------------------------------------------------------------
-constexpr int kGeoFloats = 24;
-constexpr float kGatherMaxExt = 6.f;
-
 template <int DIM>
 __global__ void k_affine_geometry(const float* __restrict__ theta, float* __restrict__ geo, int* __restrict__ mode,
                                   int N, Dims d) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const int S[3] = {d.s2, d.s1, d.s0};  // x, y, z
-  float M[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
-  bool ok = true;
-  for (int r = 0; r < DIM; ++r) {
-    float sum = 0.f;
-    for (int a = 0; a < DIM; ++a) {
-      const float th = theta[(n * DIM + r) * (DIM + 1) + a];
-      if (S[a] > 1) { M[r][a] = th * (float)(S[r] - 1) / (float)(S[a] - 1); sum += th; }
-      else { M[r][a] = 0.f; ok = false; }
-    }
-    t[r] = ((theta[(n * DIM + r) * (DIM + 1) + DIM] - sum) + 1.f) * 0.5f * (float)(S[r] - 1);
-  }
-  const float a = M[0][0], b = M[0][1], c = M[0][2], e = M[1][0], f = M[1][1], g = M[1][2], h = M[2][0], i = M[2][1], j = M[2][2];
-  const float A = f * j - g * i, B = -(e * j - g * h), Cc = e * i - f * h;
-  const float det = a * A + b * B + c * Cc;
-  float Mi[3][3];
-  const float rdet = 1.f / det;
-  Mi[0][0] = A * rdet; Mi[0][1] = -(b * j - c * i) * rdet; Mi[0][2] = (b * g - c * f) * rdet;
-  Mi[1][0] = B * rdet; Mi[1][1] = (a * j - c * h) * rdet;  Mi[1][2] = -(a * g - c * e) * rdet;
-  Mi[2][0] = Cc * rdet; Mi[2][1] = -(a * i - b * h) * rdet; Mi[2][2] = (a * f - b * e) * rdet;
-  float* gn = geo + (int64_t)n * kGeoFloats;
-  float ext[3];
-  for (int q = 0; q < 3; ++q) {
-    ext[q] = fabsf(Mi[q][0]) + fabsf(Mi[q][1]) + fabsf(Mi[q][2]) + 0.01f;
-    if (q < DIM && !(ext[q] < kGatherMaxExt)) ok = false;   // also catches NaN / inf
-  }
-  if (!(fabsf(det) > 1e-6f)) ok = false;
-  for (int r = 0; r < 3; ++r)
-    for (int q = 0; q < 3; ++q) { gn[r * 3 + q] = M[r][q]; gn[12 + r * 3 + q] = Mi[r][q]; }
-  for (int r = 0; r < 3; ++r) { gn[9 + r] = t[r]; gn[21 + r] = ext[r]; }
-  mode[n] = ok ? 0 : 1;
+  affine_geometry_one<DIM>(theta, geo, mode, n, d);
 }
 
 constexpr int kGatherCand = 12;   // listed candidates per voxel (LDS column); the rest are accumulated where found
@@ -790,7 +758,7 @@ bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* 
                                     int ride_nonzero = 0);
 int advchain_affine_box_tiles(int ndim, Dims d);
 int advchain_affine_box_gtheta_launch(const float* gout, const float* in, const float* theta, float* gpart, int64_t N,
-                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax);
+                                      int64_t C, int ndim, Dims d, int max_blocks, hipStream_t st, float* tilemax, float* geo = nullptr, int* mode = nullptr);
 bool advchain_affine_box_gin_launch(const float* gout, const float* theta, const float* geo, const int* mode, float* gin,
                                     int64_t N, int64_t C, int ndim, Dims d, hipStream_t st, const float* tilemax);
 
@@ -1351,17 +1319,19 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     float* tilemax = nullptr;
     if (gpart) {
       float* tm = reinterpret_cast<float*>(md + N);
-      nbx_theta = advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st, tm);
+      // (... and the per-sample geometry of the grad_in kernels on the side: no k_affine_geometry launch then)
+      nbx_theta = advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st, tm, geo, md);
       if (nbx_theta > 0) tilemax = tm;
     }
+    const bool have_geo = nbx_theta > 0;
     if (ndim == 3) {
-      hipLaunchKernelGGL(k_affine_geometry<3>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
+      if (!have_geo) hipLaunchKernelGGL(k_affine_geometry<3>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
       if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st, tilemax)) {}
       else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<3, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<3, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else hipLaunchKernelGGL((k_affine_gather_bwd<3, 8>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
     } else {
-      hipLaunchKernelGGL(k_affine_geometry<2>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
+      if (!have_geo) hipLaunchKernelGGL(k_affine_geometry<2>, dim3(advchain_blocks(N, 64)), dim3(64), 0, st, theta, geo, md, (int)N, d);
       if (advchain_affine_box_gin_launch(grad_out, theta, geo, md, grad_in, N, C, ndim, d, st, tilemax)) {}
       else if (C <= 1) hipLaunchKernelGGL((k_affine_gather_bwd<2, 1>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);
       else if (C <= 4) hipLaunchKernelGGL((k_affine_gather_bwd<2, 4>), g, b, 0, st, grad_out, theta, geo, md, grad_in, (int)C, d);

@@ -41,6 +41,28 @@ def _call(solver, data, model, n_iter, seed):
              solver.init_output.clone()] + [t.param.detach().clone() for t in solver.chain_of_transforms])
 
 
+def _deterministic(plan):
+    """Does the frozen selection stay on the bit-reproducible formulations?  The window scatter (2D: image warps beyond 16 px,
+    squarings beyond 32 px; 3D: beyond 4 voxels) flushes with float atomics: two runs of the SAME launches then differ in the
+    last bits, and so do a replay and its launch-by-launch twin."""
+    for site in plan.frozen:
+        if site["kind"] != "chain":
+            continue
+        vals, n, d = site["bounds"].values(), site["n"], site["d"]
+        lim_sq, lim_warp = (32.0, 16.0) if d == 2 else (4.0, 4.0)
+        if any(v >= lim_sq - 0.001 for v in vals[:n]) or vals[n] >= lim_warp - 0.001:
+            return False
+    return True
+
+
+def _same(a, b, exact):
+    for x, y in zip(a, b):
+        if exact:
+            assert torch.equal(x, y)
+        else:
+            assert float((x - y).abs().max()) <= 1e-5 * max(1e-6, float(y.abs().max())) + 1e-8
+
+
 def _close(a, b, tol=2e-5):
     for i, (x, y) in enumerate(zip(a, b)):
         scale = max(1e-6, float(y.abs().max()))
@@ -72,10 +94,14 @@ def test_replay_matches_the_ordinary_path(case, steps):
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(case):
-    """The frozen plan without a capture: the same kernels with the same arguments in the same order."""
+@pytest.mark.parametrize("steps", ["one", "many"])
+def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(case, steps):
+    """The frozen plan without a capture: the same kernels with the same arguments in the same order.  One ascent step keeps
+    every displacement on the bit-reproducible formulations (asserted): exact.  Several steps are exact too unless the plan
+    reaches the float-atomic window scatter (_deterministic)."""
     from advchain_amd import ops
     dims, names, n_iter = CASES[case]
+    n_iter = 1 if steps == "one" else n_iter
     N = 2
     model = make_model(len(dims), device=DEV)
     data = smooth_data(N, 1, dims, 7).to(DEV)
@@ -87,8 +113,9 @@ def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(
     got = _call(graph, data, model, n_iter, 300)
     assert graph.graph_stats["violations"] == 0
     again = _call(graph, data, model, n_iter, 300)
-    for x, y in zip(got, again):
-        assert torch.equal(x, y)
+    exact = _deterministic(rec["plan"])
+    assert exact or steps == "many", "one ascent step left the bit-reproducible formulations"
+    _same(got, again, exact)
     # the same call on a solver that runs eagerly under the graph's frozen plan
     plain = _solver(dims, names, N, False)
     torch.manual_seed(300)
@@ -105,13 +132,13 @@ def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(
     finally:
         ops._PLAN = None
     assert plan.cursor == len(plan.frozen) and int(plan.flag.item()) == 0
-    for t, p in zip(plain.chain_of_transforms, got[4:]):
-        assert torch.equal(t.param.detach(), p), type(t).__name__
+    _same([t.param.detach() for t in plain.chain_of_transforms], got[4:], exact)
     assert torch.equal(io, got[3])
 
 
 def test_a_violated_plan_is_detected_and_the_call_runs_the_ordinary_way():
     dims, names, n_iter = CASES["2d_full"]
+    n_iter = 2          # (displacements stay below the window scatter's regime: the ordinary path is bit-reproducible)
     N = 2
     model = make_model(2, device=DEV)
     data = smooth_data(N, 1, dims, 9).to(DEV)
@@ -146,8 +173,7 @@ def test_a_violated_plan_is_detected_and_the_call_runs_the_ordinary_way():
     got = _call(graph, data, model, n_iter, 400)
     assert rec["state"] == "replay" and graph.graph_stats["captures"] == 2
     again = _call(graph, data, model, n_iter, 400)
-    for x, y in zip(got, again):
-        assert torch.equal(x, y)
+    _same(got, again, _deterministic(rec["plan"]))
 
 
 def test_results_do_not_alias_the_captured_buffers():
