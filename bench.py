@@ -324,6 +324,13 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     extras["gpu_span_ms_by_step"] = {"min": round(per[0], 3), "median": round(per[len(per) // 2], 3), "max": round(per[-1], 3),
                                      "first": [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(min(steps, 6))]}
+    # kernel-busy time and launches per step: the sum of kernel durations of the rocprofv3 kernel trace of THIS command
+    # (tools/profile_bench.sh -> profiles/rNN/per_call_summary.txt, newest round that holds the workload), not an
+    # in-process estimate -- a replayed graph carries no per-kernel events.  host_gap = ms_per_step - gpu_busy
+    busy = profiled_busy(workload)
+    if busy is not None:
+        extras["gpu_busy_ms_per_step"], extras["launches_per_step"], extras["gpu_busy_source"] = busy
+        extras["host_gap_ms_per_step"] = round(elapsed / steps * 1e3 - busy[0], 3)
     extras["abi_calls_per_step"] = abi_calls
     if graphed:
         st = solver.graph_stats
@@ -430,6 +437,27 @@ def profiled_traffic(workload, entry):
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return None, None
+
+
+def profiled_busy(workload):
+    """(kernel-busy ms, kernel launches) per adversarial_training call of `workload` from the newest committed rocprofv3
+    kernel-trace summary (profiles/rNN/per_call_summary.txt, line "<workload>_kernel_stats.csv: GPU busy X ms/call, Y
+    launches/call"), or None."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        rounds = sorted((d for d in os.listdir(root) if d.startswith("r") and d[1:].isdigit()), reverse=True)
+    except OSError:
+        return None
+    for rnd in rounds:
+        try:
+            text = open(os.path.join(root, rnd, "per_call_summary.txt")).read()
+        except OSError:
+            continue
+        m = re.search(r"%s_kernel_stats\.csv: GPU busy ([0-9.]+) ms/call, ([0-9.]+) launches/call" % re.escape(workload), text)
+        if m:
+            return float(m.group(1)), float(m.group(2)), "profiles/%s/per_call_summary.txt (rocprofv3 --kernel-trace --stats of this command)" % rnd
+    return None
 
 
 def _time_pair(x, go, q, halo, reps, disp=None):
