@@ -42,6 +42,9 @@ PROTOTYPES = {
     "advchain_affine_grid2d_bwd_workspace": (_L, [_L, _P]),
     "advchain_affine_grid2d_bwd": (_I, [_P, _P, _P, _L, _P, _P]),
     "advchain_slot_rows_max": (_I, [_P, _P, _L, _L, _I, _P]),
+    "advchain_demons_compose_pair_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _F, _F, _I, _P]),
+    "advchain_demons_compose_pair_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L,
+                                              _I, _I, _P, _F, _F, _P]),
     "advchain_bounds_check": (_I, [_P, _P, _P, _L, _P, _P]),
     "advchain_expo_chain_fused_levels": (_I, [_L, _I, _P, _I, _P]),
     "advchain_expo_chain_fwd": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _P]),

@@ -1601,6 +1601,23 @@ int advchain_gauss_axis(const float* in, float* out, const float* aux, int64_t p
   return ADVCHAIN_OK;
 }
 
+}  // extern "C"
+
+// The shapes advchain_gauss_xy takes (pointer alignment aside): for callers that must know before they enqueue anything
+// (the composite entries of demons_compose.cpp).
+bool advchain_gauss_xy_takes(int ndim, const int64_t* dims, int64_t planes) {
+  static const bool off = getenv("ADVCHAIN_NO_GAUSS_XY") != nullptr;   // A/B knob (the one advchain_gauss_xy reads)
+  if (off || !fdims_ok(ndim, dims)) return false;
+  const Dims d = fmake_dims(ndim, dims);
+  if ((d.s2 & 3) != 0 || d.s2 < 8 || d.s2 > 512 || d.s1 < 8 || planes > 65535 || d.s0 > 65535) return false;
+  int TY = 32;
+  while (TY > 8 && (size_t)(TY + 8) * (2 * d.s2 + 8) * 4 > 53248) TY >>= 1;
+  if (TY > d.s1) TY = (d.s1 + 7) / 8 * 8;
+  return (size_t)(TY + 8) * (2 * d.s2 + 8) * sizeof(float) <= 65536;
+}
+
+extern "C" {
+
 // x and y passes of the separable Gaussian in one launch (rows of 4k <= 512 voxels, 16-byte aligned tensors).  `post` is
 // only legal when y is the last axis (ndim == 2).  Returns ADVCHAIN_ERR_UNSUPPORTED when the shape does not qualify: the
 // caller then runs the per-axis passes.

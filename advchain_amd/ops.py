@@ -184,6 +184,7 @@ PAIR_FIELDS = os.environ.get("ADVCHAIN_NO_PAIR_FIELDS") is None       # a solver
 TILED_SCATTER = True  # LDS-tiled owner-computes scatter (False: global-atomic kernels; for A/B tests)
 FUSED_LOSS = True     # the consistency loss straight from the logits (no P / D intermediates); False: A/B tests
 FUSE_2D = True        # the leading sub-pixel squarings of a 2D chain in one launch (expo_fused2d.hip); False: A/B tests
+COMPOSITE = True      # a paired 2D DemonsCompose direction as ONE C call (demons_compose.cpp: same launches); False: A/B tests
 RIDE_MASK = True      # the solver's validity mask rides through the data's warps (one launch for both); False: A/B tests
 RIDE_INTERPS = ("bilinear", "trilinear", "linear", "nearest")
 
@@ -292,6 +293,13 @@ def raw_gauss_small_pair(x, scale, adjoint=False, weights=None):
                                                      weights or _GAUSS9, float(scale), int(bool(adjoint)), _stream()),
                "gauss_small_pair")
     return out
+
+
+def raw_gauss_small_pair_into(x, out, scale, weights=None):
+    """raw_gauss_small_pair(x, scale) (forward form) into a buffer the caller allocated."""
+    _lib.check(_lib.load().advchain_gauss_small_pair(_ptr(x), _ptr(out), x.shape[0] * x.shape[1], x.dim() - 2,
+                                                     _lib.dims_array(x.shape[2:]), weights or _GAUSS9, float(scale), 0, _stream()),
+               "gauss_small_pair")
 
 
 @_on_tensor_device
@@ -435,10 +443,9 @@ def raw_gauss(x, C, pre=0, post=0, scale=1.0, aux=None, weights=None):
     return cur
 
 
-def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True, sumsq=None, disp_out=None):
+def raw_tp_interp(coef, tables, C, add_identity=False, scale=1.0, want_out=True, sumsq=None, disp_out=None, out=None):
     planes = coef.shape[0] * coef.shape[1]
-    out = None
-    if want_out:
+    if want_out and out is None:
         out = torch.empty((coef.shape[0], coef.shape[1]) + tuple(tables.full_dims), device=coef.device,
                           dtype=torch.float32)
     _lib.check(_lib.load().advchain_tp_interp_fwd(_ptr(coef), _ptr(out), _ptr(tables.itab), _ptr(tables.ftab),
@@ -1117,12 +1124,20 @@ class _DemonsField(torch.autograd.Function):
             raise NotImplementedError("the fused final smoothing exists for the 9-tap window only: ask for the positions")
         ctx.opts = (int(smooth_iter), w9, bool(pos_only))
         s1 = None
-        if pair:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))
+        # 2D paired fields with the default options: ONE C call enqueues the whole direction (advchain_demons_compose_pair_fwd:
+        # the launches of the separate calls below, in their order)
+        composite = (COMPOSITE and pair and vel.shape[1] == 2 and not nsteps_rule and int(smooth_iter) == 1 and not pos_only
+                     and len(w9) == 9 and vel.is_contiguous() and vel[0, 0].numel() <= 4096
+                     and getattr(tables, "dense_inner", None) is not None)
+        ctx.composite = composite
+        if pair and not composite:      # the batch [v; -v]: both fields of a solver step from one chain; returns (field(+v), field(-v))
             s1 = raw_gauss_small_pair(vel, scale, weights=w9)         # the negated copy is never materialised
             if s1 is None:
                 vel = torch.cat([vel, -vel], 0)
         d = vel.shape[1]
-        if s1 is None:
+        if composite:
+            s1 = torch.empty((2 * vel.shape[0],) + tuple(vel.shape[1:]), device=vel.device, dtype=torch.float32)
+        elif s1 is None:
             s1 = raw_gauss(vel, d, pre=1, scale=scale, weights=w9)
         for _ in range(int(smooth_iter) - 1):      # smooth_iter > 1 (adv_morph.py:386-387): the same window again
             s1 = raw_gauss(s1, d, weights=w9)
@@ -1172,7 +1187,9 @@ class _DemonsField(torch.autograd.Function):
             if pend is not None and pend.event.query():
                 _note_chain_bounds(key, pend.values(), n)
             hints = _CHAIN_HINTS.get(key)
-        phi0 = raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
+        full = (N, d) + tuple(tables.full_dims)
+        phi0 = torch.empty(full, device=vel.device, dtype=torch.float32) if composite else \
+            raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0))
         # the n squarings: one C call (advchain_expo_chain_fwd), phi_1..phi_{n-1} in one stacked buffer
         fields = torch.empty((n - 1,) + tuple(phi0.shape), device=phi0.device, dtype=torch.float32)
         pos = torch.empty_like(phi0)
@@ -1181,12 +1198,27 @@ class _DemonsField(torch.autograd.Function):
         if COUNT_FUSED and harr is not None and disp is not None and FUSE_2D:      # (tests: which formulation the chain takes)
             FUSE_STATS["fused_levels"] += _lib.load().advchain_expo_chain_fused_levels(phi0.shape[0], d, _lib.dims_array(phi0.shape[2:]), n, harr)
         try:
-            _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
-                                                           _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
-                                                           None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
-                       "expo_chain_fwd")
-            q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
-            rows_max = None if disp is None else raw_slot_rows_max(disp, reset=True)
+            rows_max = rc = None
+            if composite:
+                q = torch.empty_like(phi0)
+                rows_max = None if disp is None else torch.empty(disp.shape[0], device=vel.device, dtype=torch.float32)
+                rc = _lib.load().advchain_demons_compose_pair_fwd(
+                    _ptr(vel), _ptr(s1), _ptr(phi0), _ptr(fields), _ptr(pos), _ptr(q), _ptr(disp), _ptr(rows_max), _ptr(tables.itab),
+                    _ptr(tables.ftab), _lib.dims_array(tables.S), _lib.dims_array(tables.g), _lib.dims_array(tables.B),
+                    vel.shape[0], d, n, harr, w9, float(scale), float(inv), int(bool(FUSE_2D)), _stream())
+                if rc == -2:        # (a launch would not take the shape; nothing was enqueued: the separate calls)
+                    composite = ctx.composite = False
+                    raw_gauss_small_pair_into(vel, s1, scale, w9)
+                    raw_tp_interp(s1, tables, d, add_identity=True, scale=inv, disp_out=row(0), out=phi0)
+                else:
+                    _lib.check(rc, "demons_compose_pair_fwd")
+            if not composite:
+                _lib.check(_lib.load().advchain_expo_chain_fwd(_ptr(phi0), _ptr(fields), _ptr(pos), phi0.shape[0], d,
+                                                               _lib.dims_array(phi0.shape[2:]), n, _ptr(disp), harr,
+                                                               None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
+                           "expo_chain_fwd")
+                q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
+                rows_max = None if disp is None else raw_slot_rows_max(disp, reset=True)
         except BaseException:
             # (the slots, the fused-chain flag and its barrier counter may hold partial state: the next chain starts from a
             # fresh zero-filled accumulator)
@@ -1221,7 +1253,11 @@ class _DemonsField(torch.autograd.Function):
         # the whole batch, two copies and an add per chain -- cost more than the concatenation)
         smooth_iter, w9, pos_only = ctx.opts
         gq = tuple(_dev(g, "grad") for g in grads) if ctx.pair else _dev(grads[0], "grad")
-        if pos_only:
+        composite = (ctx.composite and TILED_SCATTER and ctx.pair and gq[0].is_contiguous() and gq[1].is_contiguous()
+                     and gq[0].shape == gq[1].shape)
+        if composite:
+            gpos = torch.empty_like(pos)
+        elif pos_only:
             gpos = torch.cat(gq, 0) if ctx.pair else gq.contiguous()
         else:
             gpos = raw_gauss(gq, d, post=2, aux=pos, weights=w9)          # adjoint of gauss(border_identity(.) - id) + id
@@ -1241,6 +1277,24 @@ class _DemonsField(torch.autograd.Function):
             big = 2 if d == 3 else 16
             halos = [big, big, max(1, big // 2)] + [1 if d == 3 else 2] * n
         halos = halos[:n]
+        if composite:      # ONE C call for the whole direction (advchain_demons_compose_pair_bwd: the launches of the calls below)
+            N2 = gpos.shape[0]
+            S, gg = list(tables.S), list(tables.g)
+            g, scratch = torch.empty_like(gpos), torch.empty_like(gpos)
+            t1 = torch.empty((N2, d, S[1], gg[2]), device=gpos.device, dtype=torch.float32)
+            gs1 = torch.empty((N2, d, gg[1], gg[2]), device=gpos.device, dtype=torch.float32)
+            gvel = torch.empty((N2 // 2, d, gg[1], gg[2]), device=gpos.device, dtype=torch.float32)
+            wd, wlo, WB = tables.dense_inner
+            rc = _lib.load().advchain_demons_compose_pair_bwd(
+                _ptr(gq[0]), _ptr(gq[1]), _ptr(pos), _ptr(phi0), _ptr(fields), _ptr(gpos), _ptr(g), _ptr(scratch), _ptr(ws), _ptr(t1),
+                _ptr(gs1), _ptr(gvel), (ctypes.c_int32 * n)(*[int(h) for h in halos]), _ptr(tables.itab), _ptr(tables.ftab), _ptr(wd),
+                _ptr(wlo), int(WB), _lib.dims_array(S), _lib.dims_array(gg), _lib.dims_array(tables.B), N2 // 2, d, n, w9, float(scale),
+                float(inv), _stream())
+            if rc != -2:
+                _lib.check(rc, "demons_compose_pair_bwd")
+                return gvel, None, None, None, None, None, None
+            gpos = raw_gauss(gq, d, post=2, aux=pos, weights=w9)       # (nothing was enqueued: the separate calls)
+            g = gpos
         if ws is None:     # (global-atomic A/B path: per-step calls with zero-filled outputs)
             phis = [phi0] + list(fields.unbind(0))
             for i, phi in enumerate(reversed(phis)):

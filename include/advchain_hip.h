@@ -145,6 +145,29 @@ int advchain_expo_chain_fwd(const float* phi0, float* fields, float* pos, int64_
 int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const float* fields, float* grad_phi0, float* scratch,
                             int32_t* workspace, const int32_t* halos, int64_t N, int ndim, const int64_t* dims, int n,
                             void* stream);
+/* Composite entries (round 5): ONE call enqueues a whole DemonsCompose direction for the paired field [v; -v] of a solver step
+ * -- replaces: AdvMorph.DemonsCompose (adv_morph.py:454-491: Gaussian of the low-resolution velocity, F.interpolate, the
+ * exponentiation of :116-146, composition with the identity grid, the final Gaussian) as the reference's forward() / backward()
+ * call it (adv_morph.py:299-303,322-324), and its autograd.  2D, the 9-tap window, low-resolution planes of at most 4096
+ * values.  The launches are exactly those of advchain_gauss_small_pair, advchain_tp_interp_fwd, advchain_expo_chain_fwd,
+ * advchain_gauss_xy, advchain_slot_rows_max (forward) and advchain_gauss_xy, advchain_expo_chain_bwd,
+ * advchain_band_reduce_rows_dense / _axis, advchain_gauss_small_pair (backward) in that order: same results, one trip out of
+ * the host language per direction instead of five or six.  Every buffer is the caller's: s1 (2N, d, g...), phi0 / pos / q /
+ * gpos / g / scratch (2N, d, S...), fields (n-1, 2N, d, S...), disp ((n+2) x ADVCHAIN_DISP_SLOTS, zero) + rows_max (n+2) or both
+ * NULL, t1 (2N, d, S0, g1), gs1 (2N, d, g...), gvel (N, d, g...); tables as for advchain_tp_interp_fwd (3 axes, trivial leading
+ * one), wd / wlo / WB: the densified innermost bands of advchain_band_reduce_rows_dense.  Returns ADVCHAIN_ERR_UNSUPPORTED (-2)
+ * with NOTHING enqueued when a launch would not take the shape: issue the separate calls then.                              */
+int advchain_demons_compose_pair_fwd(const float* vel, float* s1, float* phi0, float* fields, float* pos, float* q,
+                                     float* disp, float* rows_max, const int32_t* itab, const float* ftab,
+                                     const int64_t* S3, const int64_t* g3, const int64_t* B3, int64_t N, int ndim, int n,
+                                     const int32_t* hints, const float* weights9_host, float scale, float inv, int fuse,
+                                     void* stream);
+int advchain_demons_compose_pair_bwd(const float* gq_lo, const float* gq_hi, const float* pos, const float* phi0,
+                                     const float* fields, float* gpos, float* g, float* scratch, int32_t* ws, float* t1,
+                                     float* gs1, float* gvel, const int32_t* halos, const int32_t* itab, const float* ftab,
+                                     const float* wd, const int32_t* wlo, int64_t WB, const int64_t* S3, const int64_t* g3,
+                                     const int64_t* B3, int64_t N, int ndim, int n, const float* weights9_host, float scale,
+                                     float inv, void* stream);
 /* max over samples and axes of |sampling position - own voxel| of the field phi, in voxels: the displacement
  * bound `halo` above wants.  out: one float, zero-initialised by the caller (atomic max).            */
 int advchain_max_displacement(const float* phi, float* out, int64_t N, int ndim, const int64_t* dims, void* stream);

@@ -219,3 +219,33 @@ def test_fused_backward_levels_equal_the_per_squaring_launches(dims, k):
         assert torch.equal(out, g), float((out - g).abs().max())
     else:       # (a window-scatter step in front: float atomics, compared to rounding)
         assert float((out - g).abs().max()) <= 1e-5 * max(1.0, float(g.abs().max()))
+
+
+@pytest.mark.parametrize("dims,vs,N", [((256, 256), [16, 16], 8), ((192, 192), [12, 12], 4), ((64, 96), [4, 6], 2), ((37, 50), [3, 4], 3)])
+def test_composite_entries_equal_the_separate_calls(dims, vs, N):
+    """advchain_demons_compose_pair_fwd / _bwd (one C call per DemonsCompose direction, csrc/demons_compose.cpp) against the
+    five / six separate calls they sequence (ops.COMPOSITE = False): both fields and the velocity gradient, bit for bit;
+    shapes the fast kernels do not take (rows that are not a multiple of 4) fall back without enqueueing anything."""
+    from advchain_amd import bands, ops
+    tabs = bands.upsample_tables(vs, list(dims), DEV)
+    v = rand((N, 2) + tuple(vs), 51).to(DEV)
+    v = v / v.reshape(N, -1).norm(dim=1).view(N, 1, 1, 1)
+    outs = {}
+    for comp in (False, True):
+        ops.COMPOSITE = comp
+        ops._CHAIN_HINTS.clear()
+        try:
+            res = []
+            for rep in range(2):                  # (the second evaluation has hints: fused squarings inside the chain call)
+                vv = v.clone().requires_grad_(True)
+                qp, qm = ops.demons_field_pair(vv, 1.5, tabs, False)
+                (qp * qp).sum().backward(retain_graph=True)
+                g1 = vv.grad.clone()
+                (qp.sum() + 2 * (qm * qm).sum()).backward()
+                res.append((qp.detach().clone(), qm.detach().clone(), g1, vv.grad.clone()))
+            outs[comp] = res
+        finally:
+            ops.COMPOSITE = True
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
