@@ -750,7 +750,7 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
 int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                    hipStream_t st, int rm_flags = 0);
-bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H);
+bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H, int64_t N);
 
 // affine_box.hip: LDS-staged source box (linear, zeros padding, rows of 4k voxels)
 bool advchain_affine_box_fwd_launch(const float* in, const float* theta, float* out, int64_t N, int64_t C, int ndim, Dims d,
@@ -1243,7 +1243,7 @@ int advchain_expo_chain_bwd(const float* grad_pos, const float* phi0, const floa
   const Dims dd = make_dims(ndim, dims);
   static const bool no_handover = getenv("ADVCHAIN_NO_ROWMAX_HANDOVER") != nullptr;   // A/B knob: a k_march_rowmax pre-pass per launch
   auto rows = [&](int i) {
-    return !no_handover && ndim == 2 && workspace && i >= 0 && i < n - kf && halos[i] <= -2 && advchain_scatter_rows2d_takes(true, 2, dd, PAD_BORDER, -halos[i]);
+    return !no_handover && ndim == 2 && workspace && i >= 0 && i < n - kf && halos[i] <= -2 && advchain_scatter_rows2d_takes(true, 2, dd, PAD_BORDER, -halos[i], N);
   };
   for (int i = 0; i < n - kf; ++i) {                 // squaring m = n-1 .. kf; the last step of the call writes grad_phi0
     const int m = n - 1 - i;

@@ -1226,9 +1226,12 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
 using namespace advchain;
 
 // The shapes / bounds the whole-row scatter takes; TY = owned rows per workgroup (0: not taken).
-static int rows2d_tile(bool self, int64_t C, const Dims& d, int padding, int H) {
+static int rows2d_tile(bool self, int64_t C, const Dims& d, int padding, int H, int64_t N) {
   static const bool off = getenv("ADVCHAIN_NO_SCATTER_ROWS2D") != nullptr;   // A/B knob
-  static const int hmin = 3;   // measured optimum (was a tuning knob until round 4)
+  // from which bound on: 3 pixels (below, the gather form of adjoint_gather.hip is faster) -- for a squaring whose launch fills
+  // the machine, 2 (round 5, once the own rows' coordinate path moved into their deposit visit: 35 against 46 us in a chain
+  // at 64 x 2 x 256 x 256; with 96 workgroups, 8 x 2 x 192 x 192, the gather form wins, 8.6 against 14.3 us)
+  const int hmin = (self && N * ((d.s1 + 15) / 16) >= 512) ? 2 : 3;
   if (off || padding == PAD_REFLECTION || H < hmin || H > (self ? 32 : 16) || d.s0 != 1) return 0;
   if (d.s2 < 16 || d.s2 > 512 || d.voxels() * 4 >= (1ll << 31)) return 0;
   if (self ? C != 2 : (C != 1 && C != 4)) return 0;
@@ -1239,7 +1242,7 @@ static int rows2d_tile(bool self, int64_t C, const Dims& d, int padding, int H) 
   if ((size_t)C * TY * d.s2 * sizeof(int) > 65536 - 64 || TY * nseg > 64) return 0;
   return TY;
 }
-bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H) { return rows2d_tile(self, C, d, padding, H) > 0; }
+bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, int H, int64_t N) { return rows2d_tile(self, C, d, padding, H, N) > 0; }
 
 // 2D, exact bound of H = 3..16 pixels (squarings: ..32).  ADVCHAIN_ERR_UNSUPPORTED: use the gather form / the window scatter.
 // rm_flags (the chain's consecutive launches; 0 = a launch on its own): bit 0 = the row maxima of `gout` are already in
@@ -1248,7 +1251,7 @@ bool advchain_scatter_rows2d_takes(bool self, int64_t C, Dims d, int padding, in
 int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                    hipStream_t st, int rm_flags) {
-  const int TY = (workspace && gin) ? rows2d_tile(self, C, d, padding, H) : 0;
+  const int TY = (workspace && gin) ? rows2d_tile(self, C, d, padding, H, N) : 0;
   if (TY == 0) return ADVCHAIN_ERR_UNSUPPORTED;
   const size_t lds = (size_t)C * TY * d.s2 * sizeof(int);
   float* rm_a = reinterpret_cast<float*>(workspace + 4);       // (the overflow list of the tiled kernels: unused here)

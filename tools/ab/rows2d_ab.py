@@ -48,7 +48,7 @@ def main():
     dev = torch.device("cuda")
     res = {}
     for N, dims in ((64, (256, 256)), (8, (192, 192)), (5, (100, 128)), (3, (64, 512)), (2, (33, 16))):
-        for px, halo in ((3.5, -4), (7.0, -8), (14.0, -16), (28.0, -32)):
+        for px, halo in ((1.7, -2), (3.5, -4), (7.0, -8), (14.0, -16), (28.0, -32)):
             if px > min(dims) / 2:
                 continue
             phi = field(N, dims, px, 11, dev)
