@@ -222,7 +222,7 @@ int advchain_grid_sample_bicubic2d_bwd(const float* grad_out, const float* in, c
   if (N == 0) return ADVCHAIN_OK;
   const int H = (int)in_dims[0], W = (int)in_dims[1], OH = (int)out_dims[0], OW = (int)out_dims[1];
   hipStream_t st = (hipStream_t)stream;
-  if (grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * H * W, st);
+  if (grad_in) advchain_zero_async(grad_in, sizeof(float) * N * C * H * W, st);
   dim3 g(advchain_blocks((int64_t)OH * OW, kBlock), (unsigned)N), b(kBlock);
   BICUBIC_PAD(padding, { hipLaunchKernelGGL(k_bicubic2d_bwd<PAD>, g, b, 0, st, grad_out, in, grid, grad_in, grad_grid, (int)C, H, W, OH, OW); });
   ADVCHAIN_LAUNCH_CHECK();

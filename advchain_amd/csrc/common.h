@@ -196,3 +196,24 @@ extern "C" void advchain_set_error_(const char* msg);
   } while (0)
 
 static inline int advchain_blocks(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+// Zero-fill as a kernel of this library rather than hipMemsetAsync: under stream capture a memset becomes a
+// memset node, which the runtime executes outside the kernel queue's own order (LESSONS 66) -- every node of a
+// captured ascent is a kernel node.  `bytes` must be a multiple of 4 (every caller clears float arrays).
+static __global__ void __launch_bounds__(256) k_zero_fill(float* __restrict__ p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n && ((uintptr_t)(p + i) & 15) == 0) {
+      *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (int64_t j = i; j < n && j < i + 4; ++j) p[j] = 0.f;
+    }
+  }
+}
+static inline void advchain_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const int64_t n = (int64_t)(bytes / 4);
+  if (n <= 0) return;
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, st, (float*)p, n);
+}

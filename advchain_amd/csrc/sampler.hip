@@ -956,7 +956,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                          clamp_grid, workspace, 0, halo < 0 ? -halo : halo, (hipStream_t)stream);
   }
-  if (workspace && grad_in) (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
+  if (workspace && grad_in) advchain_zero_async(grad_in, sizeof(float) * N * C * id.voxels(), (hipStream_t)stream);
   return ndim == 3 ? launch_grid_sample_bwd<3>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream)
                    : launch_grid_sample_bwd<2>(grad_out, in, grid, grad_in, grad_grid, N, C, id, od, interp, padding, clamp_grid, (hipStream_t)stream);
 }
@@ -1304,7 +1304,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
   float* gpart = grad_theta ? workspace : nullptr;
   if (interp == INTERP_NEAREST && !grad_in) {
     // nearest: zero gradient w.r.t. theta
-    (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
+    advchain_zero_async(grad_theta, sizeof(float) * N * ndim * (ndim + 1), st);
     return ADVCHAIN_OK;
   }
   const int* mode = nullptr;
@@ -1339,7 +1339,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     }
     mode = md;
   } else if (grad_in) {
-    (void)hipMemsetAsync(grad_in, 0, sizeof(float) * N * C * d.voxels(), st);
+    advchain_zero_async(grad_in, sizeof(float) * N * C * d.voxels(), st);
   }
   int nb_theta = nb;      // block partials per sample of grad_theta
   if (gpart && interp == INTERP_LINEAR && padding == PAD_ZEROS && (!grad_in || mode)) {
@@ -1361,7 +1361,7 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
   ADVCHAIN_LAUNCH_CHECK();
   if (grad_theta) {
     if (interp == INTERP_NEAREST) {
-      (void)hipMemsetAsync(grad_theta, 0, sizeof(float) * N * ndim * (ndim + 1), st);
+      advchain_zero_async(grad_theta, sizeof(float) * N * ndim * (ndim + 1), st);
     } else {
       const int K = ndim * (ndim + 1);
       hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)N, K), dim3(kBlock), 0, st, workspace, grad_theta, nb_theta, K);

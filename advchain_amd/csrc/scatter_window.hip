@@ -392,7 +392,7 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
   if (d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return ADVCHAIN_ERR_UNSUPPORTED;   // 24-bit index products
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (ndim == 3 && (halo < 0 ? -halo : halo) < min3) return ADVCHAIN_ERR_UNSUPPORTED;
-  (void)hipMemsetAsync(gin, 0, sizeof(float) * N * C * d.voxels(), st);
+  advchain_zero_async(gin, sizeof(float) * N * C * d.voxels(), st);
   const bool gg = ggrid != nullptr;
   dim3 b(kBlock);
 #define GO_PAD(C_, SELF_, GG_) \

@@ -242,3 +242,24 @@ def test_batchnorm_model_in_train_mode_is_captured():
         stats0 = [b.clone() for b in model.buffers()]
         _close(got, want, 1e-4)
     assert graph.graph_stats["replays"] >= 2
+
+
+def test_hundreds_of_replays_at_the_headline_shape_stay_inside_the_frozen_selection():
+    """The fault of LESSONS 66: with the library's clears enqueued as hipMemsetAsync -- memset NODES in the capture -- one
+    process in three produced garbage gradients somewhere between the 80th and the 200th replay at this shape (caught by the
+    bounds check, so it cost time, not results).  With every node a kernel node, 18 processes x 200 replays were clean; this
+    holds one process-worth of that here: no violation, no recapture, finite results."""
+    import bench
+    wl = bench.WORKLOADS["cfg2"]
+    dev = torch.device(DEV)
+    torch.manual_seed(1234)
+    data = torch.rand(wl["batch"], 1, *wl["dims"], device=dev)
+    model = bench.make_model(len(wl["dims"])).to(dev)
+    solver = bench.build_solver(wl, dev)
+    solver.hip_graph = True
+    kw = bench.solver_kwargs(wl, dev)
+    for _ in range(solver.hip_graph_record_calls + 200):
+        loss = solver.adversarial_training(data=data, model=model, **kw)
+    assert torch.isfinite(loss).all() and torch.isfinite(solver.adv_data).all()
+    st = solver.graph_stats
+    assert st["replays"] >= 195 and st["violations"] == 0 and st["captures"] == 1, st
