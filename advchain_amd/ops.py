@@ -1145,6 +1145,7 @@ class _DemonsField(torch.autograd.Function):
         n = int(n_base)
         plan = _PLAN
         frozen = plan is not None and plan.is_frozen
+        norm_rb = None
         if nsteps_rule:  # 3D: whole-batch Frobenius norm of u / 2^n must not exceed 0.5 (adv_morph.py:159-162)
             slots = torch.zeros(64, device=vel.device, dtype=torch.float32)
             # pair: the batch is [v; -v] -- the rule is the reference's, over ONE field's batch (both halves agree)
@@ -1157,11 +1158,38 @@ class _DemonsField(torch.autograd.Function):
                 n = site["n"]
                 plan.check(ss.sqrt(), site)
             else:
-                norm = float(ss.sqrt().item())
-                while norm / (2.0 ** n) > 0.5:
-                    n += 1
-                if plan is not None:
-                    plan.note("nsteps", n=n, n_base=int(n_base))
+                # no `.item()` (round 5): the norm travels to the host behind an event of its own while the chain is
+                # enqueued with the count the previous field of this shape needed; the count is verified below, once the
+                # chain is queued -- the wait is for a kernel at the HEAD of the queue, so it drains nothing -- and only a
+                # count that changed (the first call of a shape, an ascent that crosses a power of two) enqueues the chain
+                # a second time.  The results are those of the reference's rule either way.
+                nkey = (str(s1.device), tuple(s1.shape), int(n_base), HINT_SLOT)
+                norm_rb = _Readback(ss.sqrt())
+                n = max(n, _NSTEPS_HINT.get(nkey, n))
+        mark = None if plan is None else len(plan.pending)
+        while True:
+            out = _DemonsField._enqueue_chain(ctx, vel, s1, tables, d, n, scale, w9, pos_only, composite, plan, frozen, pair)
+            if norm_rb is None:
+                break
+            norm, want = float(norm_rb.values()[0]), int(n_base)
+            while norm / (2.0 ** want) > 0.5:
+                want += 1
+            norm_rb = None
+            _NSTEPS_HINT[nkey] = want
+            NSTEPS_STATS["chains"] += 1
+            if plan is not None:         # (a frozen plan meets the count first, then the chain: keep that order in the record)
+                if want != n:
+                    del plan.pending[mark:]
+                plan.pending.insert(mark, ("nsteps", dict(n=want, n_base=int(n_base))))
+            if want == n:
+                break
+            NSTEPS_STATS["respeculated"] += 1
+            n = want
+        return out
+
+    @staticmethod
+    def _enqueue_chain(ctx, vel, s1, tables, d, n, scale, w9, pos_only, composite, plan, frozen, pair):
+        N = s1.shape[0]
         inv = 1.0 / (2.0 ** n)
         # row m of `disp`: max-slots for the displacement of phis[m], written by the kernel that produces it; row n: the
         # sampling positions `pos`, which bound the returned grid (clipping to [-1,1] and the normalised Gaussian only
@@ -1333,6 +1361,8 @@ class _HintCache(dict):
         dict.__setitem__(self, key, value)
 
 
+_NSTEPS_HINT = _HintCache()    # (device, smoothed velocity shape, n_base) -> the step count the 3D rule gave the last field of that shape
+NSTEPS_STATS = {"chains": 0, "respeculated": 0}      # 3D chains enqueued with a guessed count / enqueued again with the right one
 _PENDING_BOUNDS = _HintCache()  # chain key -> the read-back of the last forward of that key, until somebody looks at it
 
 

@@ -993,6 +993,42 @@ def test_demons_field_golden():
             assert err < (3e-3 if big else 1e-4), (key, sgn, err)
 
 
+def test_3d_step_count_is_guessed_then_verified_without_a_blocking_read():
+    """adv_morph.py:159-162: the 3D step count follows the whole-batch norm.  The chain is enqueued with the count of the
+    previous field of that shape while the norm travels to the host behind its own event; a count that proves wrong enqueues
+    the chain again.  Either way the field and its gradient are those of the rule (bit for bit the same launches)."""
+    ops = _ops()
+    fx = Fixture("g3_morph")
+    from advchain_amd.augmentor import AdvMorph
+    key = "3d_bigeps_"
+    m = fx.json()[key]
+    t = AdvMorph(spatial_dims=3, config_dict=m["config"], device=torch.device(DEV))
+    t.init_parameters()
+    gq = rand(tuple(fx.t(key + "dxy_fwd").shape), 92).to(DEV)
+
+    def run(eps):
+        pg = fx.t(key + "param", DEV).requires_grad_(True)
+        q = ops.demons_field(pg, eps, t._tables, True)
+        q.backward(gq)
+        return q.detach().clone(), pg.grad.clone()
+    ops._NSTEPS_HINT.clear()
+    before = dict(ops.NSTEPS_STATS)
+    first = run(t.epsilon)                         # hint: 8; the rule wants more: enqueued twice
+    assert ops.NSTEPS_STATS["respeculated"] == before["respeculated"] + 1
+    second = run(t.epsilon)                        # hint right: once
+    assert ops.NSTEPS_STATS["respeculated"] == before["respeculated"] + 1
+    assert ops.NSTEPS_STATS["chains"] == before["chains"] + 2
+    # (at this displacement the backward is the window scatter, whose float-atomic flush is not reproducible run to run)
+    assert torch.equal(first[0], second[0])
+    assert maxdiff(first[1], second[1]) <= 1e-4 * float(second[1].abs().max())
+    small = run(t.epsilon / 64.0)                  # back to 8 squarings: the stale hint (> 8) is corrected as well
+    assert ops.NSTEPS_STATS["respeculated"] == before["respeculated"] + 2
+    ops._NSTEPS_HINT.clear()
+    again = run(t.epsilon / 64.0)
+    assert ops.NSTEPS_STATS["respeculated"] == before["respeculated"] + 2
+    assert all(torch.equal(a, b) for a, b in zip(small, again))
+
+
 @pytest.mark.parametrize("fixture", ["g10_demons_args", "g10b_gauss_window"])
 def test_demons_compose_arguments_golden(fixture):
     """G10 (g10b: the windows `gaussian_ks` decides -- sigma = 0.3 keeps the 5 taps of gaussian_ks, gaussian_ks = 11 / 7
