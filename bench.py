@@ -176,7 +176,7 @@ def build_solver(wl, device, process_group=None):
              for nm, cfg in transform_configs(wl["dims"], wl["batch"], wl["chain"], morph_div8=wl.get("anatomy", False))]
     return ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
                                              divergence_weights=[1.0, 0.5], process_group=process_group,
-                                             hip_graph=HIP_GRAPH and process_group is None and len(wl["dims"]) == 2)
+                                             hip_graph=HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
 
 
 def solver_kwargs(wl, device):
@@ -668,6 +668,10 @@ PROFILING_RUN = False                   # --only-workload
 # 1 % of their step, and the replay's safety margin moves the 3.2-voxel warps of cfg-3 from the exact 4-voxel march scatter
 # onto the window scatter (14.45 against 14.1 ms, profiles/r05/)
 HIP_GRAPH = True
+# sharded runs replay their graphs too (solver._shardable_capture: nothing collective is captured, one all-reduce per call
+# checks the premise) only when asked (--sharded-graph): tested with two gloo ranks on one GPU, never on a multi-GPU box
+# with RCCL next to a capture, so the default for --gpus N > 1 stays launch by launch
+SHARDED_GRAPH = False
 SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
 
 
@@ -693,14 +697,18 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="dispatch every step launch by launch from Python (solver.hip_graph off); default: the ascent loop "
                          "of a step is one hipGraph replay")
+    ap.add_argument("--sharded-graph", action="store_true",
+                    help="--gpus N > 1: replay the 2D ascent loop from a hipGraph on every rank as well (one all-reduce per "
+                         "call checks the premise); default for N > 1: launch by launch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 3D configs timed after the headline workload")
     ap.add_argument("--only-workload", action="store_true",
                     help="profiling runs: the chosen workload and nothing else (no secondary configs, no north-star "
                          "kernel pair, no CPU baseline)")
     args = ap.parse_args()
-    global PROFILING_RUN, HIP_GRAPH
+    global PROFILING_RUN, HIP_GRAPH, SHARDED_GRAPH
     PROFILING_RUN = bool(args.only_workload)
     HIP_GRAPH = not args.no_graph
+    SHARDED_GRAPH = bool(args.sharded_graph)
     stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -748,7 +756,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rec["workload"], "global_batch": rec["global_batch"],
                        "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
-                       "dispatch": "hipGraph replay of the ascent loop (solver.hip_graph)" if (HIP_GRAPH and world == 1 and not stub
+                       "dispatch": "hipGraph replay of the ascent loop (solver.hip_graph)" if (HIP_GRAPH and (world == 1 or SHARDED_GRAPH) and not stub
                                                                                                   and len(wl["dims"]) == 2)
                        else "launch by launch",
                        "segmentation_net": "Conv%dd(1,4,3,1,1) eval (as adv_compose_solver.py:593)" % len(wl["dims"])},

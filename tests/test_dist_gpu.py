@@ -44,3 +44,135 @@ def test_two_rank_sharding_matches_whole_batch_on_gpu(sd, if_norm):
         mp.spawn(_worker, args=(2, initfile, sd, if_norm, tmp), nprocs=2, join=True)
         parts = [torch.load(os.path.join(tmp, "rank%d.pt" % r)) for r in range(2)]
     check_parts(parts, ref, 2e-5, 5e-5, 1e-4)
+
+
+def _graph_calls(solver, chain, params, data, model, calls, device):
+    """`calls` identical calls (the same injected parameters every time): the first ones record the launch plan, then one
+    captures, the rest replay.  Returns the result of the last one."""
+    import contextlib
+    import io
+    for _ in range(calls):
+        for t, p in zip(chain, params):
+            t.init_parameters()
+            t.set_parameters(p.to(device))
+        solver.chain_of_transforms = list(chain)
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = solver.adversarial_training(data=data, model=model, n_iter=2, lazy_load=True)
+    return [float(loss), [t.param.detach().cpu().clone() for t in solver.chain_of_transforms[:len(chain)]],
+            solver.adv_data.detach().cpu().clone()]
+
+
+def _graph_solver(data_n, group, device, hip_graph):
+    from advchain_amd.augmentor import AdvAffine, AdvBias, AdvMorph, AdvNoise, ComposeAdversarialTransformSolver
+    from tests.test_dist_gloo import _specs
+    cls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
+    chain = [cls[nm](spatial_dims=2, config_dict=cfg, device=device) for nm, cfg in _specs(2, data_n)]
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, process_group=group, hip_graph=hip_graph)
+    return solver, chain
+
+
+def _graph_worker(rank, world, initfile, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    from tests.helpers import make_model
+    device = torch.device("cuda", 0)
+    data, params = _inputs(2)
+    per = data.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    n_coll = [0]
+    orig = dist.all_reduce
+
+    def counted(*a, **k):
+        n_coll[0] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counted
+    solver, chain = _graph_solver(per, dist.group.WORLD, device, True)
+    model = make_model(2).to(device)
+    local = [p[sl].contiguous() for p in params]
+    res = _graph_calls(solver, chain, local, data[sl].contiguous().to(device), model, 5, device)
+    before = n_coll[0]
+    res = _graph_calls(solver, chain, local, data[sl].contiguous().to(device), model, 1, device)
+    torch.save(dict(loss=res[0], params=res[1], adv=res[2], stats=dict(solver.graph_stats), collectives=n_coll[0] - before,
+                    last_inner=float(solver.last_inner_dist)), os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_replaying_their_graphs_match_the_whole_batch():
+    """hip_graph under a process group (2D): nothing collective is captured -- the local loss gates the updates inside the
+    replay and ONE all-reduce per call (violation flag + per-step losses) checks afterwards that the whole-batch gate would
+    have decided the same.  Two ranks on cuda:0, each replaying its own graph, against the single-process whole-batch run
+    dispatched the ordinary way."""
+    from tests.helpers import make_model
+    device = torch.device("cuda", 0)
+    data, params = _inputs(2)
+    solver, chain = _graph_solver(data.shape[0], None, device, False)
+    ref = _graph_calls(solver, chain, params, data.to(device), make_model(2).to(device), 1, device)
+    ref_inner = float(solver.last_inner_dist)
+    with tempfile.TemporaryDirectory() as tmp:
+        initfile = os.path.join(tmp, "init")
+        mp.spawn(_graph_worker, args=(2, initfile, tmp), nprocs=2, join=True)
+        parts = [torch.load(os.path.join(tmp, "rank%d.pt" % r)) for r in range(2)]
+    for p in parts:
+        st = p["stats"]
+        assert st["captures"] == 1 and st["replays"] >= 2 and st["violations"] == 0 and st["refused"] == 0, st
+        # per replayed call: the global batch size, the check vector, the final pass's loss -- not one per ascent step
+        assert p["collectives"] == 3, p["collectives"]
+        assert abs(p["last_inner"] - ref_inner) < 1e-7 + 2e-5 * abs(ref_inner)      # the whole-batch value of the last step
+    check_parts(parts, ref, 2e-5, 5e-5, 1e-4)
+
+
+def _violation_worker(rank, world, initfile, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    from tests.helpers import make_model
+    device = torch.device("cuda", 0)
+    data, params = _inputs(2)
+    per = data.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    solver, chain = _graph_solver(per, dist.group.WORLD, device, True)
+    model = make_model(2).to(device)
+    local, mine = [p[sl].contiguous() for p in params], data[sl].contiguous().to(device)
+    _graph_calls(solver, chain, local, mine, model, 5, device)
+    (rec,) = solver._graphs.values()
+    assert rec["state"] == "replay" and solver.graph_stats["violations"] == 0
+    if rank == 0:                                # ONE rank leaves its intervals ...
+        for site in rec["plan"].frozen:
+            site["hi"].fill_(1e-9)
+    res = _graph_calls(solver, chain, local, mine, model, 1, device)
+    after_one = dict(solver.graph_stats)
+    states = [rec["state"]]
+    for _ in range(8):                           # ... again and again: both capture again, in the same call
+        _graph_calls(solver, chain, local, mine, model, 1, device)
+        states.append(rec["state"])
+        if rec["state"] != "replay":
+            break
+    _graph_calls(solver, chain, local, mine, model, 2, device)
+    torch.save(dict(loss=res[0], params=res[1], adv=res[2], after_one=after_one, states=states, final=dict(solver.graph_stats),
+                    final_state=rec["state"]), os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_violation_on_one_rank_sends_every_rank_down_the_ordinary_path():
+    """The decision after a replay is taken from all-reduced numbers: a rank whose own replay was fine re-runs the call with
+    the rank whose replay was not (their per-step collectives pair up), and both capture again in the same call."""
+    from tests.helpers import make_model
+    device = torch.device("cuda", 0)
+    data, params = _inputs(2)
+    solver, chain = _graph_solver(data.shape[0], None, device, False)
+    ref = _graph_calls(solver, chain, params, data.to(device), make_model(2).to(device), 1, device)
+    with tempfile.TemporaryDirectory() as tmp:
+        initfile = os.path.join(tmp, "init")
+        mp.spawn(_violation_worker, args=(2, initfile, tmp), nprocs=2, join=True)
+        parts = [torch.load(os.path.join(tmp, "rank%d.pt" % r)) for r in range(2)]
+    for p in parts:
+        assert p["after_one"]["violations"] == 1, p["after_one"]
+        assert p["states"] == parts[0]["states"] and p["states"][-1] == "capture", p["states"]
+        assert p["final"]["captures"] == 2 and p["final_state"] == "replay", p["final"]
+    assert parts[0]["final"] == parts[1]["final"]
+    check_parts(parts, ref, 2e-5, 5e-5, 1e-4)
