@@ -37,5 +37,7 @@ if __name__ == "__main__":
         ops.COMPOSITE = False
     if os.environ.get("AB_NO_FUSE"):
         ops.FUSE_2D = False
+    margins = [float(m) for m in os.environ.get("AB_MARGINS", "1.3").split(",")]
     for i in range(runs):
-        run("flat 1.3, 3 records", 1.3, 3, steps=200, workload=w)
+        for m in margins:
+            run("flat %.2f, 3 records" % m, m, 3, steps=200, workload=w)
