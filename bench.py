@@ -345,6 +345,10 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     if busy is not None:
         extras["gpu_busy_ms_per_step"], extras["launches_per_step"], extras["gpu_busy_source"] = busy
         extras["host_gap_ms_per_step"] = round(elapsed / steps * 1e3 - busy[0], 3)
+        if extras["host_gap_ms_per_step"] < 0:
+            extras["host_gap_note"] = ("negative: the committed trace's kernels run ~1-2 % longer under rocprofv3 than untraced, and its "
+                                       "per-call mean includes the recorded (launch-by-launch) calls; this run's own figure is "
+                                       "ms_per_step - gpu_span_ms_per_step")
     extras["abi_calls_per_step"] = abi_calls
     if graphed:
         st = solver.graph_stats
