@@ -300,8 +300,7 @@ class ComposeAdversarialTransformSolver(object):
             rec["data"].copy_(data)
         if given is not None and given.data_ptr() != rec["init_output"].data_ptr():
             rec["init_output"].copy_(given)
-        for sp, p in zip(rec["params"], init_params):
-            sp.copy_(p)
+        torch._foreach_copy_(rec["params"], init_params)      # (one launch for the chain's parameters, not one each)
         model.zero_grad()
         rec["graph"].replay()
         sharded = self.process_group is not None
@@ -312,9 +311,11 @@ class ComposeAdversarialTransformSolver(object):
             rec["flag_host"].copy_(rec["plan"].flag, non_blocking=True)
         rec["event"].record(ops._stream_obj())
         self.graph_stats["replays"] += 1
-        for t, state, op in zip(rec["transforms"], rec["attrs"], rec["out_params"]):
+        outs = [torch.empty_like(op) for op in rec["out_params"]]
+        torch._foreach_copy_(outs, rec["out_params"])
+        for t, state, o in zip(rec["transforms"], rec["attrs"], outs):
             t.__dict__.update(state)
-            t.param = op.clone()
+            t.param = o
         self.chain_of_transforms = list(rec["transforms"])
         self.last_inner_dist = check[-1].reshape(rec["out_last_inner"].shape) if sharded else rec["out_last_inner"].clone()
         io = given if given is not None else rec["out_init_output"].clone()

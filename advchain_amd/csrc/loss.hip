@@ -1572,18 +1572,14 @@ int advchain_consistency_fused_fwd(const float* pred, const float* ref, const fl
   ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fused_fwd: bad dims");
   ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536 && K >= 1 && K <= kMaxK, "consistency_fused_fwd: bad N/K (K <= 16)");
   static const bool off = getenv("ADVCHAIN_NO_FUSED_LOSS") != nullptr;   // A/B knob
-  // 3D: measured SLOWER than the three-kernel form (same box, K = 4: 4 x 4 x 128 x 128 x 64 230 against 199 us, 8 x 4 x
-  // 160 x 160 x 80 978 against 835 us) -- the z fold of the marching stencil reads three planes per row, so every voxel's
-  // softmax is evaluated 3 x (mlen + 2) / mlen times and the row step issues 24 instead of 9 loads; it wins in 2D (124
-  // against 141 us at 32 x 4 x 256 x 256), where a row is folded once.  3D therefore stays on the unfused entries unless
-  // ADVCHAIN_FUSED_LOSS_3D is set (A/B); what 3D needs is a plane exchange through LDS, not this kernel.
-  // Round 5: what 3D needed -- the plane exchange through LDS -- is k_loss_fused_fwd3d_z (z-marching; edges wanted, rows of at
-  // most 128 voxels); ADVCHAIN_NO_FUSED_LOSS_3DZ switches it off (A/B).
-  static const bool on3d = getenv("ADVCHAIN_FUSED_LOSS_3D") != nullptr;
+  // 3D: the y-marching kernel below was measured SLOWER than the three-kernel form (K = 4: 4 x 4 x 128 x 128 x 64 230 against
+  // 199 us -- its z fold reads three planes per row) and is instantiated for 2D only since round 5; 3D takes
+  // k_loss_fused_fwd3d_z (z-marching with the y neighbours through LDS; edges wanted, rows of at most 128 voxels;
+  // ADVCHAIN_NO_FUSED_LOSS_3DZ switches it off for A/B) or the unfused entries.
   const Dims d = lmake_dims(ndim, dims);
   const bool edges = want_edges && K > 1;
   const bool zmarch = ndim == 3 && z3_takes(d, edges);
-  if (off || (ndim == 3 && !on3d && !zmarch) || K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (off || (ndim == 3 && !zmarch) || K < 2 || K > 4 || (mask && mask_channels != 1)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.voxels() >= (1ll << 31) || !march4_ok(d, pred, ref, mask, R)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (N == 0) return ADVCHAIN_OK;
   if (zmarch) {
@@ -1608,8 +1604,7 @@ int advchain_consistency_fused_fwd(const float* pred, const float* ref, const fl
                    else hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, true, false>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); } \
     else { if (edges) hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, false, true>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); \
            else hipLaunchKernelGGL((k_loss_fused_fwd4<DIM_, K_, false, false>), g4, b4, 0, st, pred, ref, mask, R, sums, d, mlen, ref_is_prob); } } while (0)
-  if (ndim == 3) { switch (K) { case 2: FUSED_FWD(3, 2); break; case 3: FUSED_FWD(3, 3); break; default: FUSED_FWD(3, 4); break; } }
-  else { switch (K) { case 2: FUSED_FWD(2, 2); break; case 3: FUSED_FWD(2, 3); break; default: FUSED_FWD(2, 4); break; } }
+  switch (K) { case 2: FUSED_FWD(2, 2); break; case 3: FUSED_FWD(2, 3); break; default: FUSED_FWD(2, 4); break; }
 #undef FUSED_FWD
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
@@ -1641,14 +1636,14 @@ int advchain_consistency_fused_bwd(const float* pred, const float* ref, const fl
     ADVCHAIN_LAUNCH_CHECK();
     return ADVCHAIN_OK;
   }
+  if (ndim == 3) return ADVCHAIN_ERR_UNSUPPORTED;      // (no forward of such a shape ran fused)
   const int mlen = march4_len(d, N);
   const dim3 g4 = march4_grid(d, N, mlen), b4(kBlock);
   hipStream_t st = (hipStream_t)stream;
 #define FUSED_BWD(DIM_, K_) do { \
     if (kl) hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, true>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); \
     else hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, false>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); } while (0)
-  if (ndim == 3) { switch (K) { case 2: FUSED_BWD(3, 2); break; case 3: FUSED_BWD(3, 3); break; default: FUSED_BWD(3, 4); break; } }
-  else { switch (K) { case 2: FUSED_BWD(2, 2); break; case 3: FUSED_BWD(2, 3); break; default: FUSED_BWD(2, 4); break; } }
+  switch (K) { case 2: FUSED_BWD(2, 2); break; case 3: FUSED_BWD(2, 3); break; default: FUSED_BWD(2, 4); break; }
 #undef FUSED_BWD
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
