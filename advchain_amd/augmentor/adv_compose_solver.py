@@ -374,9 +374,11 @@ class ComposeAdversarialTransformSolver(object):
         try:
             with torch.cuda.graph(graph):
                 plan.flag.zero_()
+                plan.rewind()
                 io = rec["init_output"] if given is not None else self.get_init_output(data=rec["data"], model=model)
                 transforms = self.optimizing_transform(data=rec["data"], model=model, init_output=io, n_iter=n_iter,
                                                        optimize_flags=optimize_flags, step_sizes=step_sizes)
+                plan.finish()
                 if sharded:
                     vals = torch.cat(self._local_steps) if self._local_steps else torch.zeros(1, device=data.device)
                     rec["check"] = torch.cat([plan.flag.reshape(1).float(), (~torch.isfinite(vals)).float().sum().reshape(1), vals.float()])

@@ -232,18 +232,21 @@ def raw_compose_self_bwd(gout, phi, ws=None, chain=False, halo=0):
     return gphi
 
 
-def raw_max_displacement(phi):
-    """max |sampling position - own voxel| of a deformation `phi` (N,d,...) in voxels -> 1-element device tensor."""
-    out = torch.zeros(1, device=phi.device, dtype=torch.float32)
+def raw_max_displacement(phi, out=None):
+    """max |sampling position - own voxel| of a deformation `phi` (N,d,...) in voxels -> 1-element device tensor (`out`: a
+    ZEROED 1-element tensor to accumulate into)."""
+    if out is None:
+        out = torch.zeros(1, device=phi.device, dtype=torch.float32)
     _lib.check(_lib.load().advchain_max_displacement(_ptr(phi), _ptr(out), phi.shape[0], phi.dim() - 2,
                                                      _lib.dims_array(phi.shape[2:]), _stream()), "max_displacement")
     return out
 
 
-def raw_slot_rows_max(slots, reset=False):
+def raw_slot_rows_max(slots, reset=False, out=None):
     """Row maxima of a (rows, slots) displacement accumulator (torch.max(dim=1) semantics incl. NaN); `reset` zeroes the
     accumulator behind the read (a persistent buffer then needs no zero-fill launch per chain)."""
-    out = torch.empty(slots.shape[0], device=slots.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(slots.shape[0], device=slots.device, dtype=torch.float32)
     _lib.check(_lib.load().advchain_slot_rows_max(_ptr(slots), _ptr(out), slots.shape[0], slots.shape[1], int(bool(reset)),
                                                   _stream()), "slot_rows_max")
     return out
@@ -721,6 +724,10 @@ class LaunchPlan(object):
             sdict["lo"] = lo_t[sdict["off"]:sdict["off"] + sdict["len"]]
             sdict["hi"] = hi_t[sdict["off"]:sdict["off"] + sdict["len"]]
         self.flag = torch.zeros(1, device=device, dtype=torch.int32)
+        # what a replay measures, site after site, in ONE buffer (the producers write straight into their site's slice): one
+        # check launch at the end of the replay instead of one per site (finish())
+        self.measured = torch.zeros(max(1, len(los)), device=device, dtype=f32)
+        self._lo_t, self._hi_t, self._deferred = lo_t, hi_t, 0
         self.frozen = sites
         self.recording = False
         self.cursor = 0
@@ -728,7 +735,23 @@ class LaunchPlan(object):
 
     # -- frozen
     def rewind(self):
+        """Before the frozen sites are walked again (a capture; a launch-by-launch run of the frozen selection): the first
+        site again, the measurement slots zeroed (the warp sites accumulate a maximum into theirs)."""
         self.cursor = 0
+        self._deferred = 0
+        self.measured.zero_()
+
+    def slot(self, site):
+        """Where the producer of this site's measurement writes it (a view of `measured`)."""
+        return self.measured[site["off"]:site["off"] + site["len"]]
+
+    def finish(self):
+        """The premise check of everything measured into the slots since rewind(): one launch."""
+        if self._deferred:
+            n = self.measured.numel()
+            _lib.check(_lib.load().advchain_bounds_check(_ptr(self.measured), _ptr(self._lo_t), _ptr(self._hi_t), n,
+                                                         ctypes.c_void_p(self.flag.data_ptr()), _stream()), "bounds_check")
+            self._deferred = 0
 
     def take(self, kind, **expect):
         if self.cursor >= len(self.frozen):
@@ -742,6 +765,9 @@ class LaunchPlan(object):
     def check(self, values, site):
         if values.numel() != site["len"]:
             raise PlanMismatch("launch plan: %d measured values for a site of %d" % (values.numel(), site["len"]))
+        if values.data_ptr() == self.measured.data_ptr() + 4 * site["off"]:      # written into its slot: checked by finish()
+            self._deferred += 1
+            return
         _lib.check(_lib.load().advchain_bounds_check(_ptr(values), _ptr(site["lo"]), _ptr(site["hi"]), site["len"],
                                                      ctypes.c_void_p(self.flag.data_ptr()), _stream()), "bounds_check")
 
@@ -756,7 +782,7 @@ def grid_displacement(grid):
         key = (str(grid.device),) + tuple(grid.shape[2:])
         if plan is not None and plan.is_frozen:        # frozen plan: the recorded bound, and the premise check on the measured one
             site = plan.take("warp", d=grid.dim() - 2)
-            plan.check(raw_max_displacement(grid.detach()), site)
+            plan.check(raw_max_displacement(grid.detach(), out=plan.slot(site)), site)
             hit = [site["bounds"], None, grid._version, 0, None]
         else:
             hit = [_Readback(raw_max_displacement(grid.detach())), None, grid._version, 0, key]
@@ -1156,7 +1182,7 @@ class _DemonsField(torch.autograd.Function):
             if frozen:       # the recorded count; the replay checks on the device that the rule still gives it
                 site = plan.take("nsteps", n_base=n)
                 n = site["n"]
-                plan.check(ss.sqrt(), site)
+                plan.check(torch.sqrt(ss, out=plan.slot(site)), site)
             else:
                 # no `.item()` (round 5): the norm travels to the host behind an event of its own while the chain is
                 # enqueued with the count the previous field of this shape needed; the count is verified below, once the
@@ -1229,7 +1255,8 @@ class _DemonsField(torch.autograd.Function):
             rows_max = rc = None
             if composite:
                 q = torch.empty_like(phi0)
-                rows_max = None if disp is None else torch.empty(disp.shape[0], device=vel.device, dtype=torch.float32)
+                rows_max = None if disp is None else (plan.slot(site) if site is not None else
+                                                      torch.empty(disp.shape[0], device=vel.device, dtype=torch.float32))
                 rc = _lib.load().advchain_demons_compose_pair_fwd(
                     _ptr(vel), _ptr(s1), _ptr(phi0), _ptr(fields), _ptr(pos), _ptr(q), _ptr(disp), _ptr(rows_max), _ptr(tables.itab),
                     _ptr(tables.ftab), _lib.dims_array(tables.S), _lib.dims_array(tables.g), _lib.dims_array(tables.B),
@@ -1246,7 +1273,7 @@ class _DemonsField(torch.autograd.Function):
                                                                None if (disp is None or not FUSE_2D) else _ptr(disp[n + 1]), _stream()),
                            "expo_chain_fwd")
                 q = pos if pos_only else raw_gauss(pos, d, pre=2, post=1, weights=w9)
-                rows_max = None if disp is None else raw_slot_rows_max(disp, reset=True)
+                rows_max = None if disp is None else raw_slot_rows_max(disp, reset=True, out=None if site is None else plan.slot(site))
         except BaseException:
             # (the slots, the fused-chain flag and its barrier counter may hold partial state: the next chain starts from a
             # fresh zero-filled accumulator)

@@ -129,6 +129,7 @@ def test_replay_is_bit_identical_to_the_same_launches_enqueued_the_ordinary_way(
         io = plain.get_init_output(data=data, model=model)
         plain.chain_of_transforms = plain.optimizing_transform(data=data, model=model, init_output=io, n_iter=n_iter,
                                                                optimize_flags=flags, step_sizes=steps)
+        plan.finish()          # (the premise check of everything the sites measured: one launch, as at the end of a replay)
     finally:
         ops._PLAN = None
     assert plan.cursor == len(plan.frozen) and int(plan.flag.item()) == 0
