@@ -263,13 +263,22 @@ def _persistent_zeros(tag, shape, device):
     stream = _raw_stream(_raw_device()) if (_raw_stream and _raw_device) else torch.cuda.current_stream().cuda_stream
     key = (tag, tuple(shape), str(device), stream)
     plan = _PLAN
-    # (a capture keeps its accumulators with its plan: they live in the graph's memory pool and die with it)
-    store = plan.persistent if (plan is not None and plan.is_frozen) else _PERSISTENT
-    buf = store.get(key)
+    if plan is not None and plan.is_frozen:
+        # a capture keeps its accumulators with its plan.  freeze() made the ones the recorded calls asked for (zero-filled
+        # THEN, outside the capture: a torch.zeros met inside a capture is a fill node replayed with every call, for buffers
+        # whose consumers leave them zeroed anyway); one that was not asked for before is made here, inside the capture
+        key = key[:3]
+        buf = plan.persistent.get(key)
+        if buf is None:
+            buf = plan.persistent[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+        return buf
+    if plan is not None and plan.recording:
+        plan.wanted_zeros.add(key[:3])
+    buf = _PERSISTENT.get(key)
     if buf is None:
-        if len(store) > 64:
-            store.clear()
-        buf = store[key] = torch.zeros(shape, device=device, dtype=torch.float32)
+        if len(_PERSISTENT) > 64:
+            _PERSISTENT.clear()
+        buf = _PERSISTENT[key] = torch.zeros(shape, device=device, dtype=torch.float32)
     return buf
 
 
@@ -341,8 +350,13 @@ def cached_ones(shape, device):
             if len(_ONES) > 16:
                 _ONES.clear()
             t = _ONES[key] = torch.ones(shape, device=device, dtype=torch.float32)
-        else:       # (under capture: the fill is a node of the graph and the tensor lives in its pool)
-            t = store[("ones",) + key] = torch.ones(shape, device=device, dtype=torch.float32)
+        else:
+            # read-only: the tensor the recorded calls filled serves the capture as well (the plan keeps it alive); only a
+            # shape nobody asked for before is filled under the capture (a fill node replayed with every call)
+            t = _ONES.get(key)
+            if t is None:
+                t = torch.ones(shape, device=device, dtype=torch.float32)
+            store[("ones",) + key] = t
     return t
 
 
@@ -632,6 +646,7 @@ class LaunchPlan(object):
         self.cursor = 0
         self.flag = None
         self.persistent = {}
+        self.wanted_zeros = set()  # (tag, shape, device) of the persistent accumulators the recorded calls asked for
         self.violated = []       # diagnostics: which frozen bound a violated replay exceeded (filled by the recorded re-run)
 
     @property
@@ -731,7 +746,7 @@ class LaunchPlan(object):
         self.frozen = sites
         self.recording = False
         self.cursor = 0
-        self.persistent = {}
+        self.persistent = {k: torch.zeros(k[1], device=device, dtype=f32) for k in sorted(self.wanted_zeros, key=repr) if k[2] == str(device)}
 
     # -- frozen
     def rewind(self):

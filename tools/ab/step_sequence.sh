@@ -5,9 +5,9 @@ set -u
 wl=${1:-cfg2}; out=${2:-gpurun_out/step_sequence_$wl.txt}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp; cd /tmp
-python $repo/bench.py --workload $wl --steps 2 --warmup 1 --only-workload --no-graph > /dev/null 2>&1
+python $repo/bench.py --workload $wl --steps ${SEQ_STEPS-2} --warmup 1 --only-workload ${SEQ_GRAPH_FLAG---no-graph} > /dev/null 2>&1
 rm -rf /tmp/rp_seq
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_seq -o seq -- python $repo/bench.py --workload $wl --steps 2 --warmup 1 --only-workload --no-graph > /tmp/rp_seq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_seq -o seq -- python $repo/bench.py --workload $wl --steps ${SEQ_STEPS-2} --warmup 1 --only-workload ${SEQ_GRAPH_FLAG---no-graph} > /tmp/rp_seq.log 2>&1
 f=$(find /tmp/rp_seq -name "seq_kernel_trace.csv" | head -1)
 python - "$f" "$repo/$out" <<'PY'
 import csv, sys, re
