@@ -517,11 +517,21 @@ template <int DIM, int INTERP, int PAD, bool NEED_GIN, bool NEED_GTHETA>
 __global__ void __launch_bounds__(kBlock)
 k_affine_warp_bwd(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ theta,
                   float* __restrict__ gin, float* __restrict__ gtheta_partial, int C, Dims d,
-                  const int* __restrict__ mode) {
+                  const int* __restrict__ mode, const float* __restrict__ red_partial, float* __restrict__ red_out, int red_nb) {
   constexpr int NT = DIM * (DIM + 1);
   __shared__ float smem[4 * NT];
   const int64_t V = d.voxels();
   const int n = blockIdx.y;
+  // red_out != null (round 5): this launch also is the second stage of the theta gradient the box kernel left as block
+  // partials -- block k < NT of sample n does what block (n, k) of k_reduce_partials does, the same sums in the same order.
+  // (When the box kernels took every sample this launch has nothing else to do: one launch of ~5 us instead of two.)
+  if (red_out && (int)blockIdx.x < NT) {
+    float s[1] = {0.f};
+    for (int b = threadIdx.x; b < red_nb; b += blockDim.x) s[0] += red_partial[((int64_t)n * red_nb + b) * NT + blockIdx.x];
+    block_sum<1>(s, smem);
+    if (threadIdx.x == 0) red_out[(int64_t)n * NT + blockIdx.x] = s[0];
+    __syncthreads();
+  }
   // mode != null: grad_in of samples with mode[n] == 0 is produced by k_affine_gather_bwd; scatter only the rest
   const bool do_gin = NEED_GIN && (mode == nullptr || mode[n] != 0);
   if (!NEED_GTHETA && !do_gin) return;
@@ -865,10 +875,11 @@ static inline Dims make_dims(int ndim, const int64_t* s) {
 // =============================================================================================
 template <int DIM, int INTERP, int PAD>
 static void launch_affine_bwd(dim3 g, dim3 b, hipStream_t st, const float* gout, const float* in, const float* theta,
-                              float* gin, float* gpart, int C, Dims d, const int* mode) {
-  if (gin && gpart) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
-  else if (gin) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, false>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
-  else hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, false, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode);
+                              float* gin, float* gpart, int C, Dims d, const int* mode, const float* red_partial = nullptr,
+                              float* red_out = nullptr, int red_nb = 0) {
+  if (gin && gpart) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode, nullptr, nullptr, 0);
+  else if (gin) hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, true, false>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode, red_partial, red_out, red_nb);
+  else hipLaunchKernelGGL((k_affine_warp_bwd<DIM, INTERP, PAD, false, true>), g, b, 0, st, gout, in, theta, gin, gpart, C, d, mode, nullptr, nullptr, 0);
 }
 
 extern "C" {
@@ -1348,18 +1359,24 @@ int advchain_affine_warp_bwd(const float* grad_out, const float* in, const float
     const int nbx = nbx_theta >= 0 ? nbx_theta : advchain_affine_box_gtheta_launch(grad_out, in, theta, gpart, N, C, ndim, d, nb, st, nullptr);
     if (nbx > 0) { nb_theta = nbx; gpart = nullptr; }
   }
+  // the launch below scatters grad_in for the samples the gather form flagged (none, as a rule).  When the theta gradient is
+  // waiting as block partials of the box kernel, it reduces them on the way: no k_reduce_partials launch behind it
+  const int Kt = ndim * (ndim + 1);
+  const bool fold_reduce = grad_theta && !gpart && grad_in && interp == INTERP_LINEAR && nb >= Kt;
   if (gpart || grad_in)
   DISPATCH_PAD(padding, {
     if (ndim == 3) {
-      if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode);
+      if (interp == INTERP_LINEAR) launch_affine_bwd<3, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode,
+                                                                            fold_reduce ? workspace : nullptr, fold_reduce ? grad_theta : nullptr, nb_theta);
       else launch_affine_bwd<3, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d, mode);
     } else {
-      if (interp == INTERP_LINEAR) launch_affine_bwd<2, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode);
+      if (interp == INTERP_LINEAR) launch_affine_bwd<2, INTERP_LINEAR, PAD>(g, b, st, grad_out, in, theta, grad_in, gpart, (int)C, d, mode,
+                                                                            fold_reduce ? workspace : nullptr, fold_reduce ? grad_theta : nullptr, nb_theta);
       else launch_affine_bwd<2, INTERP_NEAREST, PAD>(g, b, st, grad_out, in, theta, grad_in, nullptr, (int)C, d, mode);
     }
   });
   ADVCHAIN_LAUNCH_CHECK();
-  if (grad_theta) {
+  if (grad_theta && !fold_reduce) {
     if (interp == INTERP_NEAREST) {
       advchain_zero_async(grad_theta, sizeof(float) * N * ndim * (ndim + 1), st);
     } else {
