@@ -9,7 +9,7 @@ from advchain_amd import ops
 
 def run(tag, margin, records, steps=300, workload="cfg2"):
     wl = bench.WORKLOADS[workload]; dev = torch.device("cuda")
-    torch.manual_seed(1234)
+    torch.manual_seed(int(os.environ.get("AB_SEED", "1234")))
     data = torch.rand(wl["batch"], 1, *wl["dims"], device=dev); model = bench.make_model(len(wl["dims"])).to(dev); kw = bench.solver_kwargs(wl, dev)
     init = ops.LaunchPlan.__init__
     ops.LaunchPlan.__init__ = lambda self, m=margin: init(self, m)
@@ -40,4 +40,4 @@ if __name__ == "__main__":
     margins = [float(m) for m in os.environ.get("AB_MARGINS", "1.3").split(",")]
     for i in range(runs):
         for m in margins:
-            run("flat %.2f, 3 records" % m, m, 3, steps=200, workload=w)
+            run("flat %.2f, 3 records" % m, m, 3, steps=int(os.environ.get("AB_STEPS", "200")), workload=w)
