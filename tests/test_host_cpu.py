@@ -292,7 +292,8 @@ def test_displacement_hint_bits_and_halo_policies():
     assert ops._hint_bits(1e9) == 255 << 8
     assert [ops.squaring_halo(x, 3) for x in (0.5, 0.9995, 1.5, 2.5, 3.5, 3.9995, 7.0)] == [-1, -2, -2, -3, -4, 8, 8]
     # (2D squarings: the whole-row scatter up to an exact 32 px; image warps stop at 16)
-    assert [ops.squaring_halo(x, 2) for x in (0.5, 1.5, 3.0, 7.9, 15.0, 15.9995, 31.0, 31.9995, 40.0)] == [-1, -2, -4, -8, -16, -32, -32, 16, 16]
+    assert [ops.squaring_halo(x, 2) for x in (0.5, 1.5, 2.5, 3.0, 5.0, 7.9, 11.0, 15.0, 15.9995, 23.0, 31.0, 31.9995, 40.0)] == \
+        [-1, -2, -3, -4, -6, -8, -12, -16, -24, -24, -32, 16, 16]
     assert [ops.warp_halo([None, x, 0, 0], 2) for x in (15.0, 15.9995, 31.0)] == [-16, 16, 16]
     assert ops.squaring_halo(float("nan"), 3) == 0
     assert ops.warp_halo([None, 0.4, 0, 0], 3) == -1 and ops.warp_halo([None, 5.0, 0, 0], 3) == 8
