@@ -316,6 +316,8 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
             return orig_all_reduce(*a, **k)
         dist.all_reduce = counted_all_reduce
     stats0 = dict(solver.graph_stats)
+    from advchain_amd import ops as _ops_mod
+    nsteps0 = dict(_ops_mod.NSTEPS_STATS)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one event per step boundary (GPU-side span of a step)
     sync()
     t0 = time.perf_counter()
@@ -330,6 +332,10 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     elapsed = time.perf_counter() - t0
     gc.enable()
     extras = {}
+    if sd == 3:
+        # 3D chains are enqueued with a guessed squaring count (ops._DemonsField: no host read in front of them); a guess
+        # that proves wrong enqueues the chain a second time -- how often that happened in the timed region
+        extras["step_count_guesses"] = {k: _ops_mod.NSTEPS_STATS[k] - nsteps0[k] for k in ("chains", "respeculated")}
     # GPU-side span of the timed steps: first to last boundary event on the launch stream.  Host-bound steps show up as
     # ms_per_step well above it only at the ends of the region; INSIDE it the two agree by construction, so the honest
     # host-boundness figure is the comparison with the ordinary path below (`ordinary_ms_per_step`) and with rocprof's
