@@ -16,6 +16,8 @@ _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 PROTOTYPES = {
     "advchain_version": (_I, []),
     "advchain_last_error": (c_char_p, []),
+    "advchain_set_deterministic": (None, [_I]),
+    "advchain_get_deterministic": (_I, []),
     "advchain_grid_sample_fwd": (_I, [_P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _P]),
     "advchain_grid_sample_fwd_ride": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P, _I, _I, _I, _I, _P]),
     "advchain_scatter_workspace": (_L, [_L, _I, _P]),

@@ -39,7 +39,8 @@ class ComposeAdversarialTransformSolver(object):
 
     def __init__(self, chain_of_transforms=[], divergence_types=['mse', 'contour'],
                  divergence_weights=[1.0, 0.5], use_gpu=True, debug=False, if_norm_image=False,
-                 min_intensity=None, max_intensity=None, is_gt=False, process_group=None, hip_graph=False):
+                 min_intensity=None, max_intensity=None, is_gt=False, process_group=None, hip_graph=False,
+                 deterministic=None):
         self.chain_of_transforms = chain_of_transforms
         self.use_gpu = use_gpu
         self.debug = debug
@@ -57,6 +58,9 @@ class ComposeAdversarialTransformSolver(object):
         # hipGraph once its launch sequence has been recorded (see _graphed_ascent); off by default -- the user's model
         # is captured with it, which needs a model without host-side control flow or side effects
         self.hip_graph = hip_graph
+        # extension (round 6): bit-reproducible results run to run.  None: follow torch.are_deterministic_algorithms_enabled()
+        # (what a user of the reference would have set); True / False: this solver's own choice.  See ops.set_deterministic
+        self.deterministic = deterministic
         self.hip_graph_record_calls = 3        # ordinary calls recorded before the capture
         self._graphs = {}
         self.graph_stats = {"recorded": 0, "captures": 0, "replays": 0, "violations": 0, "refused": 0}
@@ -97,6 +101,17 @@ class ComposeAdversarialTransformSolver(object):
         total = self._all_reduce_(local.detach().clone())
         return local + (total - local.detach())
 
+    def _apply_deterministic(self, data):
+        """The library's process-wide switch follows this solver for the duration of its call (ops.set_deterministic)."""
+        if isinstance(data, torch.Tensor) and data.is_cuda:
+            want = self.deterministic
+            if want is None:
+                want = torch.are_deterministic_algorithms_enabled()
+            want = bool(want)
+            if ops.is_deterministic() != want:
+                ops.set_deterministic(want)
+            self._deterministic_now = want      # (a plain attribute: part of the hipGraph key, a capture bakes the choice in)
+
     # ------------------------------------------------------------------------------- public API
     def adversarial_training(self, data, model, optimize_flags=None, init_output=None, lazy_load=False,
                              power_iteration=False, n_iter=1, step_sizes=None, anatomy_mask_images=None,
@@ -135,6 +150,7 @@ class ComposeAdversarialTransformSolver(object):
         else:
             raise ValueError('please use scalar or a  list of scalar to set step size')
         self._resolve_global_batch(data.size(0), data.device)
+        self._apply_deterministic(data)
         pending = None
         if self.hip_graph and n_iter >= 1 and self._graphable(data, model, init_output, anatomy_mask_images):
             # the ascent loop as one hipGraph replay (or one of the ordinary calls that record its launch plan)
@@ -151,6 +167,13 @@ class ComposeAdversarialTransformSolver(object):
                     data=data, model=model, init_output=init_output, n_iter=n_iter, optimize_flags=optimize_flags,
                     step_sizes=step_sizes, anatomy_mask_images=anatomy_mask_images,
                     anatomy_reg_weight=anatomy_reg_weight, volume_preserve_tolerance=volume_preserve_tolerance)
+        if pending is not None and self._final_pass_has_side_effects(model):
+            # a model in train() mode leaves something behind in its forward (BatchNorm running statistics, the dropout RNG):
+            # the final pass must not run on transforms a violated replay would then discard -- the verdict of the replay
+            # first (one event wait: the host's overlap with the graph is given up for such models), the pass once
+            if not pending():
+                init_output = self._redo_ascent()
+            pending = None
         dist, adv_data, adv_output, warped_back_adv_output = self.calc_adv_consistency_loss(
             data.detach(), model, init_output=init_output, chain_of_transforms=self.chain_of_transforms)
         if pending is not None and not pending():
@@ -170,6 +193,12 @@ class ComposeAdversarialTransformSolver(object):
         return dist
 
     # ------------------------------------------------------------------------------- hipGraph replay of the ascent loop
+    @staticmethod
+    def _final_pass_has_side_effects(model):
+        """Does a forward of `model` change anything but its output?  Anything in train() mode may (BatchNorm statistics,
+        num_batches_tracked, dropout RNG state); an eval()-mode module is taken to be a pure function of its input."""
+        return isinstance(model, torch.nn.Module) and any(m.training for m in model.modules())
+
     def _graphable(self, data, model, init_output, anatomy_mask_images):
         """What a capture cannot hold: host-side decisions inside the loop (the anatomy ladder, debug prints, the host NaN
         check, third-party transforms), collectives (not captured: sharded runs stay on the ordinary path) and CPU data."""

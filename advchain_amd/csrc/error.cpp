@@ -1,5 +1,7 @@
-// Error reporting + version for the advchain C ABI.
+// Error reporting + version + the process-wide deterministic switch of the advchain C ABI.
 #include <string.h>
+
+#include <atomic>
 
 static thread_local char g_last_error[512] = "";
 
@@ -10,4 +12,9 @@ extern "C" void advchain_set_error_(const char* msg) {
 
 extern "C" const char* advchain_last_error(void) { return g_last_error; }
 
-extern "C" int advchain_version(void) { return 120; }  // 0.1.2: kl term; slot_rows_max reset; gauss_small_pair, sign_axpy, nonzero_mask, consistency_finish
+// Deterministic mode (include/advchain_hip.h): read by the scatter launchers and by advchain_scatter_workspace.
+static std::atomic<int> g_deterministic{0};
+extern "C" void advchain_set_deterministic(int on) { g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); }
+extern "C" int advchain_get_deterministic(void) { return g_deterministic.load(std::memory_order_relaxed); }
+
+extern "C" int advchain_version(void) { return 130; }  // 0.1.3: deterministic mode; 0.1.2: kl term; slot_rows_max reset; gauss_small_pair, sign_axpy, nonzero_mask, consistency_finish

@@ -756,7 +756,7 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
 // scatter_window.hip
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                   int halo, int32_t* workspace, hipStream_t st);
+                                   int halo, int32_t* workspace, hipStream_t st, int32_t* det_ws);
 int advchain_scatter_rows2d_launch(bool self, const float* gout, const float* in, const float* grid, float* gin, float* ggrid,
                                    int64_t N, int64_t C, Dims d, int padding, int clamp_grid, int H, int32_t* workspace,
                                    hipStream_t st, int rm_flags = 0);
@@ -962,7 +962,7 @@ int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float
       if (rm != ADVCHAIN_ERR_UNSUPPORTED) return rm;
     }
     const int rw = advchain_scatter_window_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
-                                                  clamp_grid, halo, nullptr, (hipStream_t)stream);   // source-tiled window
+                                                  clamp_grid, halo, nullptr, (hipStream_t)stream, workspace);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(false, grad_out, in, grid, grad_in, grad_grid, N, C, ndim, id, padding,
                                          clamp_grid, workspace, 0, halo < 0 ? -halo : halo, (hipStream_t)stream);
@@ -1046,7 +1046,7 @@ static int compose_self_bwd_impl(const float* grad_out, const float* phi, float*
       if (rm != ADVCHAIN_ERR_UNSUPPORTED) return rm;
     }
     const int rw = advchain_scatter_window_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER,
-                                                  0, halo, workspace, (hipStream_t)stream);   // source-tiled window
+                                                  0, halo, workspace, (hipStream_t)stream, workspace);   // source-tiled window
     if (rw != ADVCHAIN_ERR_UNSUPPORTED) return rw;
     return advchain_scatter_tiled_launch(true, grad_out, phi, phi, grad_phi, nullptr, N, ndim, ndim, d, PAD_BORDER, 0,
                                          workspace, chain, halo < 0 ? -halo : halo, (hipStream_t)stream);

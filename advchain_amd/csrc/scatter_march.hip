@@ -833,13 +833,41 @@ k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__
     fetch_rows(za - H, rowB);
     fetch_rows(za - H + 1, rowA);
     fetch_in(za + 1, inA);
-    // ... and while they travel: the fixed-point scale from the row maxima of the rows this workgroup visits, zeroed rings
+    // ... and while they travel: the fixed-point scale from the maximum |grad_out| over the rows this workgroup visits, zeroed
+    // rings.  ws == nullptr (round 6): no row-maxima pre-pass was launched -- the workgroup reads its own (TY + 2H) x (zc + 2H)
+    // rows of grad_out itself, 16 bytes per lane, four requests in flight per thread (a plane's visited rows are one
+    // contiguous run; 2.25x the tensor over all workgroups, out of L2): the separate k_march_rowmax64 launch was 5.1 us of
+    // the north-star backward's 67.6
     {
-      const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s0 * d.s1;
       const int ya = max(y0 - H, 0), yn = min(y0 + TY + H, d.s1) - ya;
       const int zlo = max(za - H, 0), zn = min(zb + H, d.s0) - zlo;
       float m = 0.f;
-      for (int i = tid; i < yn * zn; i += NT) m = fmaxf(m, rowmax[(zlo + i / yn) * d.s1 + ya + i % yn]);
+      if (ws) {
+        const float* rowmax = reinterpret_cast<const float*>(ws + 4) + (int64_t)n * d.s0 * d.s1;
+        for (int i = tid; i < yn * zn; i += NT) m = fmaxf(m, rowmax[(zlo + i / yn) * d.s1 + ya + i % yn]);
+      } else {
+        const int per_plane = (yn * d.s2) >> 2, total = per_plane * zn;     // float4 items (S2 % 4 == 0)
+        const int pstride = d.s1 * d.s2;
+        const float* base = gon + (unsigned)(zlo * pstride + ya * d.s2);
+        bool bad = false;
+        for (int i0 = tid; i0 < total; i0 += 4 * NT) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * NT, total - 1);
+            const int pl = i / per_plane, r4 = i - pl * per_plane;
+            v[u] = *reinterpret_cast<const float4*>(base + (unsigned)(pl * pstride + 4 * r4));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float q = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+            m = fmaxf(m, q);
+            bad = bad || !(fabsf(v[u].x) <= 3.0e38f) || !(fabsf(v[u].y) <= 3.0e38f) || !(fabsf(v[u].z) <= 3.0e38f) ||
+                  !(fabsf(v[u].w) <= 3.0e38f);
+          }
+        }
+        if (bad) m = __int_as_float(0x7f800000);      // a non-finite gradient must surface (lesson 36): scale 0, factor inf
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
       if (lane == 0) wmax[wave] = m;
@@ -1360,13 +1388,16 @@ int advchain_scatter_march_launch(bool self, const float* gout, const float* in,
     const int n0w = (int)((d.s0 + zcw - 1) / zcw);
     const int rows = (int)(d.s0 * d.s1);
     dim3 rg((unsigned)((rows + kBlock / 16 - 1) / (kBlock / 16)), (unsigned)N);
-    launch_rowmax<1>(gout, reinterpret_cast<float*>(workspace + 4), d, rows, N, 1, st);
+    // round 6: the workgroups take the maximum over their own rows themselves (ADVCHAIN_WIDE_ROWMAX_PASS: the pre-pass, A/B)
+    static const bool rowmax_pass = getenv("ADVCHAIN_WIDE_ROWMAX_PASS") != nullptr;
+    if (rowmax_pass) launch_rowmax<1>(gout, reinterpret_cast<float*>(workspace + 4), d, rows, N, 1, st);
+    int32_t* const ws_arg = rowmax_pass ? workspace : nullptr;
     dim3 gw((unsigned)(n1w * n0w * N));
 #define GOW(PAD_, GG_, H_) do { \
       auto kern = k_scatter_march3d_wide<PAD_, GG_, H_>; \
       static bool attr_set = false; \
       if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideCfg<H_>::lds(GG_)); attr_set = true; } \
-      hipLaunchKernelGGL(kern, gw, dim3(WideCfg<H_>::NT), WideCfg<H_>::lds(GG_), st, gout, in, grid, gin, ggrid, d, n1w, zcw, clamp_grid, workspace); } while (0)
+      hipLaunchKernelGGL(kern, gw, dim3(WideCfg<H_>::NT), WideCfg<H_>::lds(GG_), st, gout, in, grid, gin, ggrid, d, n1w, zcw, clamp_grid, ws_arg); } while (0)
 #define GOW_H(PAD_, GG_) do { if (H == 2) GOW(PAD_, GG_, 2); else if (H == 3) GOW(PAD_, GG_, 3); else GOW(PAD_, GG_, 4); } while (0)
     if (padding == PAD_BORDER) { if (ggw) GOW_H(PAD_BORDER, true); else GOW_H(PAD_BORDER, false); }
     else { if (ggw) GOW_H(PAD_ZEROS, true); else GOW_H(PAD_ZEROS, false); }

@@ -435,8 +435,12 @@ int advchain_scatter_tiled_launch(bool self, const float* gout, const float* in,
   return ADVCHAIN_OK;
 }
 
+extern "C" int advchain_get_deterministic(void);
+// int32 elements: header [4] + overflow list / row maxima [2 N V]; in deterministic mode followed by the int64 image of
+// grad_in the window scatter accumulates into (up to 4 channels: 8 N V int32) and one max |grad_out| per batch entry
 extern "C" int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims) {
   int64_t V = 1;
   for (int i = 0; i < ndim; ++i) V *= dims[i];
-  return 4 + 2 * N * V;  // int32 elements
+  const int64_t base = 4 + 2 * N * V;
+  return advchain_get_deterministic() ? base + 8 * N * V + ((N + 3) & ~(int64_t)3) : base;
 }

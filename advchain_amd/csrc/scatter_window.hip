@@ -19,17 +19,88 @@
 
 namespace advchain {
 
+// Deterministic mode (advchain_set_deterministic, round 6): the three places where tiles meet in global memory -- the flush
+// of a window, a deposit outside a capped window, the coordinate path of a self-composition -- add 64-bit FIXED POINT
+// (value * 2^40 / max|grad_out| of the batch entry, integer atomics: the order of arrival no longer matters) into an int64
+// image of grad_in that lives in the caller's workspace, and a last pass converts it (k_det_convert): bit-reproducible run
+// to run.  The scale comes from a max |grad_out| per batch entry (k_det_absmax; a NaN / inf there turns the entry's
+// outputs into NaN) -- per entry, so that a sample's result does not depend on what else is in the batch.  Resolution
+// 2^-40 of that maximum per addition; 2^22 additions of the maximum itself fit below 2^63.
+constexpr float kDetFix = 1099511627776.f;   // 2^40
+template <bool DET>
+__device__ __forceinline__ void win_global_add(float* __restrict__ gin, unsigned long long* __restrict__ acc, int64_t idx,
+                                               float v, float sdet) {
+  if (DET) atomicAdd(acc + idx, (unsigned long long)__float2ll_rn(v * sdet));
+  else atomic_add_f32(gin + idx, v);
+}
+__device__ __forceinline__ float det_scale(const float* __restrict__ maxn, int n) {
+  const float m = maxn[n];
+  return (m > 0.f && m <= 3.0e38f) ? kDetFix / m : 0.f;
+}
+
+// max |x| per batch entry (over `per_n` floats) -> maxn[n] (zeroed by the caller); non-finite -> +inf
+__global__ void __launch_bounds__(kBlock) k_det_absmax(const float* __restrict__ x, float* __restrict__ maxn, int64_t per_n) {
+  const int n = blockIdx.y;
+  const float* p = x + (int64_t)n * per_n;
+  float m = 0.f;
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; i < per_n; i += stride) {
+    float v[4];
+    if (i + 4 <= per_n && ((uintptr_t)(p + i) & 15) == 0) {
+      const float4 q = *reinterpret_cast<const float4*>(p + i);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = i + j < per_n ? p[i + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m = fmaxf(m, fabsf(v[j])); bad = bad || !(fabsf(v[j]) <= 3.0e38f); }
+  }
+  if (bad) m = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wm[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) m = fmaxf(m, wm[w]);
+    atomicMax(reinterpret_cast<int*>(maxn) + n, __float_as_int(m));      // (non-negative floats order as their bit patterns)
+  }
+}
+
+// grad_in = int64 image * max / 2^40 (a non-finite maximum: 0 * inf = NaN, as the owner-computes scatters do)
+__global__ void __launch_bounds__(kBlock) k_det_convert(const long long* __restrict__ acc, const float* __restrict__ maxn,
+                                                        float* __restrict__ gin, int64_t per_n) {
+  const int n = blockIdx.y;
+  const float inv = maxn[n] * (1.f / kDetFix);
+  const long long* a = acc + (int64_t)n * per_n;
+  float* g = gin + (int64_t)n * per_n;
+  const int64_t stride = (int64_t)gridDim.x * kBlock * 2;
+  for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 2; i < per_n; i += stride) {
+    if (i + 2 <= per_n) {
+      const longlong2 q = *reinterpret_cast<const longlong2*>(a + i);
+      g[i] = (float)q.x * inv;
+      g[i + 1] = (float)q.y * inv;
+    } else {
+      g[i] = (float)a[i] * inv;
+    }
+  }
+}
+
 constexpr int kWinT = 32;               // sample tile edge
 constexpr int kWinCells = 8192;         // LDS window budget in cells (all channels together): 32 KiB
 constexpr int kWinCellsC4 = 12288;      // four channels: 48 KiB (2048 cells per channel = 45 x 45 capped stretched 32 x 32 tiles)
 
 // SELF : in == grid == phi (C == 2); the coordinate-path gradient is added to the same tensor (atomics: other tiles
 //        deposit there too).  Otherwise GG: grad_grid is written with plain stores.
-template <int PAD, int C, bool SELF, bool GG>
+template <int PAD, int C, bool SELF, bool GG, bool DET = false>
 __global__ void __launch_bounds__(kBlock)
 k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                    float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n2, int clamp_grid,
-                   int32_t* __restrict__ ws) {
+                   int32_t* __restrict__ ws, unsigned long long* __restrict__ acc64 = nullptr,
+                   const float* __restrict__ maxn = nullptr) {
   constexpr int kCells2 = C == 4 ? kWinCellsC4 : kWinCells;
   __shared__ int win[kCells2];
   if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
@@ -45,6 +116,8 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
   const float* gon = gout + (int64_t)n * C * V;
   const float* inn = in + (int64_t)n * C * V;
   float* ginn = gin + (int64_t)n * C * V;
+  unsigned long long* accn = DET ? acc64 + (int64_t)n * C * V : nullptr;
+  const float sdet = DET ? det_scale(maxn, n) : 0.f;
 
   // ---- 1. taps of this thread's samples, bounding box of the valid corners, max |grad_out|
   Taps<DIM, PAD> t[SPT];
@@ -140,16 +213,16 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
 #pragma unroll
           for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[j][c]));
         } else {
-          float* dst = ginn + vox0 + (cy ? d.s2 : 0) + cx;
+          const int64_t dst = vox0 + (cy ? d.s2 : 0) + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[j][c]);
+          for (int c = 0; c < C; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[j][c], sdet);
         }
       }
     if (SELF || GG) {
       const float ggx = cgx[j], ggy = cgy[j];
       if (SELF) {
-        if (ggx != 0.f) atomic_add_f32(ginn + s, ggx);
-        if (ggy != 0.f) atomic_add_f32(ginn + V + s, ggy);
+        if (ggx != 0.f) win_global_add<DET>(ginn, accn, s, ggx, sdet);
+        if (ggy != 0.f) win_global_add<DET>(ginn, accn, (int64_t)V + s, ggy, sdet);
       } else {
         float* gg = ggrid + (int64_t)n * DIM * V + s;
         gg[0] = ggx;
@@ -166,7 +239,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
     if (a == 0) continue;
     const int c = i / cells, r = i - c * cells;
     const int wy = r / ww, wx = r - wy * ww;
-    atomic_add_f32(ginn + (int64_t)c * V + (by0 + wy) * d.s2 + (bx0 + wx), (float)a * inv);
+    win_global_add<DET>(ginn, accn, (int64_t)c * V + (by0 + wy) * d.s2 + (bx0 + wx), (float)a * inv, sdet);
   }
 }
 
@@ -190,11 +263,12 @@ constexpr int kWin3Cells = 12288;        // 48 KiB of LDS: 3 workgroups per CU
 // per channel capped the windows of the 5-8 voxel fields, and what falls outside a window goes to global atomics
 // (8x4x128x128x64: 1449 us; with a 63-KiB window for all four channels 1057 us, but two workgroups a CU).
 
-template <int PAD, int C, bool SELF, bool GG, int TX, int TZ>
+template <int PAD, int C, bool SELF, bool GG, int TX, int TZ, bool DET = false>
 __global__ void __launch_bounds__(kBlock)
 k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in, const float* __restrict__ grid,
                    float* __restrict__ gin, float* __restrict__ ggrid, Dims d, int n1, int n2, int clamp_grid,
-                   int32_t* __restrict__ ws) {
+                   int32_t* __restrict__ ws, unsigned long long* __restrict__ acc64 = nullptr,
+                   const float* __restrict__ maxn = nullptr) {
   __shared__ int win[kWin3Cells];
   constexpr int CP = C == 4 ? kWin3CP4 : (SELF ? kWin3CPS : C);       // channels per deposit / flush pass
   if (ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[3] = -1;   // no max|result| from this launch
@@ -212,6 +286,8 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
   const float* gon = gout + (int64_t)n * C * V;
   const float* inn = in + (int64_t)n * C * V;
   float* ginn = gin + (int64_t)n * C * V;
+  unsigned long long* accn = DET ? acc64 + (int64_t)n * C * V : nullptr;
+  const float sdet = DET ? det_scale(maxn, n) : 0.f;
 
   // ---- 1. bounding box of the valid corners, max |grad_out|
   int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
@@ -330,9 +406,9 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
 #pragma unroll
             for (int c = 0; c < CP; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c0 + c]));
           } else {
-            float* dst = ginn + vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx + (int64_t)c0 * V;
+            const int64_t dst = vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx + (int64_t)c0 * V;
 #pragma unroll
-            for (int c = 0; c < CP; ++c) atomic_add_f32(dst + (int64_t)c * V, w * go[c0 + c]);
+            for (int c = 0; c < CP; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[c0 + c], sdet);
           }
         }
     if ((SELF || GG) && c0 == 0) {
@@ -342,9 +418,9 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
       const float ggx = pass[0] ? t.x.mult * ax : 0.f, ggy = pass[1] ? t.y.mult * ay : 0.f,
                   ggz = pass[2] ? t.z.mult * az : 0.f;
       if (SELF) {
-        if (ggx != 0.f) atomic_add_f32(ginn + s, ggx);
-        if (ggy != 0.f) atomic_add_f32(ginn + V + s, ggy);
-        if (ggz != 0.f) atomic_add_f32(ginn + 2 * (int64_t)V + s, ggz);
+        if (ggx != 0.f) win_global_add<DET>(ginn, accn, s, ggx, sdet);
+        if (ggy != 0.f) win_global_add<DET>(ginn, accn, (int64_t)V + s, ggy, sdet);
+        if (ggz != 0.f) win_global_add<DET>(ginn, accn, 2 * (int64_t)V + s, ggz, sdet);
       } else {
         float* gg = ggrid + (int64_t)n * DIM * V + s;
         gg[0] = ggx;
@@ -366,7 +442,8 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
       const int r = (int)(((float)i + 0.5f) * inv_ww), wx = i - r * ww;          // (exact: i < 2^15)
       const int rz = (int)(((float)r + 0.5f) * inv_wh), wy = r - rz * wh;
       const int c = (int)(((float)rz + 0.5f) * inv_wd), wz = rz - c * wd;
-      atomic_add_f32(ginn + (int64_t)(c0 + c) * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + wx), (float)a * inv);
+      win_global_add<DET>(ginn, accn, (int64_t)(c0 + c) * V + ((lo[2] + wz) * d.s1 + (lo[1] + wy)) * d.s2 + (lo[0] + wx),
+                          (float)a * inv, sdet);
     }
   }
   if (c0 + CP < C) __syncthreads();          // the window is cleared for the next channel pair
@@ -382,17 +459,36 @@ using namespace advchain;
 // since the corner loads are issued unconditionally it beats the owner-computes tiles from one voxel up).
 // A chained workspace is told (by the kernel itself) that this launch left no max|result| behind (header [3] = -1:
 // see scatter_tiled.hip).
+// det_ws (deterministic mode): the caller's advchain_scatter_workspace buffer; its tail holds the int64 image of grad_in and
+// the per-entry maxima -- three more launches (clear, maxima, convert), no float atomic between tiles.
 // Returns ADVCHAIN_ERR_UNSUPPORTED for what the kernels do not cover (the caller keeps the owner-computes tiles).
+extern "C" int advchain_get_deterministic(void);
 int advchain_scatter_window_launch(bool self, const float* gout, const float* in, const float* grid, float* gin,
                                    float* ggrid, int64_t N, int64_t C, int ndim, Dims d, int padding, int clamp_grid,
-                                   int halo, int32_t* workspace, hipStream_t st) {
+                                   int halo, int32_t* workspace, hipStream_t st, int32_t* det_ws) {
   static const bool off = getenv("ADVCHAIN_NO_WINDOW_SCATTER") != nullptr;   // A/B knob
   static const int min3 = 2;   // measured optimum (was a tuning knob until round 4)
   if (off || padding == PAD_REFLECTION) return ADVCHAIN_ERR_UNSUPPORTED;
   if (d.s2 >= (1 << 23) || (int64_t)d.s0 * d.s1 >= (1 << 23)) return ADVCHAIN_ERR_UNSUPPORTED;   // 24-bit index products
   if (self ? C != ndim : (C != 1 && C != 2 && C != 4)) return ADVCHAIN_ERR_UNSUPPORTED;
   if (ndim == 3 && (halo < 0 ? -halo : halo) < min3) return ADVCHAIN_ERR_UNSUPPORTED;
-  advchain_zero_async(gin, sizeof(float) * N * C * d.voxels(), st);
+  const bool det = advchain_get_deterministic() != 0 && det_ws != nullptr;
+  const int64_t V = d.voxels();
+  unsigned long long* acc64 = nullptr;
+  float* maxn = nullptr;
+  if (det) {
+    // [header 4][2 N V][int64 image: N x C x V (room for 4 channels)][max per entry: N]
+    acc64 = reinterpret_cast<unsigned long long*>(det_ws + 4 + 2 * N * V);
+    maxn = reinterpret_cast<float*>(det_ws + 4 + 2 * N * V + 8 * N * V);
+    advchain_zero_async(acc64, sizeof(unsigned long long) * N * C * V, st);
+    advchain_zero_async(maxn, sizeof(float) * N, st);
+    const int64_t per_n = C * V;
+    int64_t nb = (per_n + kBlock * 16 - 1) / (kBlock * 16);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_det_absmax, dim3((unsigned)nb, (unsigned)N), dim3(kBlock), 0, st, gout, maxn, per_n);
+  } else {
+    advchain_zero_async(gin, sizeof(float) * N * C * V, st);
+  }
   const bool gg = ggrid != nullptr;
   dim3 b(kBlock);
 #define GO_PAD(C_, SELF_, GG_) \
@@ -408,7 +504,10 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
     const int n2 = (d.s2 + kWinT - 1) / kWinT, n1 = (d.s1 + kWinT - 1) / kWinT;
     dim3 g((unsigned)(n1 * n2), (unsigned)N);
 #define GO(PAD_, C_, SELF_, GG_) \
-  hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid, workspace)
+  do { \
+    if (det) hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_, true>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid, workspace, acc64, maxn); \
+    else hipLaunchKernelGGL((k_scatter_window2d<PAD_, C_, SELF_, GG_, false>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n2, clamp_grid, workspace, acc64, maxn); \
+  } while (0)
     GO_ALL(2);
 #undef GO
   } else {
@@ -421,16 +520,26 @@ int advchain_scatter_window_launch(bool self, const float* gout, const float* in
     const int TXs = sh == 0 ? 32 : 16, TYs = kBlock / TXs, TZs = 4;
     const int n2 = (d.s2 + TXs - 1) / TXs, n1 = (d.s1 + TYs - 1) / TYs, n0 = (d.s0 + TZs - 1) / TZs;
     dim3 g((unsigned)(n0 * n1 * n2), (unsigned)N);
+#define GO3(PAD_, C_, SELF_, GG_, TX_, DET_) \
+  hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_, TX_, 4, DET_>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace, acc64, maxn)
 #define GO(PAD_, C_, SELF_, GG_) \
   do { \
-    if (sh == 0) hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_, 32, 4>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace); \
-    else hipLaunchKernelGGL((k_scatter_window3d<PAD_, C_, SELF_, GG_, 16, 4>), g, b, 0, st, gout, in, grid, gin, ggrid, d, n1, n2, clamp_grid, workspace); \
+    if (sh == 0) { if (det) GO3(PAD_, C_, SELF_, GG_, 32, true); else GO3(PAD_, C_, SELF_, GG_, 32, false); } \
+    else { if (det) GO3(PAD_, C_, SELF_, GG_, 16, true); else GO3(PAD_, C_, SELF_, GG_, 16, false); } \
   } while (0)
     GO_ALL(3);
 #undef GO
+#undef GO3
   }
 #undef GO_ALL
 #undef GO_PAD
+  if (det) {
+    const int64_t per_n = C * V;
+    int64_t nb = (per_n + kBlock * 8 - 1) / (kBlock * 8);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_det_convert, dim3((unsigned)nb, (unsigned)N), dim3(kBlock), 0, st, reinterpret_cast<const long long*>(acc64),
+                       maxn, gin, per_n);
+  }
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

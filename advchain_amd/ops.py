@@ -189,6 +189,18 @@ RIDE_MASK = True      # the solver's validity mask rides through the data's warp
 RIDE_INTERPS = ("bilinear", "trilinear", "linear", "nearest")
 
 
+def set_deterministic(on):
+    """Process-wide: route the one backward formulation whose bits depend on arrival order (the window scatter's float-atomic
+    flush) through its 64-bit fixed-point twin (include/advchain_hip.h: advchain_set_deterministic).  The solver sets it at
+    the start of every call from its `deterministic` attribute; two solvers with different settings in one process are fine as
+    long as their calls do not interleave (a workspace is sized when it is allocated, for the mode of that moment)."""
+    _lib.load().advchain_set_deterministic(1 if on else 0)
+
+
+def is_deterministic():
+    return bool(_lib.load().advchain_get_deterministic())
+
+
 def _scatter_workspace(N, dims, device):
     n = _lib.load().advchain_scatter_workspace(N, len(dims), _lib.dims_array(dims))
     return torch.empty(n, device=device, dtype=torch.int32)

@@ -167,7 +167,7 @@ def entry_label(name, a):
 
 
 # ------------------------------------------------------------------------------------------------
-def build_solver(wl, device, process_group=None):
+def build_solver(wl, device, process_group=None, hip_graph=None):
     from advchain_amd.augmentor import (AdvAffine, AdvBias, AdvMorph, AdvNoise,
                                         ComposeAdversarialTransformSolver)
     cls = {"noise": AdvNoise, "bias": AdvBias, "morph": AdvMorph, "affine": AdvAffine}
@@ -176,7 +176,8 @@ def build_solver(wl, device, process_group=None):
              for nm, cfg in transform_configs(wl["dims"], wl["batch"], wl["chain"], morph_div8=wl.get("anatomy", False))]
     return ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
                                              divergence_weights=[1.0, 0.5], process_group=process_group,
-                                             hip_graph=HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
+                                             hip_graph=(HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
+                                             if hip_graph is None else bool(hip_graph))
 
 
 def solver_kwargs(wl, device):
@@ -231,7 +232,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     extras: model / path split of a step, per-rank step times and collectives per step when sharded)."""
     import torch.distributed as dist
     from advchain_amd import _lib
-    pg = dist.group.WORLD if world > 1 else None
+    pg = dist.group.WORLD if (world > 1 or FORCE_PG) else None
     sd = len(wl["dims"])
     torch.manual_seed(1234 + rank)
     data = torch.rand(wl["batch"], 1, *wl["dims"], device=device)
@@ -308,7 +309,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     gc.disable()
     lib.records = []
     n_coll = [0]
-    if world > 1:        # collectives per step: every all_reduce the path issues goes through torch.distributed.all_reduce
+    if world > 1 or FORCE_PG:        # collectives per step: every all_reduce the path issues goes through torch.distributed.all_reduce
         orig_all_reduce = dist.all_reduce
 
         def counted_all_reduce(*a, **k):
@@ -347,14 +348,17 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     # kernel-busy time and launches per step: the sum of kernel durations of the rocprofv3 kernel trace of THIS command
     # (tools/profile_bench.sh -> profiles/rNN/per_call_summary.txt, newest round that holds the workload), not an
     # in-process estimate -- a replayed graph carries no per-kernel events.  host_gap = ms_per_step - gpu_busy
-    busy = profiled_busy(workload)
+    # (round 6: measured in this run -- torch.profiler's kernel records over further calls after the timed region; the
+    # committed rocprofv3 summary of the same command only where the profiler is not usable)
+    busy = None if PROFILING_RUN else traced_busy(step, sync)
+    if busy is not None and len(busy) == 1:
+        extras["gpu_busy_trace"] = busy[0]
+        busy = None
+    if busy is None:
+        busy = profiled_busy(workload)
     if busy is not None:
         extras["gpu_busy_ms_per_step"], extras["launches_per_step"], extras["gpu_busy_source"] = busy
         extras["host_gap_ms_per_step"] = round(elapsed / steps * 1e3 - busy[0], 3)
-        if extras["host_gap_ms_per_step"] < 0:
-            extras["host_gap_note"] = ("negative: the committed trace's kernels run ~1-2 % longer under rocprofv3 than untraced, and its "
-                                       "per-call mean includes the recorded (launch-by-launch) calls; this run's own figure is "
-                                       "ms_per_step - gpu_span_ms_per_step")
     extras["abi_calls_per_step"] = abi_calls
     if graphed:
         st = solver.graph_stats
@@ -379,6 +383,52 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                 step()
             sync()
             extras["ordinary_ms_per_step"] = round((time.perf_counter() - t1) / k_ord * 1e3, 3)
+    if (not graphed) and sd == 2 and pg is None and REPLAY_LEG and not PROFILING_RUN and not wl.get("anatomy"):
+        # the same workload with the ascent loop of a call replayed from a hipGraph (solver.hip_graph=True: opt-in in the
+        # product).  A solver of its own: recorded calls, capture, then K timed replays
+        rs = build_solver(wl, device, None, hip_graph=True)
+
+        def rstep():
+            with contextlib.redirect_stdout(io.StringIO()):
+                return rs.adversarial_training(data=data, model=model, **kw)
+        for _ in range(int(rs.hip_graph_record_calls) + 3):
+            rstep()
+        k_rep = max(3, min(steps, 20))
+        r0 = dict(rs.graph_stats)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k_rep):
+            rstep()
+        sync()
+        extras["replayed_ms_per_step"] = round((time.perf_counter() - t1) / k_rep * 1e3, 3)
+        extras["replayed"] = {"steps": k_rep, "replays": rs.graph_stats["replays"] - r0["replays"],
+                              "violations": rs.graph_stats["violations"] - r0["violations"], "captures": rs.graph_stats["captures"],
+                              "note": "solver.hip_graph=True (opt-in): prediction + ascent steps of a call as ONE hipGraph replay, the "
+                                      "final pass dispatched behind it; `value` / `ms_per_step` are the DEFAULT path (launch by launch)"}
+        del rs
+    if workload in DETERMINISTIC_LEG and world == 1 and pg is None and not PROFILING_RUN:
+        # the same steps with solver.deterministic = True (ordinary path): the window scatter's float-atomic flush replaced by its
+        # 64-bit fixed-point twin (bit-reproducible run to run) -- what the mode costs on the workloads that reach that kernel
+        from advchain_amd import ops as _ops_det
+        ds = build_solver(wl, device, None, hip_graph=False)
+        ds.deterministic = True
+
+        def dstep():
+            with contextlib.redirect_stdout(io.StringIO()):
+                return ds.adversarial_training(data=data, model=model, **kw)
+        try:
+            for _ in range(2):
+                dstep()
+            k_det = max(3, min(steps, 10))
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k_det):
+                dstep()
+            sync()
+            extras["deterministic_ms_per_step"] = round((time.perf_counter() - t1) / k_det * 1e3, 3)
+        finally:
+            _ops_det.set_deterministic(False)
+        del ds
     if not PROFILING_RUN and dominant and not lib.records:
         # nothing in the timed region could carry the dominant entry's events (a replayed graph makes no C-ABI call; the
         # composite DemonsCompose entries hold the chain inside one call): the same launches, enqueued entry by entry
@@ -391,7 +441,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                     step()
             sync()
         extras["roofline_steps"] = k_ord
-    if world > 1:
+    if world > 1 or FORCE_PG:
         dist.all_reduce = orig_all_reduce
         extras["all_reduces_per_step"] = round(n_coll[0] / float(steps), 2)
     # model / path split: an instrumented pass of a few steps after the timed region (events around the model's forward
@@ -441,6 +491,29 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, roof, breakdown, extras
+
+
+def traced_busy(step, sync, calls=2):
+    """(kernel-busy ms, kernel launches) per call, measured IN THIS RUN: `calls` further steps under torch.profiler's device
+    activity (roctracer kernel records: the begin / end timestamps rocprofv3's kernel trace reads), after the timed
+    region.  None when the profiler is not usable here."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        sync()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(calls):
+                step()
+            sync()
+        evs = [e for e in prof.events() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
+        kern = [e for e in evs if not any(w in e.name.lower() for w in ("memcpy", "memset", "hipmemcpy", "hipmemset"))]
+        if not kern:
+            return None
+        def dur(e):
+            return float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0) or 0.0)
+        return (round(sum(dur(e) for e in kern) * 1e-3 / calls, 3), round(len(kern) / float(calls), 1),
+                "torch.profiler device activity over %d further calls of this run (kernel records only)" % calls)
+    except Exception as exc:        # noqa: BLE001 -- a measurement aid: never takes the bench line down
+        return ("unavailable: %s: %s" % (type(exc).__name__, str(exc)[:120]),)
 
 
 def _rank_spread(ms, world, device):
@@ -526,6 +599,36 @@ def _time_pair(x, go, q, halo, reps, disp=None):
     return ef[0].elapsed_time(ef[1]) * 1e-3 / reps, ef[1].elapsed_time(ef[2]) * 1e-3 / reps
 
 
+def _trace_pair(x, go, q, halo, reps, disp):
+    """Per-kernel durations of the pair from the device's kernel records: `reps` fwd + bwd pairs under torch.profiler.
+    Returns {"pair_us", "kernels": {name: avg us}} or None when the profiler is not usable."""
+    from advchain_amd import ops
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(reps):
+                ops.raw_grid_sample_fwd(x, q, 0, 0, True, disp_hint=disp)
+                ops.raw_grid_sample_bwd(go, x, q, 0, 0, True, True, True, halo)
+            torch.cuda.synchronize()
+        per = {}
+        for e in prof.events():
+            if getattr(e, "device_type", None) is None or "cuda" not in str(e.device_type).lower():
+                continue
+            nm = e.name.split("(")[0]
+            if not nm.startswith("void advchain::k_") and not nm.startswith("advchain::k_") and "k_" not in nm:
+                continue
+            d = float(getattr(e, "device_time_total", 0.0) or getattr(e, "cuda_time_total", 0.0) or 0.0)
+            per.setdefault(nm, []).append(d)
+        per = {k: v for k, v in per.items() if len(v) >= reps}
+        if not per:
+            return None
+        return {"pair_us": round(sum(sum(v) for v in per.values()) / reps, 2),
+                "kernels": {k.replace("void ", "").replace("advchain::", ""): round(sum(v) / len(v), 2) for k, v in per.items()}}
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def grid_sample3d_roofline(device, reps=20):
     """North-star kernel: 3D trilinear grid_sample fwd+bwd at 4x1x128x128x64, at TWO displacement levels: a freshly
     initialised AdvMorph field (sub-voxel) and the field the cfg-3 solver ends with after its 3 ascent steps."""
@@ -556,10 +659,18 @@ def grid_sample3d_roofline(device, reps=20):
         entry = ops.grid_displacement(q)
         halo = ops.warp_halo(entry, 3)
         tf, tb = _time_pair(x, go, q, halo, reps, float(entry[1]))
+        # the figure to quote: the kernels' own durations from the device's kernel records (what the
+        # committed rocprofv3 trace of tools/north_star_pair.py reads, profiles/rNN/ns_pair_summary.txt); the back-to-back
+        # event timing overlaps the launch ramp of one kernel with the tail of its twin and reads ~8 % less
+        tr = _trace_pair(x, go, q, halo, reps, float(entry[1]))
+        t_pair = tr["pair_us"] * 1e-6 if tr else (tf + tb)
         levels[tag] = {"max_displacement_voxels": round(float(entry[1]), 3), "bwd_form": _bwd_form(halo),
-                       "fwd_us": round(tf * 1e6, 2), "bwd_us": round(tb * 1e6, 2),
-                       "achieved": round((bf + bb) / (tf + tb) / 1e9, 1),
-                       "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4),
+                       "frac": round((bf + bb) / t_pair / 1e9 / HBM_PEAK_GBS, 4),
+                       "achieved": round((bf + bb) / t_pair / 1e9, 1),
+                       "frac_from": "kernel records of this run (torch.profiler device activity)" if tr else "HIP events, launches back to back",
+                       "trace": tr,
+                       "events": {"fwd_us": round(tf * 1e6, 2), "bwd_us": round(tb * 1e6, 2),
+                                  "frac": round((bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS, 4)},
                        "traffic": profiled_traffic("north_star", tag)[0]}
         if tag == "init_field":
             q0 = q
@@ -673,15 +784,19 @@ def run_stub(steps, warmup, rank, world):
 
 
 PROFILING_RUN = False                   # --only-workload
-# --no-graph: every step dispatched launch by launch from Python (the ordinary path).  Default: the 2D workloads replay their
-# ascent loop from a hipGraph (cfg-1 is host-bound, cfg-2 borders on it); the 3D ones stay on the ordinary path -- the host is
-# 1 % of their step, and the replay's safety margin moves the 3.2-voxel warps of cfg-3 from the exact 4-voxel march scatter
-# onto the window scatter (14.45 against 14.1 ms, profiles/r05/)
-HIP_GRAPH = True
+# Default (round 6): every step dispatched launch by launch from Python -- the product's default path (solver.hip_graph is
+# opt-in) is what `value` reports; the 2D workloads are then timed once more with their ascent loop replayed from a hipGraph
+# (`replayed_ms_per_step`, `replayed`).  --graph: the replay IS the timed region (round 5's headline), the ordinary path beside
+# it (`ordinary_ms_per_step`).  3D workloads never replay here: the host is 1 % of their step, and the replay's safety margin
+# moves the 3.2-voxel warps of cfg-3 from the exact 4-voxel march scatter onto the window scatter (14.45 against 14.1 ms)
+HIP_GRAPH = False
 # sharded runs replay their graphs too (solver._shardable_capture: nothing collective is captured, one all-reduce per call
 # checks the premise) only when asked (--sharded-graph): tested with two gloo ranks on one GPU, never on a multi-GPU box
 # with RCCL next to a capture, so the default for --gpus N > 1 stays launch by launch
 SHARDED_GRAPH = False
+REPLAY_LEG = True                       # 2D, one GPU, ordinary path timed: time the replayed ascent loop as well
+FORCE_PG = False                        # --force-pg
+DETERMINISTIC_LEG = ("cfg2", "cfg5")     # workloads whose backward reaches the window scatter: timed once more in deterministic mode
 SECONDARY = ("cfg3", "cfg4", "cfg5")   # the 3D BASELINE configs, timed after the headline workload at N = 1
 
 
@@ -704,9 +819,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="dispatch every step launch by launch from Python (solver.hip_graph off); default: the ascent loop "
-                         "of a step is one hipGraph replay")
+    ap.add_argument("--graph", action="store_true",
+                    help="time the steps with the ascent loop of a 2D workload replayed from a hipGraph (solver.hip_graph=True, "
+                         "opt-in in the product); default: launch by launch -- the product's default path -- with the replay "
+                         "timed beside it as `replayed_ms_per_step`")
+    ap.add_argument("--no-graph", action="store_true", help="(default since round 6; kept for old command lines)")
+    ap.add_argument("--no-replay-leg", action="store_true", help="skip the secondary replayed timing of a 2D workload")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="--gpus 1: initialise the nccl (= RCCL) process group with ONE rank anyway and run the solver "
+                         "through it (device-tensor all-reduces on the data path, `rccl_ranks` from a real all-reduce)")
     ap.add_argument("--sharded-graph", action="store_true",
                     help="--gpus N > 1: replay the 2D ascent loop from a hipGraph on every rank as well (one all-reduce per "
                          "call checks the premise); default for N > 1: launch by launch")
@@ -715,9 +836,10 @@ def main():
                     help="profiling runs: the chosen workload and nothing else (no secondary configs, no north-star "
                          "kernel pair, no CPU baseline)")
     args = ap.parse_args()
-    global PROFILING_RUN, HIP_GRAPH, SHARDED_GRAPH
+    global PROFILING_RUN, HIP_GRAPH, SHARDED_GRAPH, REPLAY_LEG
     PROFILING_RUN = bool(args.only_workload)
-    HIP_GRAPH = not args.no_graph
+    HIP_GRAPH = bool(args.graph) and not args.no_graph
+    REPLAY_LEG = not (args.no_replay_leg or args.only_workload)
     SHARDED_GRAPH = bool(args.sharded_graph)
     stub = os.environ.get("ADVCHAIN_BENCH_STUB") == "1"
     if args.gpus < 1:
@@ -739,11 +861,17 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     rccl_ranks = 1
-    if world > 1:
+    global FORCE_PG
+    FORCE_PG = bool(args.force_pg) and world == 1 and not stub
+    if world > 1 or FORCE_PG:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if stub:
             dist.init_process_group("gloo")
+        elif FORCE_PG:       # one rank, no launcher: the rendezvous is this process alone
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         else:
             dist.init_process_group("nccl", device_id=device)
         # ranks that actually took part in a collective on device memory (RCCL), not what the environment claims
@@ -765,7 +893,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rec["workload"], "global_batch": rec["global_batch"],
-                       "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world,
+                       "adv_steps": wl["n_iter"], "parallelism": "batch-sharded x%d" % world + (" (one-rank RCCL group forced)" if FORCE_PG else ""),
                        "dispatch": "hipGraph replay of the ascent loop (solver.hip_graph)" if (HIP_GRAPH and (world == 1 or SHARDED_GRAPH) and not stub
                                                                                                   and len(wl["dims"]) == 2)
                        else "launch by launch",
@@ -793,7 +921,7 @@ def main():
             if not (args.no_cpu_baseline or args.only_workload):
                 out["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or FORCE_PG:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -42,6 +42,24 @@ extern "C" {
 int advchain_version(void);
 const char* advchain_last_error(void);
 
+/* ---- deterministic mode (round 6) ---------------------------------------------------------
+ * replaces: nothing the reference writes down -- its CPU path (the parity target) is deterministic by construction, and
+ *           on a GPU it inherits torch.use_deterministic_algorithms(), under which grid_sampler_{2,3}d_backward
+ *           (reached from adv_morph.py:546-557 through autograd) raises for want of a deterministic kernel.  Here the one
+ *           formulation whose bits depend on arrival order -- the source-tiled window scatter (2D image warps above
+ *           16 px, squarings above 32 px; 3D above 4 voxels), which flushes its LDS windows with float atomics -- gets a
+ *           bit-reproducible twin: the tiles add 64-bit fixed point (2^40 / max|grad_out| of the batch entry) into an
+ *           int64 image of grad_in inside the caller's workspace and one more pass converts it.  Every other backward
+ *           formulation (gather forms, owner-computes scatters, affine tiles) is deterministic already.
+ * PROCESS-WIDE switch, read when a backward entry is called and by advchain_scatter_workspace (which then returns the larger
+ * size: allocate workspaces AFTER setting the mode; a workspace sized in the other mode must not be reused).  Not covered
+ * (still float atomics): the overflow list of the LDS-tiled scatter (reflection padding, 3-channel image warps, calls without
+ * a displacement bound), nearest-neighbour / size-changing backward, the bicubic backward, affine samples flagged as
+ * degenerate, and the VALUE of the consistency loss / of the 3D step-count norm (partial sums arrive in any order; nothing
+ * downstream of them but the number itself depends on the order).                                                       */
+void advchain_set_deterministic(int on);
+int advchain_get_deterministic(void);
+
 /* ---- dense-field warp ------------------------------------------------------------------
  * replaces: F.grid_sample(data, grid.permute(..), mode, padding_mode, align_corners=True)
  *           advchain/augmentor/adv_morph.py:546-557 (AdvMorph.transform), and the final
@@ -78,7 +96,7 @@ int advchain_grid_sample_fwd_ride(const float* in, const float* grid, float* out
  * overflow list.  Bounds above the gather form (2D: any; 3D: hints >= 2, i.e. one voxel and more) select the
  * source-tiled window scatter (float atomics between tiles: summation order, ~1e-7 relative, varies run to run).
  * 0 = default tiles.  halo < 0: |halo| is exact (guaranteed by the caller): see advchain_compose_self_bwd.  */
-int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements */
+int64_t advchain_scatter_workspace(int64_t N, int ndim, const int64_t* dims); /* int32 elements (larger in deterministic mode) */
 int advchain_grid_sample_bwd(const float* grad_out, const float* in, const float* grid, float* grad_in,
                              float* grad_grid, int32_t* workspace, int64_t N, int64_t C, int ndim,
                              const int64_t* in_dims, const int64_t* out_dims, int interp, int padding, int clamp_grid,

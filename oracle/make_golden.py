@@ -21,8 +21,8 @@ import torch.nn.functional as F
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle._import_reference import import_reference  # noqa: E402
-from tests.helpers import (bn_dropout_model, counted_torch_seed, device_independent, make_model_multi, notebook_configs,  # noqa: E402
-                           sampled_record, seeded_init_param)
+from tests.helpers import (SAMPLE_FULL, anatomy_blob, bn_dropout_model, counted_torch_seed, device_independent,  # noqa: E402
+                           make_model_multi, notebook_configs, sampled_record, seeded_init_param)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 CPU = torch.device("cpu")
@@ -485,6 +485,14 @@ G6L_CASES = {
     # the smallest batch at which the product's fused 2D squaring launch (expo_fused2d.hip) takes the chain, so that the
     # default path of the headline workload meets a reference fixture directly
     "2d_full_256_n8": dict(sd=2, N=8, dims=(256, 256), names=["noise", "bias", "morph", "affine"], seed=4701),
+    # round 6: the 3D BASELINE geometries themselves, one sample each.  cfg-3 / cfg-4's 128 x 128 x 64
+    # ([bias, morph, affine], rows of 64 voxels: the lane <-> x marching sampler / adjoint, and -- second variant, the
+    # velocity x 4 as in 3d_full_64_multivoxel -- the ring forward and the wide march scatter), and cfg-5's 160 x 160 x 80
+    # (morph only, vector_size = dims // 8, anatomy mask with the reference's default weight and tolerance: rows of 80)
+    "3d_cfg3_128": dict(sd=3, N=1, dims=(128, 128, 64), names=["bias", "morph", "affine"], seed=4800),
+    "3d_cfg3_128_multivoxel": dict(sd=3, N=1, dims=(128, 128, 64), names=["bias", "morph", "affine"], seed=4850,
+                                   param_scale={"morph": 4.0}),
+    "3d_cfg5_160": dict(sd=3, N=1, dims=(160, 160, 80), names=["morph"], morph_div8=True, seed=4900, anatomy=True),
 }
 
 
@@ -508,7 +516,18 @@ def _g6l_run(aug, c, jitter=None, trial=0):
                                                    divergence_types=["mse", "contour"], divergence_weights=[1.0, 0.5])
     data = smooth_data(N, 1, dims, c["seed"])
     model = make_model(sd)
-    steps, losses, fields = [], [], []
+    steps, losses, fields, anat = [], [], [], []
+    kw = {}
+    if c.get("anatomy"):
+        kw.update(anatomy_mask_images=anatomy_blob(N, dims), anatomy_reg_weight=50,
+                  volume_preserve_tolerance=c.get("volume_preserve_tolerance", 5e-4))
+        orig_anat = solver.compute_anatomy_misoverlapping_loss
+
+        def anat_rec(anatomy_mask_images):
+            v = orig_anat(anatomy_mask_images)
+            anat.append(float(v.detach()))
+            return v
+        solver.compute_anatomy_misoverlapping_loss = anat_rec
     for ti, t in enumerate(chain):
         def wrap(t=t, ti=ti, orig=t.optimize_parameters):
             def f(step_size=None):
@@ -544,8 +563,9 @@ def _g6l_run(aug, c, jitter=None, trial=0):
         return v
     solver.loss_fn = loss_rec
     with contextlib.redirect_stdout(io.StringIO()):
-        loss = solver.adversarial_training(data=data, model=model, n_iter=c.get("n_iter", 1), lazy_load=True, step_sizes=1)
-    return dict(chain=chain, specs=specs, solver=solver, steps=steps, losses=losses, loss=loss, fields=fields)
+        loss = solver.adversarial_training(data=data, model=model, n_iter=c.get("n_iter", 1), lazy_load=True, step_sizes=1, **kw)
+    return dict(chain=chain, specs=specs, solver=solver, steps=steps, losses=losses, loss=loss, fields=fields, anat=anat,
+                train={k: v for k, v in kw.items() if k != "anatomy_mask_images"})
 
 
 def g6l_large(aug):
@@ -564,11 +584,19 @@ def g6l_large(aug):
         run = _g6l_run(aug, c)
         chain, specs, solver, steps, losses, loss = (run[k] for k in ("chain", "specs", "solver", "steps", "losses", "loss"))
         n_it = c.get("n_iter", 1)
-        assert len(steps) == n_it * len(chain)
+        assert len(steps) == n_it * len(chain), (tag, len(steps), run["anat"])
+        if c.get("anatomy"):
+            # [init check, the step's regulariser, end-of-loop check]: both checks pass, so the reference drew no random
+            # re-initialisation and took no extra step (adv_compose_solver.py:495, 377-398) -- the run is RNG-free
+            tol = run["train"]["volume_preserve_tolerance"]
+            print("  %s: anatomy mis-overlap trace %s (tolerance %g)" % (tag, run["anat"], tol))
+            assert len(run["anat"]) == 2 + n_it and run["anat"][0] <= tol and run["anat"][-1] <= tol, run["anat"]
         out = dict(meta=dict(spatial_dims=sd, batch=N, dims=list(dims), names=c["names"], morph_div8=c.get("morph_div8", False),
                              seed=c["seed"], chain=[dict(name=nm, config=cfg) for nm, cfg in specs], n_iter=n_it,
-                             param_scale=c.get("param_scale", {}), jitter_levels=G6L_JITTER),
-                   loss_trace=np.array(losses, dtype=np.float64), final_loss=loss.detach().double())
+                             param_scale=c.get("param_scale", {}), jitter_levels=G6L_JITTER,
+                             has_anatomy=bool(c.get("anatomy")), train=run["train"]),
+                   loss_trace=np.array(losses, dtype=np.float64), final_loss=loss.detach().double(),
+                   anatomy_trace=np.array(run["anat"], dtype=np.float64))
         recs = dict(adv_data=solver.adv_data, init_output=solver.init_output, warped_back=solver.warped_back_adv_output)
         for j, rec in enumerate(steps):      # step 0 keeps the round-3 key names; later steps carry a suffix _s<k>
             sfx = "" if j < len(chain) else "_s%d" % (j // len(chain))
@@ -579,7 +607,7 @@ def g6l_large(aug):
         if "morph" in c["names"]:
             mi = c["names"].index("morph")
             recs["morph_field"] = run["fields"][0]
-            small = [ti for ti in range(len(chain)) if steps[ti]["grad"].numel() <= 8192]      # bias, morph, affine
+            small = [ti for ti in range(len(chain)) if steps[ti]["grad"].numel() <= SAMPLE_FULL]      # bias, morph, affine
             for lvl, amp in enumerate(G6L_JITTER):
                 spread = {ti: torch.zeros_like(steps[ti]["grad"]) for ti in small}
                 for trial in range(3):

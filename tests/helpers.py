@@ -181,6 +181,14 @@ def notebook_configs(dims, batch, names, morph_div8=False):
     return out
 
 
+def anatomy_blob(n, dims):
+    """The 0/1 anatomy mask of the g6l cases that carry one (an ellipsoid of half the extent along every axis, the same for
+    every sample): shared by oracle/make_golden.py and the tests that replay the case."""
+    axes = torch.meshgrid([torch.linspace(-1, 1, s) for s in dims], indexing="ij")
+    blob = (sum(a ** 2 for a in axes) <= 0.5 ** 2 * len(dims)).float()
+    return blob[None, None].repeat(n, 1, *([1] * len(dims))).contiguous()
+
+
 def seeded_init_param(name, shape, seed):
     """Initial parameters of a g6l case, from a seed (the fixtures do not store them): bias well inside its clip range,
     affine at 60 % of its bounds, noise / morph on the unit L2 sphere per sample (what init_parameters() produces)."""
@@ -194,7 +202,7 @@ def seeded_init_param(name, shape, seed):
 
 
 SAMPLE_STRIDE = 61      # tensors above SAMPLE_FULL elements are stored as every 61st element + float64 moments
-SAMPLE_FULL = 8192
+SAMPLE_FULL = 16384     # (8192 until round 5; 16384 keeps cfg-5's 3 x 20 x 20 x 10 velocity gradient whole.  Readers go by key)
 
 
 def sampled_record(t):

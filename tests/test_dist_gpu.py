@@ -176,3 +176,85 @@ def test_a_violation_on_one_rank_sends_every_rank_down_the_ordinary_path():
         assert p["final"]["captures"] == 2 and p["final_state"] == "replay", p["final"]
     assert parts[0]["final"] == parts[1]["final"]
     check_parts(parts, ref, 2e-5, 5e-5, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL itself (round 6)
+def _rccl_worker(rank, world, initfile, out):
+    """ONE rank on cuda:0 through the `nccl` backend (= RCCL on ROCm): library load, communicator bound to the device
+    (`device_id`), all-reduces of DEVICE tensors on the solver's data path -- everything of the multi-GPU path that a one-GPU
+    box can execute."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", init_method="file://" + initfile, rank=rank, world_size=world, device_id=device)
+    one = torch.ones(1, device=device)
+    dist.all_reduce(one)
+    res = {"backend": dist.get_backend(), "ranks": float(one.item())}
+    n_coll = [0]
+    orig = dist.all_reduce
+
+    def counted(t, *a, **k):
+        assert t.is_cuda, "a host tensor reached the RCCL all-reduce"
+        n_coll[0] += 1
+        return orig(t, *a, **k)
+    dist.all_reduce = counted
+    for sd, if_norm in ((2, True), (3, False), ("3a", False)):
+        data, params = _inputs(sd)
+        before = n_coll[0]
+        r = _run_gpu(sd, data, params, dist.group.WORLD, if_norm, shard=slice(0, data.shape[0]), global_n=data.shape[0])
+        res[str(sd)] = dict(loss=r[0], params=r[1], adv=r[2], scores=r[3] if len(r) > 3 else None, collectives=n_coll[0] - before)
+    # the replayed ascent loop under the group (2D): one all-reduce per call carries the check vector
+    from tests.helpers import make_model
+    data, params = _inputs(2)
+    solver, chain = _graph_solver(data.shape[0], dist.group.WORLD, device, True)
+    g = _graph_calls(solver, chain, params, data.to(device), make_model(2).to(device), 6, device)
+    res["graph"] = dict(loss=g[0], params=g[1], adv=g[2], stats=dict(solver.graph_stats))
+    dist.all_reduce = orig
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_carries_the_solver_collectives():
+    """multi-GPU readiness on a one-GPU box.  `dist.init_process_group("nccl", world_size=1,
+    device_id=cuda:0)` and one 2D (if_norm_image: min / max all-reduces), one 3D (the step-count norm) and one 3D anatomy
+    (ladder decisions) solver call through `process_group`, plus a replayed 2D ascent loop: every collective of the path runs
+    through RCCL on device tensors; results equal the run without a group."""
+    from tests.helpers import make_model
+    refs = {}
+    for sd, if_norm in ((2, True), (3, False), ("3a", False)):
+        data, params = _inputs(sd)
+        refs[str(sd)] = _run_gpu(sd, data, params, None, if_norm)
+    device = torch.device("cuda", 0)
+    data, params = _inputs(2)
+    solver, chain = _graph_solver(data.shape[0], None, device, False)
+    gref = _graph_calls(solver, chain, params, data.to(device), make_model(2).to(device), 1, device)
+    with tempfile.TemporaryDirectory() as tmp:
+        initfile = os.path.join(tmp, "init")
+        mp.spawn(_rccl_worker, args=(1, initfile, tmp), nprocs=1, join=True)
+        part = torch.load(os.path.join(tmp, "rank0.pt"))
+    assert part["backend"] == "nccl" and part["ranks"] == 1.0, part
+    for key, ref in refs.items():
+        p = part[key]
+        assert p["collectives"] >= 2, (key, p["collectives"])
+        check_parts([p], ref, 2e-5, 5e-5, 1e-4)
+    st = part["graph"]["stats"]
+    assert st["captures"] == 1 and st["replays"] >= 2 and st["violations"] == 0, st
+    check_parts([part["graph"]], gref, 2e-5, 5e-5, 1e-4)
+
+
+def test_bench_forced_one_rank_group():
+    """`bench.py --gpus 1 --force-pg`: the bench line's `rccl_ranks` comes from a real RCCL all-reduce and the timed steps run
+    their collectives through the one-rank group."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-pg", "--workload", "cfg1", "--steps", "3",
+                        "--warmup", "1", "--no-secondary", "--no-cpu-baseline", "--no-replay-leg"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1 and "forced" in line["config"]["parallelism"], line["config"]
+    assert line["all_reduces_per_step"] >= 2, line.get("all_reduces_per_step")

@@ -245,6 +245,38 @@ def test_batchnorm_model_in_train_mode_is_captured():
     assert graph.graph_stats["replays"] >= 2
 
 
+def test_a_violated_replay_leaves_a_train_mode_model_as_the_ordinary_path_does():
+    """the final consistency pass runs the model in train() mode (BatchNorm statistics tracked,
+    adv_compose_solver.py:256-259).  With the verdict of a replay only read AFTER that pass, a violated replay ran it twice
+    -- once on transforms it then discarded -- and the running statistics / num_batches_tracked saw two updates.  For a
+    model with anything in train() mode the verdict is now read first: after a violated call the model's buffers are
+    exactly what the ordinary path leaves."""
+    dims, names, _ = CASES["2d_full"]
+    N, n_iter = 2, 2
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3, 1, 1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                torch.nn.Conv2d(4, 4, 1)).to(DEV).train()
+    eager, graph = _solver(dims, names, N, False), _solver(dims, names, N, True)
+    data = smooth_data(N, 1, dims, 13).to(DEV)
+    for k in range(5):
+        _call(graph, data, model, n_iter, 800 + k)
+    (rec,) = graph._graphs.values()
+    assert rec["state"] == "replay" and graph.graph_stats["violations"] == 0
+    stats0 = [b.clone() for b in model.buffers()]
+    want = _call(eager, data, model, n_iter, 900)
+    stats1 = [b.clone() for b in model.buffers()]
+    for b, s in zip(model.buffers(), stats0):
+        b.copy_(s)
+    for site in rec["plan"].frozen:          # every interval shrunk to nothing: the replay is violated
+        site["hi"].fill_(1e-9)
+    got = _call(graph, data, model, n_iter, 900)
+    assert graph.graph_stats["violations"] == 1
+    for b, s in zip(model.buffers(), stats1):
+        assert torch.equal(b, s), (b, s)
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+
+
 def test_hundreds_of_replays_at_the_headline_shape_stay_inside_the_frozen_selection():
     """The fault of LESSONS 66: with the library's clears enqueued as hipMemsetAsync -- memset NODES in the capture -- one
     process in three produced garbage gradients somewhere between the 80th and the 200th replay at this shape (caught by the

@@ -11,8 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (Fixture, compare_sampled, counted_torch_seed, fixture_model, make_model, maxdiff, rand,
-                           seeded_init_param, smooth_data)
+from tests.helpers import (Fixture, anatomy_blob, compare_sampled, counted_torch_seed, fixture_model, make_model, maxdiff,
+                           rand, seeded_init_param, smooth_data)
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
@@ -174,7 +174,10 @@ def _teacher_forced(case, fx, solver, chain, meta, model, data, kw, n_steps, n_t
 
 
 G6L_CASES = ["2d_full_256", "3d_full_64", "3d_morph_40x40x80", "2d_cfg1_192", "3d_full_64_multivoxel", "2d_bma_256_n2",
-             "2d_full_256_n8"]
+             "2d_full_256_n8",
+             # round 6: the 3D BASELINE geometries themselves (cfg-3 / cfg-4: 128 x 128 x 64, sub-voxel and 2-4 voxels;
+             # cfg-5: 160 x 160 x 80 morph-only with the anatomy regulariser), one sample each
+             "3d_cfg3_128", "3d_cfg3_128_multivoxel", "3d_cfg5_160"]
 
 
 def _parity_log(line):
@@ -229,6 +232,10 @@ def test_teacher_forced_step_at_realistic_size(case):
         _parity_log("%-24s field diff vs reference %.3e (normalised units) -> jitter level %d (%g)" % (case, fdiff, lvl, levels[lvl]))
     data = smooth_data(N, 1, dims, seed).to(DEV)
     model = make_model(sd, device=DEV)
+    # (round 6: a case may carry the anatomy regulariser -- adv_compose_solver.py:329-338; the fixture's run took no random
+    # re-initialisation and no extra step: both volume checks pass, oracle/make_golden.py g6l_large)
+    train_kw = dict(meta.get("train") or {})
+    anatomy = anatomy_blob(N, dims).to(DEV) if meta.get("has_anatomy") else None
     # ---- the ascent step through the product's own loop, gradients captured before the update
     init_output = solver.get_init_output(model, data)
     assert compare_sampled(fx, "init_output", init_output, 0) < 2e-5
@@ -246,10 +253,12 @@ def test_teacher_forced_step_at_realistic_size(case):
         t.optimize_parameters = wrap()
     ops._CHAIN_HINTS.clear()
     with contextlib.redirect_stdout(io.StringIO()):
-        _run_one_step(solver, model, data, init_output, [1] * len(chain), None, {})
+        _run_one_step(solver, model, data, init_output, [1] * len(chain), anatomy, train_kw)
     for t in chain:
         t.optimize_parameters = t._orig_opt
     d0 = float(fx.arr("loss_trace")[0])
+    if anatomy is not None:     # [init check, the step's regulariser, end-of-loop check]
+        d0 += train_kw.get("anatomy_reg_weight", 50) * float(fx.arr("anatomy_trace")[1])
     assert abs(float(solver.last_inner_dist) - d0) < 1e-7 + TOL * abs(d0), (float(solver.last_inner_dist), d0)
     for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
         gkey = "grad_%d" % ti
@@ -340,7 +349,8 @@ def test_teacher_forced_step_at_realistic_size(case):
     refused0 = ops.FUSE_STATS["refused"]
     try:
         with contextlib.redirect_stdout(io.StringIO()):
-            loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=True, step_sizes=1)
+            loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=True, step_sizes=1,
+                                               **(dict(train_kw, anatomy_mask_images=anatomy) if anatomy is not None else {}))
     finally:
         ops.COUNT_FUSED = False
     if case == "2d_full_256_n8":
