@@ -61,11 +61,18 @@ PROTOTYPES = {
     "advchain_norm_workspace": (_L, [_L, _L]),
     "advchain_norm_axpy": (_I, [_P, _P, _P, _P, _F, _L, _L, _P]),
     "advchain_norm_axpy_gated": (_I, [_P, _P, _P, _P, _F, _L, _L, _P, _P, _P]),
+    "advchain_update_multi": (_I, [_P, _I, _P, _P]),
     "advchain_consistency_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
     "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
     "advchain_consistency_fused_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
     "advchain_consistency_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
 }
+
+class UpdateDesc(ctypes.Structure):
+    """advchain_update_desc of include/advchain_hip.h."""
+    _fields_ = [("base", c_void_p), ("x", c_void_p), ("out", c_void_p), ("old", c_void_p), ("N", c_int64), ("M", c_int64),
+                ("kind", ctypes.c_int32), ("step", c_float)]
+
 
 _lib = None
 

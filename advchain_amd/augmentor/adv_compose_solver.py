@@ -658,8 +658,10 @@ class ComposeAdversarialTransformSolver(object):
                     self._backward_to_transforms(dist, optimize_flags)
                     i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
                     #           is stepped with step_sizes[0]; kept for result parity
+                    if device_guard and self._fused_update(flagged, step_sizes):
+                        flagged = []          # (one launch stepped every transform: nothing left for the loop below)
                     for flag, transform in zip(optimize_flags, self.chain_of_transforms):
-                        if flag:
+                        if flag and flagged:
                             if self.debug:
                                 print('update {} parameters'.format(transform.get_name()))
                             try:
@@ -710,6 +712,35 @@ class ComposeAdversarialTransformSolver(object):
                     stop_flag = True
         ops.HINT_SLOT = 0       # (a later user-level forward() keys its kernel-selection hints to "no ascent step")
         return transforms
+
+    def _fused_update(self, flagged, step_sizes):
+        """The updates of one ascent step as ONE launch (ops.update_multi) when every transform is a built-in one stepping with
+        its own built-in method: the per-transform optimize_parameters() calls of adv_compose_solver.py:349-364 with the same
+        formulas (adv_noise.py:51-64, adv_bias.py:139-148, adv_morph.py:501-516, adv_affine.py:182-198), the device-side NaN
+        gate included.  Anything else -- a subclass, a method replaced on the instance, a missing gradient (the reference
+        logs a warning there), more than 8 transforms -- returns False and the loop steps them one by one."""
+        if not ops.FUSED_UPDATE or not flagged or len(flagged) > 8 or self.debug:
+            return False
+        try:
+            step = float(step_sizes[0])
+        except Exception:
+            return False
+        items = []
+        for t in flagged:
+            if type(t) not in _NATIVE or 'optimize_parameters' in vars(t):
+                return False
+            p = t.param
+            g = p.grad if isinstance(p, torch.Tensor) else None
+            if not (isinstance(g, torch.Tensor) and g.is_cuda and g.dtype == torch.float32 and g.shape == p.shape):
+                return False
+            items.append((None if t.power_iteration else p, g, 1.0 if t.power_iteration else step,
+                          1 if isinstance(t, AdvAffine) else 0, p))
+        outs = ops.update_multi(items, gate=flagged[0]._gate)
+        for t, o in zip(flagged, outs):
+            t.param = o
+            if isinstance(t, AdvMorph):
+                t._field_cache = {}
+        return True
 
     def _backward_to_transforms(self, dist, optimize_flags):
         """``dist.backward()`` of adv_compose_solver.py:348, restricted to the transform parameters: the reference

@@ -1270,9 +1270,106 @@ k_norm_axpy_row(const float* __restrict__ base, const float* __restrict__ x, flo
   for (int64_t i = threadIdx.x; i < M; i += kBlock) out[off + i] = (base ? base[off + i] : 0.f) + inv * x[off + i];
 }
 
+// ---- the parameter updates of ONE ascent step in ONE launch (round 6: launch consolidation) ------------------------------
+// An ascent step ends with one update per transform (adv_compose_solver.py:349-364 -> the optimize_parameters of
+// adv_noise.py:51-64, adv_bias.py:139-148, adv_morph.py:501-516, adv_affine.py:182-198): a unit-normalised step for noise /
+// bias / morph, a sign step for affine -- five launches of 5-10 us at cfg-2 (two for the 65536-element noise rows), each
+// behind a launch boundary.  Here a workgroup takes one (transform, sample) row: 1024 threads square-sum the row (16 bytes
+// per lane where the row allows), reduce through the waves, and write base + step * x / (||x|| + 1e-20) (or the sign
+// step); the gate is the one of k_norm_axpy.  Same formula as the separate kernels; the order of the square sum differs
+// (one workgroup per row at every size), i.e. the result agrees with theirs to rounding, not bit for bit.
+struct UpdDesc {
+  const float* base;
+  const float* x;
+  float* out;
+  const float* old;
+  long long M;
+  int rows, kind, block0;
+  float step;
+};
+constexpr int kUpdMax = 8;
+struct UpdPack {
+  UpdDesc d[kUpdMax];
+  int n;
+};
+
+__global__ void __launch_bounds__(1024) k_update_multi(UpdPack p, const float* __restrict__ gate) {
+  __shared__ float wsum[16];
+  __shared__ float inv_s;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kUpdMax; ++k)
+    if (k < p.n && (int)blockIdx.x >= p.d[k].block0) i = k;
+  const UpdDesc u = p.d[i];
+  const long long off = (long long)((int)blockIdx.x - u.block0) * u.M;
+  const float* __restrict__ x = u.x + off;
+  const float* __restrict__ base = u.base ? u.base + off : nullptr;
+  float* __restrict__ out = u.out + off;
+  const int tid = threadIdx.x;
+  if (gate && !(fabsf(gate[0]) <= 3.0e38f)) {      // the NaN guard of the step: the old parameters stay
+    for (long long j = tid; j < u.M; j += 1024) out[j] = u.old[off + j];
+    return;
+  }
+  if (u.kind == 1) {                                // sign step
+    for (long long j = tid; j < u.M; j += 1024) {
+      const float v = x[j];
+      const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);
+      out[j] = (base ? base[j] : 0.f) + u.step * sg;
+    }
+    return;
+  }
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0 &&
+                  (u.M & 3) == 0;
+  float s = 0.f;
+  if (al) {
+    const long long M4 = u.M >> 2;
+    for (long long j = tid; j < M4; j += 1024) {
+      const float4 q = reinterpret_cast<const float4*>(x)[j];
+      s += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+    }
+  } else {
+    for (long long j = tid; j < u.M; j += 1024) { const float q = x[j]; s += q * q; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    inv_s = u.step / (sqrtf(t) + 1e-20f);
+  }
+  __syncthreads();
+  const float inv = inv_s;
+  if (al) {
+    const long long M4 = u.M >> 2;
+    for (long long j = tid; j < M4; j += 1024) {
+      const float4 q = reinterpret_cast<const float4*>(x)[j];
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (base) b = reinterpret_cast<const float4*>(base)[j];
+      reinterpret_cast<float4*>(out)[j] = make_float4(b.x + inv * q.x, b.y + inv * q.y, b.z + inv * q.z, b.w + inv * q.w);
+    }
+  } else {
+    for (long long j = tid; j < u.M; j += 1024) out[j] = (base ? base[j] : 0.f) + inv * x[j];
+  }
+}
+
 }  // namespace advchain
 
 using namespace advchain;
+
+// (the descriptor of include/advchain_hip.h; this translation unit does not include the public header)
+struct advchain_update_desc {
+  const float* base;
+  const float* x;
+  float* out;
+  const float* old;
+  int64_t N;
+  int64_t M;
+  int32_t kind;
+  float step;
+};
 
 static inline bool fdims_ok(int ndim, const int64_t* s) {
   if (ndim != 2 && ndim != 3) return false;
@@ -1751,6 +1848,27 @@ int advchain_norm_axpy_gated(const float* base, const float* x, float* out, floa
 int advchain_norm_axpy(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
                        int64_t M, void* stream) {
   return advchain_norm_axpy_gated(base, x, out, workspace, step, N, M, nullptr, nullptr, stream);
+}
+
+int advchain_update_multi(const advchain_update_desc* descs, int n, const float* gate, void* stream) {
+  ADVCHAIN_CHECK_ARG(descs && n >= 1 && n <= kUpdMax, "update_multi: 1..8 descriptors");
+  UpdPack p;
+  p.n = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const advchain_update_desc& d = descs[i];
+    ADVCHAIN_CHECK_ARG(d.x && d.out && (!gate || d.old), "update_multi: null pointer");
+    ADVCHAIN_CHECK_ARG(d.N >= 0 && d.N < 65536 && d.M >= 0 && (d.kind == 0 || d.kind == 1), "update_multi: bad N / M / kind");
+    if (d.N == 0 || d.M == 0) continue;
+    UpdDesc& u = p.d[p.n++];
+    u.base = d.base; u.x = d.x; u.out = d.out; u.old = d.old;
+    u.M = d.M; u.rows = (int)d.N; u.kind = d.kind; u.block0 = blocks; u.step = d.step;
+    blocks += (int)d.N;
+  }
+  if (blocks == 0) return ADVCHAIN_OK;
+  hipLaunchKernelGGL(k_update_multi, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, p, gate);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
 }
 
 }  // extern "C"

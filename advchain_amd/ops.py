@@ -567,6 +567,36 @@ def normalized_axpy(base, x, step=1.0, gate=None, old=None):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
+FUSED_UPDATE = True   # the parameter updates of an ascent step as ONE launch (advchain_update_multi); False: one per transform (A/B tests)
+
+
+@_on_tensor_device
+def update_multi(items, gate=None):
+    """The parameter updates of one ascent step in one launch.  items: [(base or None, x, step, kind, old)] with kind 0 =
+    base + step * x / (||x||_2 per sample + 1e-20), kind 1 = base + step * sign(x); `gate` (a device scalar): a non-finite gate
+    keeps `old`.  Returns the new tensors (no autograd: parameter updates)."""
+    lib = _lib.load()
+    descs = (_lib.UpdateDesc * len(items))()
+    outs, keep = [], []
+    g = None if gate is None else _dev(gate.detach().reshape(1), "gate")
+    for d, (base, x, step, kind, old) in zip(descs, items):
+        x = _dev(x.detach(), "x")
+        base = None if base is None else _dev(base.detach(), "base")
+        old = None if old is None else _dev(old.detach(), "old")
+        if g is not None and (old is None or old.shape != x.shape):
+            raise RuntimeError("gated update: `old` must have the shape of the result")
+        if base is not None and base.shape != x.shape:
+            raise RuntimeError("update_multi: base and x differ in shape")
+        out = torch.empty_like(x)
+        N = x.shape[0]
+        d.base, d.x, d.out, d.old = _ptr(base), _ptr(x), _ptr(out), _ptr(old)
+        d.N, d.M, d.kind, d.step = N, x.numel() // max(N, 1), int(kind), float(step)
+        outs.append(out)
+        keep.extend((x, base, old))
+    _lib.check(lib.advchain_update_multi(ctypes.byref(descs), len(items), _ptr(g), _stream()), "update_multi")
+    return outs
+
+
 class _Readback:
     """A few device floats copied to pinned host memory right where they are produced, with an event recorded behind
     the copy.  `values()` waits on THAT event only: by the time the backward asks, the copy finished long ago, so the

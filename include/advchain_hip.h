@@ -357,6 +357,25 @@ int advchain_norm_axpy(const float* base, const float* x, float* out, float* wor
 /* the same with the NaN gate of advchain_sign_axpy */
 int advchain_norm_axpy_gated(const float* base, const float* x, float* out, float* workspace, float step, int64_t N,
                              int64_t M, const float* gate, const float* old, void* stream);
+/* The parameter updates of ONE ascent step in ONE launch (round 6).
+ * replaces: the per-transform optimize_parameters() calls at the end of a step (adv_compose_solver.py:349-364 ->
+ *           adv_noise.py:51-64, adv_bias.py:139-148, adv_morph.py:501-516: param + step * unit_normalize(grad);
+ *           adv_affine.py:182-198: param + step * sign(grad)) and the NaN guard of adv_compose_solver.py:343-347 -- what
+ *           advchain_norm_axpy_gated / advchain_sign_axpy do one transform at a time.  descs: n <= 8 HOST descriptors;
+ *           kind 0: out[r] = (base ? base[r] : 0) + step * x[r] / (||x[r]||_2 + 1e-20) per row r of M values; kind 1: the sign
+ *           step.  gate (may be NULL): a device scalar; when it is NaN / inf every `out` receives `old` (required then).
+ *           One workgroup per row: same formula as the separate entries, square sums in a different order (rounding).   */
+typedef struct advchain_update_desc {
+  const float* base;
+  const float* x;
+  float* out;
+  const float* old;
+  int64_t N;
+  int64_t M;
+  int32_t kind;
+  float step;
+} advchain_update_desc;
+int advchain_update_multi(const advchain_update_desc* descs, int n, const float* gate, void* stream);
 
 /* ---- consistency loss ------------------------------------------------------------------
  * replaces: calc_segmentation_consistency / contour_loss / kl_divergence, advchain/common/loss.py:8-87,102-220,223-249

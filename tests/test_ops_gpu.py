@@ -1445,3 +1445,66 @@ def test_out_of_range_corners_do_not_read_the_image(dims):
     fin = torch.isfinite(r)
     assert torch.equal(torch.isfinite(o), fin)
     assert maxdiff(o[fin], r[fin]) < TOL
+
+
+def test_update_multi_matches_the_per_transform_updates():
+    """advchain_update_multi (round 6): the parameter updates of one ascent step in ONE launch -- noise / bias / morph rows of
+    65536 / 16 / 512 / odd lengths through the unit-normalised step, affine through the sign step -- against the entries that
+    step one transform at a time (advchain_norm_axpy_gated, advchain_sign_axpy: adv_noise.py:51-64, adv_bias.py:139-148,
+    adv_morph.py:501-516, adv_affine.py:182-198).  Same formula, another summation order: 2e-6 of scale.  A NaN / inf gate
+    keeps the old parameters of EVERY transform (adv_compose_solver.py:343-347); power iteration = no base."""
+    ops = _ops()
+    shapes = [((5, 1, 256, 256), 0), ((5, 1, 4, 4), 0), ((5, 2, 16, 16), 0), ((5, 3, 7, 11, 5), 0), ((5, 5), 1), ((3, 9), 1)]
+    params = [rand(sh, 300 + i).to(DEV) for i, (sh, _) in enumerate(shapes)]
+    grads = [(rand(sh, 320 + i) * (10.0 ** (i - 2))).to(DEV) for i, (sh, _) in enumerate(shapes)]
+    grads[4][0, 2] = 0.0                                     # sign(0) = 0
+    for power in (False, True):
+        for gate_val in (None, 0.37, float("nan"), float("inf")):
+            gate = None if gate_val is None else torch.tensor(gate_val, device=DEV)
+            items = [(None if power else p, g, 1.0 if power else 0.7, kind, p) for p, g, (_, kind) in zip(params, grads, shapes)]
+            outs = ops.update_multi(items, gate=gate)
+            for p, g, (sh, kind), o in zip(params, grads, shapes, outs):
+                if kind == 0:
+                    ref = ops.normalized_axpy(None if power else p, g, 1.0 if power else 0.7, gate=gate, old=p)
+                else:
+                    ref = ops.sign_axpy(None if power else p, g, 1.0 if power else 0.7, gate=gate, old=p)
+                assert o.shape == p.shape
+                if gate_val is not None and not np.isfinite(gate_val):
+                    assert torch.equal(o, p) and torch.equal(ref, p)
+                else:
+                    assert maxdiff(o.cpu(), ref.cpu()) <= 2e-6 * max(1.0, float(ref.abs().max())), (sh, power, gate_val)
+    # a zero gradient row: x / (0 + 1e-20) * step = 0 (no NaN), as the separate entry
+    (o,) = ops.update_multi([(torch.ones(2, 1, 2, 2, device=DEV), torch.zeros(2, 1, 2, 2, device=DEV), 0.5, 0, None)])
+    assert torch.equal(o, torch.ones_like(o))
+    with pytest.raises(Exception):
+        ops.update_multi([(None, rand((2, 4), 1), 1.0, 0, None)])      # CPU tensor: no CPU path
+
+
+def test_solver_step_with_the_fused_update_matches_the_per_transform_updates():
+    """A whole ascent call with ops.FUSED_UPDATE on / off: parameters and adversarial data agree to rounding."""
+    import bench
+    import contextlib
+    import io
+    ops = _ops()
+    wl = dict(bench.WORKLOADS["cfg1"], batch=3, n_iter=2)
+    res = {}
+    for fused in (True, False):
+        ops.FUSED_UPDATE = fused
+        try:
+            solver = bench.build_solver(wl, DEV, None, hip_graph=False)
+            torch.manual_seed(11)
+            data = torch.rand(3, 1, *wl["dims"], device=DEV)
+            model = bench.make_model(2).to(DEV)
+            torch.manual_seed(12)
+            lib = __import__("advchain_amd._lib", fromlist=["load"]).load()
+            lib.records = []
+            with lib.timed(["advchain_update_multi", "advchain_norm_axpy_gated", "advchain_sign_axpy"]), contextlib.redirect_stdout(io.StringIO()):
+                loss = solver.adversarial_training(data=data, model=model, n_iter=2, step_sizes=1, power_iteration=False)
+            names = [r[0] for r in lib.records]
+            res[fused] = ([loss.detach().clone(), solver.adv_data.clone()] + [t.param.detach().clone() for t in solver.chain_of_transforms], names)
+        finally:
+            ops.FUSED_UPDATE = True
+    assert res[True][1].count("advchain_update_multi") == 2 and "advchain_sign_axpy" not in res[True][1], res[True][1]
+    assert "advchain_update_multi" not in res[False][1] and res[False][1].count("advchain_sign_axpy") == 2, res[False][1]
+    for a, b in zip(res[True][0], res[False][0]):
+        assert maxdiff(a.cpu(), b.cpu()) <= 2e-5 * max(1.0, float(b.abs().max()))
