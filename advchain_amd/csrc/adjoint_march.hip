@@ -524,9 +524,11 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
                          Dims d, int32_t* ws, hipStream_t st) {
   using G = MarchCfg<C, SELF, GG, NW, RPW, WIDE>;
   auto kern = k_adjoint_march<C, SELF, GG, MODE, NW, RPW, WIDE>;
+  // occupancy experiment (round 6, profiles/r06/f1_3d/): see launch_fwd_march (sample_march.hip)
+  static const size_t lds_pad = getenv("ADVCHAIN_MARCH_LDS_PAD") ? (size_t)atoi(getenv("ADVCHAIN_MARCH_LDS_PAD")) * 1024 : 0;
   static bool attr_set = false;
-  if (G::LDS > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  if (G::LDS + lds_pad > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS + lds_pad));
     attr_set = true;
   }
   static const int dbg = (getenv("ADVCHAIN_MARCH_DEBUG") ? atoi(getenv("ADVCHAIN_MARCH_DEBUG")) : 0) |
@@ -535,7 +537,7 @@ static void launch_march(const float* gout, const float* in, const float* grid, 
   const int nseg = (WIDE || d.s2 <= 64) ? 1 : (d.s2 + kSegOwn - 1) / kSegOwn;
   const int zc = march_zc(d, N * nseg, G::TY);
   const int n0 = (d.s0 + zc - 1) / zc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, gout, in, grid, gin, ggrid, d,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS + lds_pad, st, gout, in, grid, gin, ggrid, d,
                      n1, zc, dbg, SELF ? ws : (int32_t*)nullptr, nseg);
 }
 

@@ -519,9 +519,12 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
                              int final_mode, float* disp_out, hipStream_t st) {
   using G = FwdMarchCfg<C, SELF, NW, RPW>;
   auto kern = k_sample_march<C, SELF, MODE, NW, RPW>;
+  // occupancy experiment (round 6, profiles/r06/f1_3d/): ADVCHAIN_MARCH_LDS_PAD = extra dynamic LDS in KiB that nobody touches --
+  // the kernel then runs with the workgroups-per-CU a fused two-level kernel's LDS footprint would leave it (results unchanged)
+  static const size_t lds_pad = getenv("ADVCHAIN_MARCH_LDS_PAD") ? (size_t)atoi(getenv("ADVCHAIN_MARCH_LDS_PAD")) * 1024 : 0;
   static bool attr_set = false;
-  if (G::LDS > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  if (G::LDS + lds_pad > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS + lds_pad));
     attr_set = true;
   }
   const int n1 = (d.s1 + G::TY - 1) / G::TY;
@@ -529,7 +532,7 @@ static void launch_fwd_march(const float* in, const float* grid, float* out, con
   const int zc = fwd_march_zc(d, N * nseg, G::TY, C);
   const int n0 = (d.s0 + zc - 1) / zc;
   static const bool no_xcd = false;   // measured optimum (was a tuning knob until round 4)
-  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS, st, in, grid, out, phi0, d, n1, zc,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nseg * n1 * n0), (unsigned)N), dim3(G::NT), G::LDS + lds_pad, st, in, grid, out, phi0, d, n1, zc,
                      final_mode, disp_out, no_xcd ? -nseg : nseg);
 }
 

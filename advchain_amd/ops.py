@@ -567,7 +567,7 @@ def normalized_axpy(base, x, step=1.0, gate=None, old=None):
 # ------------------------------------------------------------------------------------------------
 # autograd Functions
 # ------------------------------------------------------------------------------------------------
-FUSED_UPDATE = True   # the parameter updates of an ascent step as ONE launch (advchain_update_multi); False: one per transform (A/B tests)
+FUSED_UPDATE = os.environ.get("ADVCHAIN_FUSED_UPDATE_OFF") is None   # the parameter updates of an ascent step as ONE launch (advchain_update_multi); False: one per transform (A/B)
 
 
 @_on_tensor_device
