@@ -518,16 +518,28 @@ __global__ void __launch_bounds__(kBlock) k_max_displacement(const float* __rest
   }
 }
 
-// out[r] = max_j slots[r][j]  (NaN propagates, as torch.max does): one workgroup per row of displacement slots
-__global__ void __launch_bounds__(kBlock) k_slot_rows_max(float* __restrict__ slots, float* __restrict__ out, int cols, int reset) {
+// out[r] = max_j slots[r][j]  (NaN propagates, as torch.max does): one workgroup per row of displacement slots.
+// NT threads, VEC floats per request: a row of 4096 slots is ONE 16-byte request per thread of a 1024-thread workgroup (round 6;
+// 256 threads walking 16 dependent 4-byte trips took 9 us a launch, six launches per cfg-2 call)
+template <int NT, int VEC>
+__global__ void __launch_bounds__(NT) k_slot_rows_max(float* __restrict__ slots, float* __restrict__ out, int cols, int reset) {
   float* p = slots + (int64_t)blockIdx.x * cols;
   float m = -3.4e38f;
   bool nan = false;
-  for (int j = threadIdx.x; j < cols; j += kBlock) {
-    const float v = p[j];
-    nan = nan || !(v == v);
-    m = fmaxf(m, v);
-    if (reset) p[j] = 0.f;      // the accumulator is the caller's persistent buffer: ready for the next chain
+  if (VEC == 4) {
+    for (int j = threadIdx.x * 4; j < cols; j += NT * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + j);
+      nan = nan || !(v.x == v.x) || !(v.y == v.y) || !(v.z == v.z) || !(v.w == v.w);
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      if (reset) *reinterpret_cast<float4*>(p + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int j = threadIdx.x; j < cols; j += NT) {
+      const float v = p[j];
+      nan = nan || !(v == v);
+      m = fmaxf(m, v);
+      if (reset) p[j] = 0.f;      // the accumulator is the caller's persistent buffer: ready for the next chain
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -535,12 +547,12 @@ __global__ void __launch_bounds__(kBlock) k_slot_rows_max(float* __restrict__ sl
     const int other = __shfl_xor((int)nan, o, 64);   // not inside `nan || ...`: a lane that short-circuits leaves the shuffle
     nan = nan || other != 0;
   }
-  __shared__ float sm[kBlock / 64];
-  __shared__ int sn[kBlock / 64];
+  __shared__ float sm[NT / 64];
+  __shared__ int sn[NT / 64];
   if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sn[threadIdx.x >> 6] = nan; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < kBlock / 64; ++w) { m = fmaxf(m, sm[w]); nan = nan || sn[w]; }
+    for (int w = 1; w < NT / 64; ++w) { m = fmaxf(m, sm[w]); nan = nan || sn[w]; }
     out[blockIdx.x] = nan ? __int_as_float(0x7fc00000) : m;
   }
 }
@@ -701,7 +713,10 @@ extern "C" int advchain_slot_rows_max(float* slots, float* out, int64_t rows, in
   ADVCHAIN_CHECK_ARG(slots && out, "slot_rows_max: null pointer");
   ADVCHAIN_CHECK_ARG(rows >= 0 && rows < 65536 && cols >= 1 && cols < (1ll << 31), "slot_rows_max: bad shape");
   if (rows == 0) return ADVCHAIN_OK;
-  hipLaunchKernelGGL(k_slot_rows_max, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols, reset);
+  if ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(slots) & 15) == 0 && cols >= 2048)
+    hipLaunchKernelGGL((k_slot_rows_max<1024, 4>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, slots, out, (int)cols, reset);
+  else
+    hipLaunchKernelGGL((k_slot_rows_max<kBlock, 1>), dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, slots, out, (int)cols, reset);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

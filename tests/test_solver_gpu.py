@@ -320,6 +320,8 @@ def test_teacher_forced_step_at_realistic_size(case):
     # ---- later steps, teacher-forced: inject the REFERENCE's theta_k (stored in full), compare dist_k, gradients, theta_k+1
     for k in range(1, n_iter):
         prev = "" if k == 1 else "_s%d" % (k - 1)
+        if not all("param_out_%d%s__full" % (ti, prev) in fx for ti in range(len(chain))):
+            break       # (a parameter too large to be stored in full -- the 256 x 256 noise: the free-running comparison below is the test)
         for ti, t in enumerate(chain):
             t.eval()
             t.param = fx.t("param_out_%d%s__full" % (ti, prev), DEV)
