@@ -31,6 +31,7 @@ PROTOTYPES = {
     "advchain_affine_theta_fwd": (_I, [_P, _P, _F, _P, _P, _L, _I, _P]),
     "advchain_affine_theta_bwd": (_I, [_P, _P, _F, _P, _P, _P, _L, _I, _P]),
     "advchain_tp_interp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _F, _P, _P, _P]),
+    "advchain_tp_interp_fwd_smoothed_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _F, _P, _P, _F, _P]),
     "advchain_band_reduce_axis": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _F, _P]),
     "advchain_band_reduce_rows_dense": (_I, [_P, _P, _P, _P, _P, _L, _L, _L, _L, _F, _P]),
     "advchain_bias_field_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _F, _I, _F, _P]),

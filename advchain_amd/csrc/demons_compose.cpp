@@ -42,11 +42,16 @@ int advchain_demons_compose_pair_fwd(const float* vel, float* s1, float* phi0, f
   const int64_t* Sd = S3 + 1;
   // nothing is enqueued unless every launch below takes the shape (the caller then issues the separate calls)
   if (prod(ndim, gd) > 4096 || !advchain_gauss_xy_takes(ndim, Sd, 2 * N * ndim) || !aligned16(pos, q)) return -2;
-  int rc = advchain_gauss_small_pair(vel, s1, N * ndim, ndim, gd, weights9_host, scale, 0, stream);
+  // smoothing + upsampling: one launch where the low-resolution plane fits the fused kernel (round 6), else the two calls
+  int rc = advchain_tp_interp_fwd_smoothed_pair(vel, s1, phi0, itab, ftab, S3, g3, B3, N * ndim, ndim, 1, inv, disp, weights9_host,
+                                                scale, stream);
+  if (rc == -2) {
+    rc = advchain_gauss_small_pair(vel, s1, N * ndim, ndim, gd, weights9_host, scale, 0, stream);
+    if (rc != 0) return rc;
+    rc = advchain_tp_interp_fwd(s1, phi0, itab, ftab, S3, g3, B3, 2 * N * ndim, ndim, ndim, 1, inv, nullptr, disp, stream);
+  }
   if (rc != 0) return rc;
-  rc = advchain_tp_interp_fwd(s1, phi0, itab, ftab, S3, g3, B3, 2 * N * ndim, ndim, ndim, 1, inv, nullptr, disp, stream);
-  if (rc != 0) return rc;
-  const int64_t slots = 4096;    // ADVCHAIN_DISP_SLOTS
+  const int64_t slots = ADVCHAIN_DISP_SLOTS;
   rc = advchain_expo_chain_fwd(phi0, fields, pos, 2 * N, ndim, Sd, n, disp, hints, (disp && fuse) ? disp + (int64_t)(n + 1) * slots : nullptr, stream);
   if (rc != 0) return rc;
   rc = advchain_gauss_xy(pos, q, nullptr, 2 * N * ndim, ndim, ndim, Sd, weights9_host, 2, 1, 1.0f, stream, nullptr, 2 * N * ndim);

@@ -215,6 +215,66 @@ k_tp_interp_fwd(const float* __restrict__ coef, float* __restrict__ out, BandTab
   }
 }
 
+// The same with the smoothing of the low-resolution plane in front (round 6: launch consolidation): the batch [v; -v] of a
+// paired 2D field -- workgroup plane b smooths velocity plane b % P scaled by +-gscale in LDS (the arithmetic of k_gauss_small,
+// mirror 1: same taps, same order, zero padding), the workgroup of the first row chunk writes it to s1, and the rows are
+// blended from that LDS plane instead of a global one.  One launch instead of two per DemonsCompose pair (the small-plane
+// smoothing was 6 us of kernel behind a launch boundary, eleven times per cfg-2 call); every workgroup of a plane repeats the
+// 2 x 9-tap smoothing of its <= 1024 values, which is nothing next to its 32 rows of output.
+constexpr int kGsFuseMax = 1024;
+struct GaussW9 { float w[9]; };
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+k_tp_interp_fwd_gs(const float* __restrict__ vel, float* __restrict__ s1, float* __restrict__ out, BandTables T, Dims full, int C,
+                   int add_identity, float scale, float* __restrict__ disp_out, GaussW9 gw, float gscale, int P) {
+  __shared__ float lds[kTpMaxLds];
+  __shared__ float gs[2][kGsFuseMax];
+  const int plane = blockIdx.z, i0 = blockIdx.y;
+  const int i1b = blockIdx.x * kTpChunk, i1e = min(i1b + kTpChunk, full.s1);
+  const int g1 = T.a[1].g, g2 = T.a[2].g, Vg = g1 * g2;        // (2D: a trivial leading axis)
+  const int V = (int)full.voxels();
+  const int c = plane % C;
+  {
+    const float* src = vel + (int64_t)(plane % P) * Vg;
+    const float sc = plane >= P ? -gscale : gscale;
+    for (int i = threadIdx.x; i < Vg; i += kBlock) gs[0][i] = src[i] * sc;
+    __syncthreads();
+    int cur = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int Sa = pass == 0 ? g2 : g1, st = pass == 0 ? 1 : g2;      // innermost axis first, like k_gauss_small
+      for (int i = threadIdx.x; i < Vg; i += kBlock) {
+        const int ia = (i / st) % Sa;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = -4; k <= 4; ++k) {
+          const int j = ia + k;
+          if (j >= 0 && j < Sa) acc += gw.w[k + 4] * gs[cur][i + k * st];
+        }
+        gs[cur ^ 1][i] = acc;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (s1 && blockIdx.x == 0 && blockIdx.y == 0)
+      for (int i = threadIdx.x; i < Vg; i += kBlock) s1[(int64_t)plane * Vg + i] = gs[0][i];      // (two passes: back in buffer 0)
+  }
+  float dmax = 0.f;
+  const float to_vox = fabsf(scale) * 0.5f * (float)((c == 0 ? full.s2 : (c == 1 ? full.s1 : full.s0)) - 1);
+  tp_rows<VEC>(gs[0], T, full, i0, i1b, i1e, lds, [&](int i1, int x, const float (&val)[VEC]) {
+    float o[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      dmax = fmaxf(dmax, fabsf(val[q]));
+      float base = 0.f;
+      if (add_identity) base = c == 0 ? lin_coord(x + q, full.s2) : (c == 1 ? lin_coord(i1, full.s1) : lin_coord(i0, full.s0));
+      o[q] = base + scale * val[q];
+    }
+    store_vec<VEC>(out + (int64_t)plane * V + ((int64_t)i0 * full.s1 + i1) * full.s2 + x, o);
+  });
+  if (disp_out) wave_max_to_slots(fminf(dmax * to_vox, 1.0e9f), disp_out);
+}
+
 // The 3D linear upsampling (bands of 2 on every axis), ZB consecutive i0 planes per workgroup, software-pipelined (round 4).
 // One plane per workgroup meant: tables, coefficients, barrier, 10 outputs per thread, barrier -- 19200 workgroups of ~4 us for
 // a 196 MB write at cfg-5 (1.9 TB/s), and hoisting the table loads alone changed nothing (104 us either way: the chain is per
@@ -1458,6 +1518,35 @@ int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, c
   else
     hipLaunchKernelGGL(k_tp_interp_fwd<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, coef, out, T, full, (int)C,
                        add_identity, scale, sumsq, disp_out);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// advchain_gauss_small_pair (forward) + advchain_tp_interp_fwd in ONE launch: vel (P planes of g1 x g2) -> s1 (2P planes, the
+// smoothed batch [v; -v]) and out (2P planes of S1 x S2) = (add_identity ? identity : 0) + scale * up(s1).  2D, planes of at most
+// 1024 values, the 9-tap window.  ADVCHAIN_ERR_UNSUPPORTED (-2), nothing enqueued, for anything else: issue the two calls.
+int advchain_tp_interp_fwd_smoothed_pair(const float* vel, float* s1, float* out, const int32_t* itab, const float* ftab,
+                                         const int64_t* S, const int64_t* g, const int64_t* B, int64_t P, int64_t C,
+                                         int add_identity, float scale, float* disp_out, const float* weights9, float gscale,
+                                         void* stream) {
+  ADVCHAIN_CHECK_ARG(vel && out && itab && ftab && weights9, "tp_interp_fwd_smoothed_pair: null pointer");
+  ADVCHAIN_CHECK_ARG(P >= 0 && 2 * P < 65536 && C >= 1, "tp_interp_fwd_smoothed_pair: bad planes/C");
+  BandTables T;
+  ADVCHAIN_CHECK_ARG(unpack_tables(itab, ftab, S, g, B, T), "tp_interp_fwd_smoothed_pair: bad band tables");
+  static const bool off = getenv("ADVCHAIN_NO_TP_GS_FUSE") != nullptr;   // A/B knob
+  if (off || S[0] != 1 || g[0] != 1 || g[1] * g[2] > kGsFuseMax || T.a[2].g > kTpMaxLds) return ADVCHAIN_ERR_UNSUPPORTED;
+  if (P == 0) return ADVCHAIN_OK;
+  Dims full{(int)S[0], (int)S[1], (int)S[2]};
+  ADVCHAIN_CHECK_ARG(full.voxels() < (1ll << 31), "tp_interp_fwd_smoothed_pair: volume too large");
+  GaussW9 gw;
+  for (int k = 0; k < 9; ++k) gw.w[k] = weights9[k];
+  dim3 grid((unsigned)((full.s1 + kTpChunk - 1) / kTpChunk), 1u, (unsigned)(2 * P));
+  if (full.s2 % 4 == 0 && full.s2 >= 128 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+    hipLaunchKernelGGL(k_tp_interp_fwd_gs<4>, grid, dim3(kBlock), 0, (hipStream_t)stream, vel, s1, out, T, full, (int)C, add_identity,
+                       scale, disp_out, gw, gscale, (int)P);
+  else
+    hipLaunchKernelGGL(k_tp_interp_fwd_gs<1>, grid, dim3(kBlock), 0, (hipStream_t)stream, vel, s1, out, T, full, (int)C, add_identity,
+                       scale, disp_out, gw, gscale, (int)P);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -270,6 +270,18 @@ int advchain_affine_theta_bwd(const float* param, const float* cfg_host, float p
 int advchain_tp_interp_fwd(const float* coef, float* out, const int32_t* itab, const float* ftab, const int64_t* S,
                            const int64_t* g, const int64_t* B, int64_t planes, int64_t C, int ndim, int add_identity,
                            float scale, float* sumsq, float* disp_out, void* stream);
+/* advchain_gauss_small_pair (forward) + advchain_tp_interp_fwd in ONE launch (round 6) for the paired 2D field [v; -v].
+ * replaces: the first two steps of AdvMorph.DemonsCompose -- the Gaussian of the low-resolution velocity (adv_morph.py:377-452,
+ *           called at :460-462) and F.interpolate to full size (adv_morph.py:464) -- for forward() / backward() of one solver
+ *           step (adv_morph.py:299-303,322-324).  vel: (P planes of g1 x g2 values); s1 (may be NULL): (2P planes) receives the
+ *           smoothed batch [G(gscale v); G(-gscale v)]; out: (2P planes of S1 x S2) = (add_identity ? identity : 0) + scale * up(s1);
+ *           disp_out as for advchain_tp_interp_fwd.  Same arithmetic as the two calls, bit for bit.  2D tables (trivial leading
+ *           axis), low-resolution planes of at most 1024 values, the 9-tap window; ADVCHAIN_ERR_UNSUPPORTED (-2) with nothing
+ *           enqueued otherwise.                                                                                              */
+int advchain_tp_interp_fwd_smoothed_pair(const float* vel, float* s1, float* out, const int32_t* itab, const float* ftab,
+                                         const int64_t* S, const int64_t* g, const int64_t* B, int64_t P, int64_t C,
+                                         int add_identity, float scale, float* disp_out, const float* weights9, float gscale,
+                                         void* stream);
 /* adjoint along one axis: in (outer, S_axis, inner) -> out (outer, g_axis, inner),
  * out = W_axis^T ((in - in2) * scale); in2 may be NULL.
  * replaces: upsample_{bi,tri}linear backward / conv_transpose backward w.r.t. its input.        */
