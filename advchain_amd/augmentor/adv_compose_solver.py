@@ -254,7 +254,9 @@ class ComposeAdversarialTransformSolver(object):
     def _graph_key(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
         """Everything the captured launch sequence depends on besides tensor CONTENTS: shapes, the model's storage, the
         arguments of the call, every plain attribute of the solver and of its transforms."""
-        tr = tuple((type(t).__name__,) + self._plain_attrs(t) for t in self.chain_of_transforms)
+        # (the OBJECTS as well: a replay hands its results to the transforms it captured -- a chain rebuilt from the same
+        # configuration is a new signature, ADVICE r5)
+        tr = tuple((type(t).__name__, id(t)) + self._plain_attrs(t) for t in self.chain_of_transforms)
         mod = (id(model), model.training) + tuple(p.data_ptr() for p in model.parameters()) \
             + tuple(b.data_ptr() for b in model.buffers())
         mine = self._plain_attrs(self, skip=('graph_stats',))
@@ -305,6 +307,18 @@ class ComposeAdversarialTransformSolver(object):
             return io
 
         self._redo_ascent = lambda: ordinary(True)
+        if self.process_group is not None:
+            # the record / capture / replay state is kept per rank (keyed by its local shapes and pointers): a rank that meets
+            # a new key (an uneven last shard, a rebuilt chain) while the others replay would issue n_iter per-step all-reduces
+            # against their one per call -- a collective mismatch.  One all-reduce per call tells every rank
+            # whether all of them are in the same state; if not, all of them run this call the ordinary way (their per-step
+            # collectives pair up), each recording where its own state still records
+            order = {"record": 0.0, "off": 1.0, "capture": 2.0, "replay": 3.0}
+            mine = order[rec["state"]]
+            both = self._all_reduce_(torch.tensor([mine, -mine], device=data.device), "min").tolist()
+            if both[0] != -both[1]:
+                self.graph_stats["deferred"] = self.graph_stats.get("deferred", 0) + 1
+                return ordinary(rec["state"] == "record"), None
         if rec["state"] == "record":
             return ordinary(True), None
         if rec["state"] == "off":

@@ -51,11 +51,18 @@ int advchain_demons_compose_pair_fwd(const float* vel, float* s1, float* phi0, f
     rc = advchain_tp_interp_fwd(s1, phi0, itab, ftab, S3, g3, B3, 2 * N * ndim, ndim, ndim, 1, inv, nullptr, disp, stream);
   }
   if (rc != 0) return rc;
+  // from here on launches are queued: a -2 of an inner entry can no longer mean "nothing was enqueued"  -- the
+  // pre-check above is what promises the shapes; if the two ever drift apart the caller must not re-issue the chain on a
+  // displacement accumulator that already holds this call's partial state
+  auto late = [](int r, const char* what) {
+    if (r == -2) { advchain_set_error_(what); return ADVCHAIN_ERR_ARG; }
+    return r;
+  };
   const int64_t slots = ADVCHAIN_DISP_SLOTS;
   rc = advchain_expo_chain_fwd(phi0, fields, pos, 2 * N, ndim, Sd, n, disp, hints, (disp && fuse) ? disp + (int64_t)(n + 1) * slots : nullptr, stream);
-  if (rc != 0) return rc;
+  if (rc != 0) return late(rc, "demons_compose_pair_fwd: the chain refused a shape the pre-check had accepted (launches already queued)");
   rc = advchain_gauss_xy(pos, q, nullptr, 2 * N * ndim, ndim, ndim, Sd, weights9_host, 2, 1, 1.0f, stream, nullptr, 2 * N * ndim);
-  if (rc != 0) return rc;
+  if (rc != 0) return late(rc, "demons_compose_pair_fwd: the final smoothing refused a shape the pre-check had accepted (launches already queued)");
   if (disp && rows_max) rc = advchain_slot_rows_max(disp, rows_max, n + 2, slots, 1, stream);
   return rc;
 }
@@ -81,6 +88,10 @@ int advchain_demons_compose_pair_bwd(const float* gq_lo, const float* gq_hi, con
   int rc = advchain_gauss_xy(gq_lo, gpos, pos, planes, ndim, ndim, Sd, weights9_host, 0, 2, 1.0f, stream, gq_hi, N * ndim);
   if (rc != 0) return rc;
   rc = advchain_expo_chain_bwd(gpos, phi0, fields, g, scratch, ws, halos, 2 * N, ndim, Sd, n, stream);
+  if (rc == -2) {      // (launches are queued: see the forward entry)
+    advchain_set_error_("demons_compose_pair_bwd: the chain refused a shape the pre-check had accepted (launches already queued)");
+    return ADVCHAIN_ERR_ARG;
+  }
   if (rc != 0) return rc;
   // W^T along x (innermost; densified bands where that kernel takes the shape) with the fused (g - gpos) * inv, then along y
   rc = advchain_band_reduce_rows_dense(g, gpos, t1, wd, wlo, planes * S3[1], S3[2], g3[2], WB, inv, stream);

@@ -118,8 +118,9 @@ def test_two_ranks_replaying_their_graphs_match_the_whole_batch():
     for p in parts:
         st = p["stats"]
         assert st["captures"] == 1 and st["replays"] >= 2 and st["violations"] == 0 and st["refused"] == 0, st
-        # per replayed call: the global batch size, the check vector, the final pass's loss -- not one per ascent step
-        assert p["collectives"] == 3, p["collectives"]
+        # per replayed call: the global batch size, the agreement on the replay state (round 6), the check vector, the final
+        # pass's loss -- not one per ascent step
+        assert p["collectives"] == 4, p["collectives"]
         assert abs(p["last_inner"] - ref_inner) < 1e-7 + 2e-5 * abs(ref_inner)      # the whole-batch value of the last step
     check_parts(parts, ref, 2e-5, 5e-5, 1e-4)
 
