@@ -739,7 +739,7 @@ class ComposeAdversarialTransformSolver(object):
             step = float(step_sizes[0])
         except Exception:
             return False
-        items = []
+        items, fused, alone = [], [], []
         for t in flagged:
             if type(t) not in _NATIVE or 'optimize_parameters' in vars(t):
                 return False
@@ -747,14 +747,26 @@ class ComposeAdversarialTransformSolver(object):
             g = p.grad if isinstance(p, torch.Tensor) else None
             if not (isinstance(g, torch.Tensor) and g.is_cuda and g.dtype == torch.float32 and g.shape == p.shape):
                 return False
+            # one workgroup per (transform, sample) row: a 3D noise row (a million values) belongs to the two-launch form,
+            # whose workgroups share a row
+            if not isinstance(t, AdvAffine) and g.numel() // max(1, g.shape[0]) > self._FUSED_UPDATE_ROW_MAX:
+                alone.append(t)
+                continue
+            fused.append(t)
             items.append((None if t.power_iteration else p, g, 1.0 if t.power_iteration else step,
                           1 if isinstance(t, AdvAffine) else 0, p))
+        if not items:
+            return False
         outs = ops.update_multi(items, gate=flagged[0]._gate)
-        for t, o in zip(flagged, outs):
+        for t, o in zip(fused, outs):
             t.param = o
             if isinstance(t, AdvMorph):
                 t._field_cache = {}
+        for t in alone:
+            t.optimize_parameters(step_size=step)
         return True
+
+    _FUSED_UPDATE_ROW_MAX = 1 << 18
 
     def _backward_to_transforms(self, dist, optimize_flags):
         """``dist.backward()`` of adv_compose_solver.py:348, restricted to the transform parameters: the reference
