@@ -676,7 +676,7 @@ k_affine_box_gin(const float* __restrict__ gout, const float* __restrict__ theta
             int* cell = cell0 + (cz * G::TY + cy) * G::TX + cx;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-              if (c < C) atomicAdd(cell + c * TILE, __float2int_rn(ws * go[u][c]));
+              if (c < C) atomicAdd(cell + c * TILE, fix_round(ws * go[u][c]));
           }
         }
     }

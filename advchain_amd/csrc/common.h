@@ -161,6 +161,24 @@ __device__ __forceinline__ float lane_prev_f(float v) {   // lane i <- lane i-1
 constexpr int kSumSlots = 64;
 __device__ __forceinline__ int sum_slot() { return (int)((blockIdx.x + blockIdx.y * 7u) % kSumSlots); }
 
+// float -> 32-bit fixed point for the LDS-integer scatters (round 6): v_cvt_rpi_i32_f32 -- floor(x + 0.5) in ONE instruction;
+// the compiler only selects it under -ffast-math -- instead of the v_rndne_f32 + v_cvt_i32_f32 pair of __float2int_rn: 8 of
+// the 134 VALU instructions of a visited row in the wide march scatter, 2 C per item in the whole-row scatter, 8 C per sample in
+// the march / window scatters.  Exact halves round up instead of to even (one unit of the fixed-point resolution, the same on
+// every run).  A/B build switch: -DADVCHAIN_FIX_RPI=0.
+#ifndef ADVCHAIN_FIX_RPI
+#define ADVCHAIN_FIX_RPI 1
+#endif
+__device__ __forceinline__ int fix_round(float x) {
+#if ADVCHAIN_FIX_RPI
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return __float2int_rn(x);
+#endif
+}
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   // hardware global_atomic_add_f32 (no CAS loop); device memory only
   unsafeAtomicAdd(p, v);

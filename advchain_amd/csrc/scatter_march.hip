@@ -378,7 +378,7 @@ k_scatter_march3d(const float* __restrict__ gout, const float* __restrict__ in, 
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx)
 #pragma unroll
-              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * TY * 64, __float2int_rn(wzy * a[c][cx]));
+              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * TY * 64, fix_round(wzy * a[c][cx]));
           }
         }
         if (own) {
@@ -654,7 +654,7 @@ k_scatter_march3d_flat(const float* __restrict__ gout, const float* __restrict__
 #pragma unroll
             for (int cx = 0; cx < 2; ++cx)
 #pragma unroll
-              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * chan_cells, __float2int_rn(wzy * a[c][cx]));
+              for (int c = 0; c < C; ++c) atomicAdd(cell + colx[cx] + c * chan_cells, fix_round(wzy * a[c][cx]));
           }
       }
     }
@@ -740,6 +740,10 @@ k_scatter_march3d_flat(const float* __restrict__ gout, const float* __restrict__
 //   * two stages and one spare plane in each ring: ONE barrier per step.
 // 16 waves own 16 rows (2.25 visits per sample at H = 4 instead of 3); 156 KiB of LDS, one workgroup a CU.
 // ---------------------------------------------------------------------------------------------------------------------
+// A/B build switch (tools/ab/build_variant.sh -DADVCHAIN_WIDE_TRIM=0): the trimmed deposit arithmetic of the wide march scatter
+#ifndef ADVCHAIN_WIDE_TRIM
+#define ADVCHAIN_WIDE_TRIM 1
+#endif
 template <int H>
 struct WideCfg {
   static constexpr int TY = 16, NWV = 16, NT = NWV * 64, XS = 68;
@@ -966,11 +970,28 @@ k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__
             const int pz = t.z.i0 + cz;
             anyz[cz] = pz >= zlo && pz < zhi;
             wzm[cz] = anyz[cz] ? t.wz(cz) : 0.f;
-            int slot = sz + min(max(pz - zp, -H), H + 1);
+          }
+#if ADVCHAIN_WIDE_TRIM
+          {
+            // the upper corner's slot is the lower one's successor in the ring (where the clamp engages the corner carries
+            // weight 0 and any slot inside the ring will do): one wrap each instead of two clamps and four selects
+            int slot = sz + min(max(t.z.i0 - zp, -H), H + 1);
+            slot += slot < 0 ? NS : 0;
+            slot -= slot >= NS ? NS : 0;
+            slotz[0] = slot * (TY * 64);
+            slot += 1;
+            slot -= slot >= NS ? NS : 0;
+            slotz[1] = slot * (TY * 64);
+          }
+#else
+#pragma unroll
+          for (int cz = 0; cz < 2; ++cz) {
+            int slot = sz + min(max(t.z.i0 + cz - zp, -H), H + 1);
             slot += slot < 0 ? NS : 0;
             slot -= slot >= NS ? NS : 0;
             slotz[cz] = slot * (TY * 64);
           }
+#endif
           const float gsc = go * scale;
           const float a0 = wxm[0] * gsc, a1 = wxm[1] * gsc;
 #pragma unroll
@@ -979,8 +1000,8 @@ k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__
             for (int cy = 0; cy < 2; ++cy) {
               const float wzy = wzm[cz] * wym[cy];
               int* cell = acc + slotz[cz] + rowy[cy];
-              atomicAdd(cell + colx[0], __float2int_rn(wzy * a0));
-              atomicAdd(cell + colx[1], __float2int_rn(wzy * a1));
+              atomicAdd(cell + colx[0], fix_round(wzy * a0));
+              atomicAdd(cell + colx[1], fix_round(wzy * a1));
             }
         }
         if (own) {
@@ -1062,6 +1083,10 @@ k_scatter_march3d_wide(const float* __restrict__ gout, const float* __restrict__
 // or stored (grad_grid).  Whole rows: the halo work is in y only, (TY+2H)/TY (the 2D tiles of scatter_tiled.hip pay it
 // on both axes and need an overflow list; the window scatter pays 1.7 global float atomics per sample and channel).
 // ---------------------------------------------------------------------------------------------------------------------
+// A/B build switch (tools/ab/build_all_variant.sh -DADVCHAIN_ROWS2D_FLAT=0): the branch-light deposits of the whole-row scatter
+#ifndef ADVCHAIN_ROWS2D_FLAT
+#define ADVCHAIN_ROWS2D_FLAT 1
+#endif
 __device__ __forceinline__ float rows2d_fix_scale(int H) {   // (2H+2)^2 deposits of weight <= 1 stay below 2^31
   return H <= 2 ? 33554432.f : (H <= 4 ? 16777216.f : (H <= 8 ? 4194304.f : (H <= 16 ? 1048576.f : 262144.f)));
 }
@@ -1111,6 +1136,10 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
   constexpr int U = 2;
   constexpr int MAXO = 8;                         // own items per wave: TY * nseg / 8, capped by the launcher
   const int oitems = (yend - y0) * nseg;
+  // item -> (row, segment) through a reciprocal (exact: items < 2^12): an integer division by the run-time nseg is ~20
+  // instructions, three times per item
+  const float inv_nseg = 1.f / (float)nseg;
+  auto item_row = [&](int it) { return (int)(((float)it + 0.5f) * inv_nseg); };
   float ggv[MAXO][2];
   auto visit = [&](int ys, int xs0, bool own, float (&g)[2], const float (&go)[C], float (&gg)[2]) {
     const bool xin = xs0 < W;
@@ -1132,6 +1161,38 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
       for (int c = 0; c < C; ++c) o.load(inn + (int64_t)c * V, vl[c]);
     }
     if (any) {
+      if constexpr (ADVCHAIN_ROWS2D_FLAT && SELF) {
+      // branch-light deposits for the squarings (round 6; the 3D march scatters do the same since lesson 37 b): per-axis masked weights, and
+      // a masked corner adds its zero at the lane's OWN column of an owned row -- never two lanes on one cell -- instead of
+      // four exec-mask regions per item; 24-bit multiplies for the cell rows (a 32-bit v_mul_lo costs four VALU slots)
+      const int ownr = __mul24(min(max(ys - y0, 0), TY - 1), W), ownc = min(xs0, W - 1);
+      int rowc[2], colc[2];
+      float wxm[2], wym[2];
+#pragma unroll
+      for (int cx = 0; cx < 2; ++cx) {
+        const bool ok = xin && (cx ? t.x.v1 : t.x.v0);
+        wxm[cx] = ok ? (cx ? t.x.w1 : t.x.w0) * scale : 0.f;
+        colc[cx] = ok ? t.x.i0 + cx : ownc;
+      }
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy) {
+        const int py = t.y.i0 + cy;
+        const bool ok = py >= y0 && py < yend && (cy ? t.y.v1 : t.y.v0);
+        wym[cy] = ok ? (cy ? t.y.w1 : t.y.w0) : 0.f;
+        rowc[cy] = ok ? __mul24(py - y0, W) : ownr;
+      }
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const float wsc = wxm[cx] * wym[cy];
+          int* cell = acc + rowc[cy] + colc[cx];
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, fix_round(wsc * go[c]));
+        }
+      } else {
+      // (the image warps keep the per-corner branches: with four channels the masked form holds 89 VGPRs and measured
+      // 82 against 74 us at 12 px)
 #pragma unroll
       for (int cy = 0; cy < 2; ++cy) {
         const int py = t.y.i0 + cy;
@@ -1142,8 +1203,9 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
           const float wsc = (cx ? t.x.w1 : t.x.w0) * (cy ? t.y.w1 : t.y.w0) * scale;
           int* cell = acc + (py - y0) * W + t.x.i0 + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, __float2int_rn(wsc * go[c]));
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * TY * W, fix_round(wsc * go[c]));
         }
+      }
       }
     }
     if (own && (SELF || GG)) {
@@ -1164,7 +1226,7 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
     for (int u = 0; u < U; ++u) {
       ggv[k0 + u][0] = ggv[k0 + u][1] = 0.f;
       const int it = min(wave + (k0 + u) * NWV, max(oitems - 1, 0));
-      const int r = it / nseg;
+      const int r = item_row(it);
       ys[u] = y0 + r;
       xs[u] = (it - r * nseg) * 64 + lane;
       const int s = ys[u] * W + min(xs[u], W - 1);
@@ -1187,7 +1249,7 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int it = min(it0 + u, hitems - 1);
-      const int r = it / nseg;
+      const int r = item_row(it);
       ys[u] = r < hlo ? ya + r : yend + (r - hlo);
       xs[u] = (it - r * nseg) * 64 + lane;
       const int s = ys[u] * W + min(xs[u], W - 1);
@@ -1211,7 +1273,7 @@ k_scatter_rows2d(const float* __restrict__ gout, const float* __restrict__ in, c
   for (int k = 0; k < MAXO; ++k) {
     const int it = wave + k * NWV;
     if (it >= oitems) continue;                                       // wave-uniform
-    const int r = it / nseg;
+    const int r = item_row(it);
     const int x = (it - r * nseg) * 64 + lane;
     const bool on = x < W;
     const int s = (y0 + r) * W + min(x, W - 1);

@@ -211,7 +211,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
           const float ws = w * scale;
           int* cell = win + cell0 + (cy ? ww : 0) + cx;
 #pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[j][c]));
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, fix_round(ws * go[j][c]));
         } else {
           const int64_t dst = vox0 + (cy ? d.s2 : 0) + cx;
 #pragma unroll
@@ -404,7 +404,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
             const float ws = w * scale;
             int* cell = win + cell0 + (cz ? plane : 0) + (cy ? ww : 0) + cx;
 #pragma unroll
-            for (int c = 0; c < CP; ++c) atomicAdd(cell + c * cells, __float2int_rn(ws * go[c0 + c]));
+            for (int c = 0; c < CP; ++c) atomicAdd(cell + c * cells, fix_round(ws * go[c0 + c]));
           } else {
             const int64_t dst = vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx + (int64_t)c0 * V;
 #pragma unroll

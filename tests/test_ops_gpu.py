@@ -1491,6 +1491,9 @@ def test_solver_step_with_the_fused_update_matches_the_per_transform_updates():
     res = {}
     for fused in (True, False):
         ops.FUSED_UPDATE = fused
+        # (the same kernel-selection hints for both runs: none -- with the first run's read-backs in the caches the second one
+        # may take another, equally valid, backward formulation somewhere, and the two differ by 1e-5 of scale)
+        ops._CHAIN_HINTS.clear(); ops._WARP_HINTS.clear(); ops._PENDING_BOUNDS.clear(); ops._NSTEPS_HINT.clear()
         try:
             solver = bench.build_solver(wl, DEV, None, hip_graph=False)
             torch.manual_seed(11)
@@ -1507,5 +1510,6 @@ def test_solver_step_with_the_fused_update_matches_the_per_transform_updates():
             ops.FUSED_UPDATE = True
     assert res[True][1].count("advchain_update_multi") == 1 and "advchain_sign_axpy" not in res[True][1], res[True][1]
     assert "advchain_update_multi" not in res[False][1] and res[False][1].count("advchain_sign_axpy") == 1, res[False][1]
-    for a, b in zip(res[True][0], res[False][0]):
-        assert maxdiff(a.cpu(), b.cpu()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    diffs = [maxdiff(a.cpu(), b.cpu()) for a, b in zip(res[True][0], res[False][0])]
+    for a, b, dv in zip(res[True][0], res[False][0], diffs):
+        assert dv <= 2e-5 * max(1.0, float(b.abs().max())), (diffs, res[True][1], res[False][1])
