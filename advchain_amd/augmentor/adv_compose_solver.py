@@ -53,6 +53,9 @@ class ComposeAdversarialTransformSolver(object):
         self.is_gt = is_gt
         self.class_weights = None
         self.process_group = process_group     # extension: batch-sharded replicas
+        # extension: the whole-batch size when sharded (the sum of the ranks' batches).  None: asked of the group at the start
+        # of every call (one all-reduce and one host read-back per call); set it when every call has the same global batch
+        self.global_batch = None
         self.device_nan_guard = True           # NaN guard of the ascent loop on the device (False: a host read-back per step)
         # extension: replay the ascent loop of adversarial_training (initial prediction + the n_iter ascent steps) as ONE
         # hipGraph once its launch sequence has been recorded (see _graphed_ascent); off by default -- the user's model
@@ -85,8 +88,14 @@ class ComposeAdversarialTransformSolver(object):
         if self.process_group is None:
             self._global_batch = None
             return
-        t = torch.tensor([float(n_local)], device=device)
-        self._global_batch = int(self._all_reduce_(t).item())
+        if self.global_batch is not None:
+            # told by the caller (a fixed per-rank batch is the normal case): no collective and, more to the point, no host
+            # read-back at the start of every call -- the `.item()` below waits for an all-reduce that itself waits for
+            # everything the rank has queued, i.e. it drains the rank's queue once per call
+            self._global_batch = int(self.global_batch)
+        else:
+            t = torch.tensor([float(n_local)], device=device)
+            self._global_batch = int(self._all_reduce_(t).item())
         for tr in self.chain_of_transforms:
             if isinstance(tr, AdvMorph):
                 tr.process_group = self.process_group

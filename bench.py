@@ -174,10 +174,16 @@ def build_solver(wl, device, process_group=None, hip_graph=None):
     sd = len(wl["dims"])
     chain = [cls[nm](spatial_dims=sd, config_dict=cfg, device=device)
              for nm, cfg in transform_configs(wl["dims"], wl["batch"], wl["chain"], morph_div8=wl.get("anatomy", False))]
-    return ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
-                                             divergence_weights=[1.0, 0.5], process_group=process_group,
-                                             hip_graph=(HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
-                                             if hip_graph is None else bool(hip_graph))
+    solver = ComposeAdversarialTransformSolver(chain_of_transforms=chain, divergence_types=["mse", "contour"],
+                                               divergence_weights=[1.0, 0.5], process_group=process_group,
+                                               hip_graph=(HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
+                                               if hip_graph is None else bool(hip_graph))
+    if process_group is not None:
+        # weak scaling: every rank holds the workload's batch -- the global batch is known without asking the group (saves the
+        # all-reduce + host read-back that would otherwise open every call and drain the rank's queue)
+        import torch.distributed as dist
+        solver.global_batch = wl["batch"] * dist.get_world_size(process_group)
+    return solver
 
 
 def solver_kwargs(wl, device):
@@ -350,7 +356,9 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
     # in-process estimate -- a replayed graph carries no per-kernel events.  host_gap = ms_per_step - gpu_busy
     # (round 6: measured in this run -- torch.profiler's kernel records over further calls after the timed region; the
     # committed rocprofv3 summary of the same command only where the profiler is not usable)
-    busy = None if PROFILING_RUN else traced_busy(step, sync)
+    # (one rank only: a profiler that fails on ONE rank of a sharded run would leave the ranks with different numbers of steps,
+    # i.e. with collectives that no longer pair up)
+    busy = None if (PROFILING_RUN or world > 1) else traced_busy(step, sync)
     if busy is not None and len(busy) == 1:
         extras["gpu_busy_trace"] = busy[0]
         busy = None
