@@ -89,6 +89,10 @@ __global__ void __launch_bounds__(kBlock) k_det_convert(const long long* __restr
   }
 }
 
+// A/B build switch (tools/ab/build_all_variant.sh -DADVCHAIN_WINDOW_FLAT=0): the branch-light window deposits
+#ifndef ADVCHAIN_WINDOW_FLAT
+#define ADVCHAIN_WINDOW_FLAT 1
+#endif
 constexpr int kWinT = 32;               // sample tile edge
 constexpr int kWinCells = 8192;         // LDS window budget in cells (all channels together): 32 KiB
 constexpr int kWinCellsC4 = 12288;      // four channels: 48 KiB (2048 cells per channel = 45 x 45 capped stretched 32 x 32 tiles)
@@ -201,6 +205,38 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
     const int vox0 = __mul24(t[j].y.i0, d.s2) + t[j].x.i0;
     const bool inx[2] = {wx0 >= 0 && wx0 < ww, wx0 + 1 >= 0 && wx0 + 1 < ww};
     const bool iny[2] = {wy0 >= 0 && wy0 < wh, wy0 + 1 >= 0 && wy0 + 1 < wh};
+#if ADVCHAIN_WINDOW_FLAT
+    {
+      // branch-light deposits (round 6, as in the owner-computes scatters): every corner adds into the window with a masked
+      // weight -- a corner that is invalid or lies outside a capped window adds zero at a cell of the lane's own -- and only a
+      // wave that really has a valid corner outside its window (rare on smooth fields) takes the global-atomic branch
+      const int own_cell = cells > 0 ? (int)threadIdx.x % cells : 0;
+      bool outside = false;
+#pragma unroll
+      for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+          const bool okc = t[j].ok(0, cy, cx), inw = inx[cx] && iny[cy] && cells > 0;
+          outside = outside || (okc && !inw);
+          const float ws = (okc && inw) ? t[j].w(0, cy, cx) * scale : 0.f;
+          int* cell = win + ((okc && inw) ? cell0 + (cy ? ww : 0) + cx : own_cell);
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, fix_round(ws * go[j][c]));
+        }
+      if (__ballot(outside) != 0) {
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < 2; ++cx) {
+            if (!t[j].ok(0, cy, cx) || (inx[cx] && iny[cy] && cells > 0)) continue;
+            const float w = t[j].w(0, cy, cx);
+            const int64_t dst = vox0 + (cy ? d.s2 : 0) + cx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[j][c], sdet);
+          }
+      }
+    }
+#else
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
@@ -218,6 +254,7 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
           for (int c = 0; c < C; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[j][c], sdet);
         }
       }
+#endif
     if (SELF || GG) {
       const float ggx = cgx[j], ggy = cgy[j];
       if (SELF) {
@@ -392,6 +429,39 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     const bool inx[2] = {wx0 >= 0 && wx0 < ww, wx0 + 1 >= 0 && wx0 + 1 < ww};
     const bool iny[2] = {wy0 >= 0 && wy0 < wh, wy0 + 1 >= 0 && wy0 + 1 < wh};
     const bool inz[2] = {wz0 >= 0 && wz0 < wd, wz0 + 1 >= 0 && wz0 + 1 < wd};
+#if ADVCHAIN_WINDOW_FLAT
+    {
+      const int own_cell = cells > 0 ? (int)threadIdx.x % cells : 0;      // (see the 2D kernel)
+      bool outside = false;
+#pragma unroll
+      for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+          for (int cx = 0; cx < 2; ++cx) {
+            const bool okc = t.ok(cz, cy, cx), inw = inx[cx] && iny[cy] && inz[cz] && cells > 0;
+            outside = outside || (okc && !inw);
+            const float ws = (okc && inw) ? t.w(cz, cy, cx) * scale : 0.f;
+            int* cell = win + ((okc && inw) ? cell0 + (cz ? plane : 0) + (cy ? ww : 0) + cx : own_cell);
+#pragma unroll
+            for (int c = 0; c < CP; ++c) atomicAdd(cell + c * cells, fix_round(ws * go[c0 + c]));
+          }
+      if (__ballot(outside) != 0) {
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+              if (!t.ok(cz, cy, cx) || (inx[cx] && iny[cy] && inz[cz] && cells > 0)) continue;
+              const float w = t.w(cz, cy, cx);
+              const int64_t dst = vox0 + (cz ? planev : 0) + (cy ? rowv : 0) + cx + (int64_t)c0 * V;
+#pragma unroll
+              for (int c = 0; c < CP; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[c0 + c], sdet);
+            }
+      }
+    }
+#else
 #pragma unroll
     for (int cz = 0; cz < 2; ++cz)
 #pragma unroll
@@ -411,6 +481,7 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
             for (int c = 0; c < CP; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[c0 + c], sdet);
           }
         }
+#endif
     if ((SELF || GG) && c0 == 0) {
       float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
