@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kBlock) k_det_convert(const long long* __restr
   }
 }
 
-// A/B build switch (tools/ab/build_all_variant.sh -DADVCHAIN_WINDOW_FLAT=0): the branch-light window deposits
+// A/B build switch (tools/ab/build_all_variant.sh -DADVCHAIN_WINDOW_FLAT=0): the branch-light deposits of the 3D window scatter
 #ifndef ADVCHAIN_WINDOW_FLAT
 #define ADVCHAIN_WINDOW_FLAT 1
 #endif
@@ -205,38 +205,6 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
     const int vox0 = __mul24(t[j].y.i0, d.s2) + t[j].x.i0;
     const bool inx[2] = {wx0 >= 0 && wx0 < ww, wx0 + 1 >= 0 && wx0 + 1 < ww};
     const bool iny[2] = {wy0 >= 0 && wy0 < wh, wy0 + 1 >= 0 && wy0 + 1 < wh};
-#if ADVCHAIN_WINDOW_FLAT
-    {
-      // branch-light deposits (round 6, as in the owner-computes scatters): every corner adds into the window with a masked
-      // weight -- a corner that is invalid or lies outside a capped window adds zero at a cell of the lane's own -- and only a
-      // wave that really has a valid corner outside its window (rare on smooth fields) takes the global-atomic branch
-      const int own_cell = cells > 0 ? (int)threadIdx.x % cells : 0;
-      bool outside = false;
-#pragma unroll
-      for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-        for (int cx = 0; cx < 2; ++cx) {
-          const bool okc = t[j].ok(0, cy, cx), inw = inx[cx] && iny[cy] && cells > 0;
-          outside = outside || (okc && !inw);
-          const float ws = (okc && inw) ? t[j].w(0, cy, cx) * scale : 0.f;
-          int* cell = win + ((okc && inw) ? cell0 + (cy ? ww : 0) + cx : own_cell);
-#pragma unroll
-          for (int c = 0; c < C; ++c) atomicAdd(cell + c * cells, fix_round(ws * go[j][c]));
-        }
-      if (__ballot(outside) != 0) {
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-          for (int cx = 0; cx < 2; ++cx) {
-            if (!t[j].ok(0, cy, cx) || (inx[cx] && iny[cy] && cells > 0)) continue;
-            const float w = t[j].w(0, cy, cx);
-            const int64_t dst = vox0 + (cy ? d.s2 : 0) + cx;
-#pragma unroll
-            for (int c = 0; c < C; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[j][c], sdet);
-          }
-      }
-    }
-#else
 #pragma unroll
     for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
@@ -254,7 +222,6 @@ k_scatter_window2d(const float* __restrict__ gout, const float* __restrict__ in,
           for (int c = 0; c < C; ++c) win_global_add<DET>(ginn, accn, dst + (int64_t)c * V, w * go[j][c], sdet);
         }
       }
-#endif
     if (SELF || GG) {
       const float ggx = cgx[j], ggy = cgy[j];
       if (SELF) {
@@ -431,7 +398,11 @@ k_scatter_window3d(const float* __restrict__ gout, const float* __restrict__ in,
     const bool inz[2] = {wz0 >= 0 && wz0 < wd, wz0 + 1 >= 0 && wz0 + 1 < wd};
 #if ADVCHAIN_WINDOW_FLAT
     {
-      const int own_cell = cells > 0 ? (int)threadIdx.x % cells : 0;      // (see the 2D kernel)
+      // branch-light deposits (round 6, as in the owner-computes scatters): every corner adds into the window with a masked
+      // weight -- a corner that is invalid or lies outside a capped window adds zero at a cell of the lane's own -- and only a
+      // wave that really has a valid corner outside its window (rare on smooth fields) takes the global-atomic branch.
+      // 3D only: -1..-2 % per launch, cfg-5 82.56 -> 82.24 ms; the 2D kernel measured no different and keeps its branches
+      const int own_cell = cells > 0 ? (int)threadIdx.x % cells : 0;
       bool outside = false;
 #pragma unroll
       for (int cz = 0; cz < 2; ++cz)
