@@ -510,7 +510,7 @@ k_adjoint_march(const float* __restrict__ gout, const float* __restrict__ in, co
 using namespace advchain;
 
 static int march_zc(const Dims& d, int64_t N, int ty) {
-  static const int forced = 0;   // (0: the rule below; was a tuning knob until round 4)
+  static const int forced = getenv("ADVCHAIN_MARCH_ZC") ? atoi(getenv("ADVCHAIN_MARCH_ZC")) : 0;   // A/B knob (0: the rule below)
   if (forced > 0) return forced;
   // enough workgroups to fill 256 CUs four deep, but chunks no shorter than 8 planes (2 of ZC + 2 steps are halo work)
   const int64_t cols = N * ((d.s1 + ty - 1) / ty);

@@ -502,7 +502,7 @@ k_sample_march_flat(const float* __restrict__ in, const float* __restrict__ grid
 using namespace advchain;
 
 static int fwd_march_zc(const Dims& d, int64_t N, int ty, int C) {
-  static const int forced = 0;   // (0: the rule below; was a tuning knob until round 4)
+  static const int forced = getenv("ADVCHAIN_FWD_MARCH_ZC") ? atoi(getenv("ADVCHAIN_FWD_MARCH_ZC")) : 0;   // A/B knob (0: the rule below)
   if (forced > 0) return forced;
   // measured at 4 x C x 128 x 128 x 64: the one-channel warp is latency-bound and wants 8 workgroups per CU even at
   // chunks of 4 planes (15.4 us against 17.7 at 8 and 25 at 16 planes); 3-4 channels want 4 per CU and chunks >= 8
