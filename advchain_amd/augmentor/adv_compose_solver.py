@@ -65,6 +65,7 @@ class ComposeAdversarialTransformSolver(object):
         # (what a user of the reference would have set); True / False: this solver's own choice.  See ops.set_deterministic
         self.deterministic = deterministic
         self.hip_graph_record_calls = 3        # ordinary calls recorded before the capture
+        self.hip_graph_margin = 1.3            # recorded maxima x margin pick the frozen kernel selection (ops.LaunchPlan)
         self._graphs = {}
         self.graph_stats = {"recorded": 0, "captures": 0, "replays": 0, "violations": 0, "refused": 0}
         self._global_batch = None
@@ -163,7 +164,8 @@ class ComposeAdversarialTransformSolver(object):
         pending = None
         if self.hip_graph and n_iter >= 1 and self._graphable(data, model, init_output, anatomy_mask_images):
             # the ascent loop as one hipGraph replay (or one of the ordinary calls that record its launch plan)
-            init_output, pending = self._graphed_ascent(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes)
+            init_output, pending = self._graphed_ascent(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes,
+                                                        anatomy_mask_images, anatomy_reg_weight, volume_preserve_tolerance)
         else:
             if self.hip_graph and n_iter >= 1:
                 self.graph_stats["refused"] += 1
@@ -209,11 +211,17 @@ class ComposeAdversarialTransformSolver(object):
         return isinstance(model, torch.nn.Module) and any(m.training for m in model.modules())
 
     def _graphable(self, data, model, init_output, anatomy_mask_images):
-        """What a capture cannot hold: host-side decisions inside the loop (the anatomy ladder, debug prints, the host NaN
-        check, third-party transforms), collectives (not captured: sharded runs stay on the ordinary path) and CPU data."""
+        """What a capture cannot hold: host-side decisions inside the loop (debug prints, the host NaN check, third-party
+        transforms), collectives (not captured: sharded runs stay on the ordinary path) and CPU data.  The anatomy ladder
+        (adv_compose_solver.py:369-403) is a host decision BEHIND the n_iter steps: the graph holds the steps and the score
+        of the first volume check, the ladder is walked from that score the ordinary way (round 6); its score is a
+        whole-batch mean, so a sharded run with an anatomy mask stays on the ordinary path."""
         chain = self.chain_of_transforms
+        anat = anatomy_mask_images
         return (isinstance(data, torch.Tensor) and data.is_cuda and data.dtype == torch.float32
-                and anatomy_mask_images is None and not self.debug and self._shardable_capture(data)
+                and (anat is None or (isinstance(anat, torch.Tensor) and anat.is_cuda and anat.dtype == torch.float32
+                                      and anat.size() == data.size() and self.process_group is None))
+                and not self.debug and self._shardable_capture(data)
                 and self.device_nan_guard and not getattr(self, 'full_backward', False)
                 and ops.ADAPTIVE_HALO and len(chain) > 0 and all(type(t) in _NATIVE for t in chain)
                 and not any(getattr(t, 'debug', False) for t in chain)
@@ -260,7 +268,7 @@ class ComposeAdversarialTransformSolver(object):
                     out.append((k, p))
         return tuple(out)
 
-    def _graph_key(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
+    def _graph_key(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes, anatomy=None):
         """Everything the captured launch sequence depends on besides tensor CONTENTS: shapes, the model's storage, the
         arguments of the call, every plain attribute of the solver and of its transforms."""
         # (the OBJECTS as well: a replay hands its results to the transforms it captured -- a chain rebuilt from the same
@@ -270,9 +278,10 @@ class ComposeAdversarialTransformSolver(object):
             + tuple(b.data_ptr() for b in model.buffers())
         mine = self._plain_attrs(self, skip=('graph_stats',))
         return (tuple(data.shape), str(data.device), None if init_output is None else tuple(init_output.shape), bool(lazy_load),
-                int(n_iter), tuple(bool(f) for f in optimize_flags), tuple(step_sizes), tr, mod, mine)
+                int(n_iter), tuple(bool(f) for f in optimize_flags), tuple(step_sizes), tr, mod, mine, anatomy)
 
-    def _graphed_ascent(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes):
+    def _graphed_ascent(self, data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes,
+                        anatomy_mask_images=None, anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4):
         """get_init_output + init_random_transformation + optimizing_transform with the launches of the prediction and of the
         ascent loop replayed from a hipGraph.
 
@@ -282,14 +291,24 @@ class ComposeAdversarialTransformSolver(object):
         the ordinary way, copies them and the data into the captured buffers and replays.  The replay checks ON THE DEVICE
         that what it measures stays inside the intervals the frozen selection is exact for (ops.LaunchPlan.check); the
         returned closure waits for the graph (not for the final pass queued behind it) and tells whether the check held.
-        Returns (init_output, closure or None)."""
-        self.init_random_transformation(lazy_load)
-        key = self._graph_key(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes)
+        Returns (init_output, closure or None).
+
+        With an anatomy mask the graph holds the n_iter steps (each with its constant regulariser term) and the score of the
+        first volume check; the host waits for the replay, reads flag and score together and walks the ladder
+        (optimizing_transform's `_ladder`) from there -- nothing to do when the check passes, further steps the ordinary way
+        when it does not.  The recorded calls are divided at the same place, so the plan holds the same sites."""
+        anat = anatomy_mask_images
+        anat_kw = dict(anatomy_mask_images=anat, anatomy_reg_weight=anatomy_reg_weight,
+                       volume_preserve_tolerance=volume_preserve_tolerance)
+        self.init_random_transformation(lazy_load, anatomy_mask_images=anat, volume_preserve_tolerance=volume_preserve_tolerance)
+        key = self._graph_key(data, model, init_output, lazy_load, n_iter, optimize_flags, step_sizes,
+                              None if anat is None else (tuple(anat.shape), float(anatomy_reg_weight),
+                                                         float(volume_preserve_tolerance)))
         rec = self._graphs.get(key)
         if rec is None:
             if len(self._graphs) >= 8:       # (each holds a memory pool of one whole call)
                 self._graphs.clear()
-            rec = self._graphs[key] = {"plan": ops.LaunchPlan(), "state": "record", "graph": None}
+            rec = self._graphs[key] = {"plan": ops.LaunchPlan(float(self.hip_graph_margin)), "state": "record", "graph": None}
         chain = list(self.chain_of_transforms)
         init_params = [t.param.detach() for t in chain]
         given = init_output
@@ -301,13 +320,18 @@ class ComposeAdversarialTransformSolver(object):
             if record:
                 rec["plan"].begin_record()
             ops._PLAN = rec["plan"] if record else None
+            lad = {"defer": True} if anat is not None else None
             try:
                 io = given if given is not None else self.get_init_output(data=data, model=model)
                 self.chain_of_transforms = self.optimizing_transform(
                     data=data, model=model, init_output=io, n_iter=n_iter, optimize_flags=optimize_flags,
-                    step_sizes=step_sizes)
+                    step_sizes=step_sizes, _ladder=lad, **anat_kw)
             finally:
                 ops._PLAN = None
+            if lad is not None and "score" in lad:      # the ladder: never recorded, never captured
+                self.chain_of_transforms = self.optimizing_transform(
+                    data=data, model=model, init_output=io, n_iter=n_iter, optimize_flags=optimize_flags,
+                    step_sizes=step_sizes, _ladder={"resume": lad["score"]}, **anat_kw)
             if record:
                 rec["plan"].end_record()
                 self.graph_stats["recorded"] += 1
@@ -335,7 +359,7 @@ class ComposeAdversarialTransformSolver(object):
         if rec["state"] == "capture":
             captured = True
             try:
-                self._capture_ascent(rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes)
+                self._capture_ascent(rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes, anat_kw)
             except Exception as exc:         # not capturable after all (the model, most likely): the ordinary path from now on
                 logging.warning('advchain_amd: hipGraph capture of the ascent loop failed (%s: %s); running it the ordinary way',
                                 type(exc).__name__, exc)
@@ -352,6 +376,8 @@ class ComposeAdversarialTransformSolver(object):
             rec["data"].copy_(data)
         if given is not None and given.data_ptr() != rec["init_output"].data_ptr():
             rec["init_output"].copy_(given)
+        if anat is not None and anat.data_ptr() != rec["anat"].data_ptr():
+            rec["anat"].copy_(anat)
         torch._foreach_copy_(rec["params"], init_params)      # (one launch for the chain's parameters, not one each)
         model.zero_grad()
         rec["graph"].replay()
@@ -361,6 +387,8 @@ class ComposeAdversarialTransformSolver(object):
             rec["check_host"].copy_(check, non_blocking=True)
         else:
             rec["flag_host"].copy_(rec["plan"].flag, non_blocking=True)
+            if rec.get("score") is not None:
+                rec["score_host"].copy_(rec["score"].reshape(1), non_blocking=True)
         rec["event"].record(ops._stream_obj())
         self.graph_stats["replays"] += 1
         outs = [torch.empty_like(op) for op in rec["out_params"]]
@@ -399,10 +427,22 @@ class ComposeAdversarialTransformSolver(object):
                     rec["plan"].thaw()
                     rec["state"], rec["graph"] = "capture", None
             return False
+        if rec.get("score") is not None:
+            # the ladder is a host decision: flag and score now (the host's run-ahead over the final pass is given up)
+            if not held():
+                return ordinary(True), None
+            self.chain_of_transforms = self.optimizing_transform(
+                data=data, model=model, init_output=io, n_iter=n_iter, optimize_flags=optimize_flags,
+                step_sizes=step_sizes, _ladder={"resume": rec["score_host"][0].clone()}, **anat_kw)
+            return io, None
         return io, held
 
-    def _capture_ascent(self, rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes):
+    def _capture_ascent(self, rec, chain, init_params, data, model, given, n_iter, optimize_flags, step_sizes, anat_kw):
         plan = rec["plan"]
+        anat = anat_kw["anatomy_mask_images"]
+        rec["anat"] = None if anat is None else anat.detach().clone()
+        lad = {"defer": True} if anat is not None else None
+        anat_kw = dict(anat_kw, anatomy_mask_images=rec["anat"])
         rec["data"] = data.detach().clone()
         rec["init_output"] = None if given is None else given.detach().clone()
         rec["params"] = [p.clone() for p in init_params]
@@ -429,7 +469,8 @@ class ComposeAdversarialTransformSolver(object):
                 plan.rewind()
                 io = rec["init_output"] if given is not None else self.get_init_output(data=rec["data"], model=model)
                 transforms = self.optimizing_transform(data=rec["data"], model=model, init_output=io, n_iter=n_iter,
-                                                       optimize_flags=optimize_flags, step_sizes=step_sizes)
+                                                       optimize_flags=optimize_flags, step_sizes=step_sizes, _ladder=lad,
+                                                       **anat_kw)
                 plan.finish()
                 if sharded:
                     vals = torch.cat(self._local_steps) if self._local_steps else torch.zeros(1, device=data.device)
@@ -448,6 +489,9 @@ class ComposeAdversarialTransformSolver(object):
         rec["attrs"] = [{k: v for k, v in vars(t).items() if self._plain(v) is not None} for t in transforms]
         rec["out_init_output"] = io
         rec["out_last_inner"] = self.last_inner_dist
+        rec["score"] = lad.get("score") if lad is not None else None
+        if rec["score"] is not None:
+            rec["score_host"] = torch.zeros(1, dtype=torch.float32, pin_memory=True)
         if sharded:
             rec["check_host"] = torch.zeros(rec["check"].numel(), dtype=torch.float32, pin_memory=True)
         self.graph_stats["captures"] += 1
@@ -619,98 +663,128 @@ class ComposeAdversarialTransformSolver(object):
             print('anatomy preserving error:', score)
         return score
 
+    def _ascent_step(self, model, data, init_output, optimize_flags, step_sizes, i_iter, use_anatomy,
+                     anatomy_mask_images, anatomy_reg_weight):
+        """One step of the ascent loop (adv_compose_solver.py:300-366): forward through the chain and the model, the
+        consistency loss, backward to the parameters, the normalised-gradient updates."""
+        model.zero_grad()
+        ops.HINT_SLOT = i_iter      # (ascent step i of this call resembles ascent step i of the previous call)
+        self.make_learnable_transformation(optimize_flags=optimize_flags,
+                                           chain_of_transforms=self.chain_of_transforms)
+        self._shared_fields(self.chain_of_transforms, True)
+        try:
+            geo = self.if_contains_geo_transform(self.chain_of_transforms)
+            ride = geo and self._ride_ok(self.chain_of_transforms)
+            augmented_data = self.forward(data.detach(), _ride=ride)     # (a new tensor object: forward() clears ITS requires_grad flag)
+            with _disable_tracking_bn_stats(model):
+                perturbed_output = self.get_net_output(model, augmented_data)
+            if geo:
+                if ride:
+                    warped_back_prediction, mask = self._predict_backward_with_mask(perturbed_output, self.chain_of_transforms,
+                                                                                    init_output)
+                else:
+                    warped_back_prediction = self.predict_backward(perturbed_output)
+                    mask = self._validity_mask(init_output, self.chain_of_transforms)
+                dist = self.loss_fn(pred=warped_back_prediction, reference=init_output, mask=mask)
+                if use_anatomy:
+                    assert anatomy_mask_images.size() == data.size(), \
+                        "gt mask should be of the same size as input image "
+                    reg_loss = anatomy_reg_weight * self.compute_anatomy_misoverlapping_loss(
+                        anatomy_mask_images=anatomy_mask_images)
+                    if self.debug:
+                        print("consistency loss", dist.item())
+                        print("reg_loss:", reg_loss.item())
+                    # constant w.r.t. every parameter (Q18); a rank-local share keeps the partials summable
+                    dist = dist + reg_loss / (1 if self.process_group is None else self._dist().get_world_size(self.process_group))
+            else:
+                dist = self.loss_fn(pred=perturbed_output, reference=init_output.detach())
+            value = self._global_value(dist)
+            if self.debug:
+                print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
+            self.last_inner_dist = value.detach()
+            # NaN / inf guard (adv_compose_solver.py:343-347: a non-finite loss skips backward and updates).  For an
+            # all-native chain it is evaluated ON THE DEVICE: backward and updates are enqueued unconditionally and
+            # every update kernel keeps the old parameters when the loss is not finite -- the host never reads the
+            # loss back in the middle of a step, so it runs ahead of the GPU for the whole call (the read-back
+            # stalled the GPU once per step: 9.8 ms per cfg-2 call for 8.8 ms of kernels).  Third-party transforms
+            # get the literal check.
+            flagged = [t for flag, t in zip(optimize_flags, self.chain_of_transforms) if flag]
+            device_guard = (self.device_nan_guard and value.is_cuda and all(_native_update(t) for t in flagged)
+                            and not getattr(self, 'full_backward', False))
+            if not device_guard and not math.isfinite(float(value.detach())):     # one read-back, no launches
+                dist = 0
+            else:
+                for t in flagged:
+                    t._gate = value.detach() if device_guard else None
+                self._backward_to_transforms(dist, optimize_flags)
+                i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
+                #           is stepped with step_sizes[0]; kept for result parity
+                if device_guard and self._fused_update(flagged, step_sizes):
+                    flagged = []          # (one launch stepped every transform: nothing left for the loop below)
+                for flag, transform in zip(optimize_flags, self.chain_of_transforms):
+                    if flag and flagged:
+                        if self.debug:
+                            print('update {} parameters'.format(transform.get_name()))
+                        try:
+                            step_size = step_sizes[i_tr]
+                        except Exception:
+                            step_size = transform.get_step_size()
+                            logging.warning(f'use default step size:{step_size}')
+                        transform.optimize_parameters(step_size=step_size)
+        finally:
+            # (also when the backward or an update raised: a stale loss must not gate a later manual update)
+            for transform in self.chain_of_transforms:
+                if getattr(transform, '_gate', None) is not None:
+                    transform._gate = None
+            self._shared_fields(self.chain_of_transforms, False)
+        model.zero_grad()
+
     def optimizing_transform(self, model, data, init_output, optimize_flags, n_iter=1, step_sizes=None,
-                             anatomy_mask_images=None, anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4):
-        """The N-step ascent loop (adv_compose_solver.py:289-405)."""
+                             anatomy_mask_images=None, anatomy_reg_weight=50, volume_preserve_tolerance=5 * 1e-4,
+                             _ladder=None):
+        """The N-step ascent loop with the volume-preservation ladder behind it (adv_compose_solver.py:289-405).
+
+        `_ladder` (private; the hipGraph path) splits the loop where the host first has to look at a device value:
+        {"defer": True} stops BEFORE the first volume check, leaving its score (a device scalar, no read-back) in
+        `_ladder["score"]`; {"resume": score} enters the loop AT that check with the score handed in and walks the ladder
+        from there the ordinary way.  defer + resume == the undivided loop, launch for launch."""
         stop_flag = False if n_iter > 0 else True
         i_iter = 0
         one_time_iter = n_iter
         transforms = []
         use_anatomy = anatomy_mask_images is not None and abs(anatomy_reg_weight) > 1e-32
+        ladder = _ladder if _ladder is not None else {}
+        resumed = "resume" in ladder
+        if resumed:
+            # the first n_iter steps and the rescaling behind them were run (replayed) by the caller, who hands in the score of
+            # the first volume check: the loop is entered at that check
+            i_iter = n_iter
         while stop_flag is False:
-            model.zero_grad()
-            i_iter += 1
-            ops.HINT_SLOT = i_iter      # (ascent step i of this call resembles ascent step i of the previous call)
-            self.make_learnable_transformation(optimize_flags=optimize_flags,
-                                               chain_of_transforms=self.chain_of_transforms)
-            self._shared_fields(self.chain_of_transforms, True)
-            try:
-                geo = self.if_contains_geo_transform(self.chain_of_transforms)
-                ride = geo and self._ride_ok(self.chain_of_transforms)
-                augmented_data = self.forward(data.detach(), _ride=ride)     # (a new tensor object: forward() clears ITS requires_grad flag)
-                with _disable_tracking_bn_stats(model):
-                    perturbed_output = self.get_net_output(model, augmented_data)
-                if geo:
-                    if ride:
-                        warped_back_prediction, mask = self._predict_backward_with_mask(perturbed_output, self.chain_of_transforms,
-                                                                                        init_output)
-                    else:
-                        warped_back_prediction = self.predict_backward(perturbed_output)
-                        mask = self._validity_mask(init_output, self.chain_of_transforms)
-                    dist = self.loss_fn(pred=warped_back_prediction, reference=init_output, mask=mask)
-                    if use_anatomy:
-                        assert anatomy_mask_images.size() == data.size(), \
-                            "gt mask should be of the same size as input image "
-                        reg_loss = anatomy_reg_weight * self.compute_anatomy_misoverlapping_loss(
-                            anatomy_mask_images=anatomy_mask_images)
-                        if self.debug:
-                            print("consistency loss", dist.item())
-                            print("reg_loss:", reg_loss.item())
-                        # constant w.r.t. every parameter (Q18); a rank-local share keeps the partials summable
-                        dist = dist + reg_loss / (1 if self.process_group is None else self._dist().get_world_size(self.process_group))
-                else:
-                    dist = self.loss_fn(pred=perturbed_output, reference=init_output.detach())
-                value = self._global_value(dist)
-                if self.debug:
-                    print('[inner loop], step {}: dist {}'.format(str(i_iter), value.item()))
-                self.last_inner_dist = value.detach()
-                # NaN / inf guard (adv_compose_solver.py:343-347: a non-finite loss skips backward and updates).  For an
-                # all-native chain it is evaluated ON THE DEVICE: backward and updates are enqueued unconditionally and
-                # every update kernel keeps the old parameters when the loss is not finite -- the host never reads the
-                # loss back in the middle of a step, so it runs ahead of the GPU for the whole call (the read-back
-                # stalled the GPU once per step: 9.8 ms per cfg-2 call for 8.8 ms of kernels).  Third-party transforms
-                # get the literal check.
-                flagged = [t for flag, t in zip(optimize_flags, self.chain_of_transforms) if flag]
-                device_guard = (self.device_nan_guard and value.is_cuda and all(_native_update(t) for t in flagged)
-                                and not getattr(self, 'full_backward', False))
-                if not device_guard and not math.isfinite(float(value.detach())):     # one read-back, no launches
-                    dist = 0
-                else:
-                    for t in flagged:
-                        t._gate = value.detach() if device_guard else None
-                    self._backward_to_transforms(dist, optimize_flags)
-                    i_tr = 0  # never advanced in the reference (adv_compose_solver.py:349-364): every transform
-                    #           is stepped with step_sizes[0]; kept for result parity
-                    if device_guard and self._fused_update(flagged, step_sizes):
-                        flagged = []          # (one launch stepped every transform: nothing left for the loop below)
-                    for flag, transform in zip(optimize_flags, self.chain_of_transforms):
-                        if flag and flagged:
-                            if self.debug:
-                                print('update {} parameters'.format(transform.get_name()))
-                            try:
-                                step_size = step_sizes[i_tr]
-                            except Exception:
-                                step_size = transform.get_step_size()
-                                logging.warning(f'use default step size:{step_size}')
-                            transform.optimize_parameters(step_size=step_size)
-            finally:
-                # (also when the backward or an update raised: a stale loss must not gate a later manual update)
-                for transform in self.chain_of_transforms:
-                    if getattr(transform, '_gate', None) is not None:
-                        transform._gate = None
-                self._shared_fields(self.chain_of_transforms, False)
-            model.zero_grad()
+            if not resumed:
+                i_iter += 1
+                self._ascent_step(model, data, init_output, optimize_flags, step_sizes, i_iter, use_anatomy,
+                                  anatomy_mask_images, anatomy_reg_weight)
 
             if i_iter == n_iter:
-                transforms = []
-                for flag, transform in zip(optimize_flags, self.chain_of_transforms):
-                    if flag:
-                        transform.rescale_parameters()
-                        transform.eval()
-                    transforms.append(transform)
+                if resumed:
+                    transforms = list(self.chain_of_transforms)      # (rescaled and in eval() since the deferred part)
+                else:
+                    transforms = []
+                    for flag, transform in zip(optimize_flags, self.chain_of_transforms):
+                        if flag:
+                            transform.rescale_parameters()
+                            transform.eval()
+                        transforms.append(transform)
                 if self.if_contains_geo_transform(transforms) and use_anatomy:
+                    if resumed:
+                        score, resumed = ladder["resume"], False
+                    else:
+                        score = self.compute_anatomy_misoverlapping_loss(anatomy_mask_images)
+                        if ladder.get("defer"):
+                            ladder["score"] = score
+                            break
                     print('activating volume preserving check')
-                    if abs(self.compute_anatomy_misoverlapping_loss(anatomy_mask_images)) <= volume_preserve_tolerance:
+                    if abs(score) <= volume_preserve_tolerance:
                         print('Success! pass the volume preserving check')
                         stop_flag = True
                     else:

@@ -178,6 +178,8 @@ def build_solver(wl, device, process_group=None, hip_graph=None):
                                                divergence_weights=[1.0, 0.5], process_group=process_group,
                                                hip_graph=(HIP_GRAPH and (process_group is None or SHARDED_GRAPH) and len(wl["dims"]) == 2)
                                                if hip_graph is None else bool(hip_graph))
+    if os.environ.get("ADVCHAIN_PLAN_MARGIN"):       # (experiment knob of tools/sessions/r06_s14.sh)
+        solver.hip_graph_margin = float(os.environ["ADVCHAIN_PLAN_MARGIN"])
     if process_group is not None:
         # weak scaling: every rank holds the workload's batch -- the global batch is known without asking the group (saves the
         # all-reduce + host read-back that would otherwise open every call and drain the rank's queue)
@@ -396,7 +398,7 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                 step()
             sync()
             extras["ordinary_ms_per_step"] = round((time.perf_counter() - t1) / k_ord * 1e3, 3)
-    if (not graphed) and sd == 2 and pg is None and REPLAY_LEG and not PROFILING_RUN and not wl.get("anatomy"):
+    if (not graphed) and (sd == 2 or wl.get("anatomy")) and pg is None and REPLAY_LEG and not PROFILING_RUN:
         # the same workload with the ascent loop of a call replayed from a hipGraph (solver.hip_graph=True: opt-in in the
         # product).  A solver of its own: recorded calls, capture, then K timed replays
         rs = build_solver(wl, device, None, hip_graph=True)
@@ -418,6 +420,9 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
                               "violations": rs.graph_stats["violations"] - r0["violations"], "captures": rs.graph_stats["captures"],
                               "note": "solver.hip_graph=True (opt-in): prediction + ascent steps of a call as ONE hipGraph replay, the "
                                       "final pass dispatched behind it; `value` / `ms_per_step` are the DEFAULT path (launch by launch)"}
+        viol = [v for rec in rs._graphs.values() for v in rec["plan"].violated]
+        if viol:
+            extras["replayed"]["violated_bounds"] = viol[-8:]
         del rs
     if workload in DETERMINISTIC_LEG and world == 1 and pg is None and not PROFILING_RUN:
         # the same steps with solver.deterministic = True (ordinary path): the window scatter's float-atomic flush replaced by its

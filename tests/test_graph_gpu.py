@@ -208,19 +208,98 @@ def test_results_do_not_alias_the_captured_buffers():
 
 
 def test_what_a_capture_cannot_hold_takes_the_ordinary_path():
-    import bench
+    """Debug prints read device values in the middle of a step: such a solver is refused (and says so in its statistics)."""
     dims, names, n_iter = CASES["3d_bma"]
     N = 2
     model = make_model(3, device=DEV)
     data = smooth_data(N, 1, dims, 11).to(DEV)
     graph = _solver(dims, names, N, True)
-    mask = bench.ellipsoid(N, dims).to(DEV)
+    graph.debug = True
     import contextlib
     import io
     for _ in range(3):
         with contextlib.redirect_stdout(io.StringIO()):
-            graph.adversarial_training(data=data, model=model, n_iter=1, anatomy_mask_images=mask)
+            graph.adversarial_training(data=data, model=model, n_iter=1)
     assert graph.graph_stats["refused"] == 3 and graph.graph_stats["replays"] == 0
+
+
+def _anat_call(solver, data, model, mask, n_iter, seed, tol):
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        loss = solver.adversarial_training(data=data, model=model, n_iter=n_iter, lazy_load=False, step_sizes=1,
+                                           anatomy_mask_images=mask, anatomy_reg_weight=50, volume_preserve_tolerance=tol)
+    return ([loss.detach().clone(), solver.adv_data.clone(), solver.warped_back_adv_output.detach().clone(),
+             solver.init_output.clone()] + [t.param.detach().clone() for t in solver.chain_of_transforms]), out.getvalue()
+
+
+@pytest.mark.parametrize("case", ["3d_morph", "2d_full"])
+def test_the_anatomy_ladder_behind_a_replay_passing_check(case):
+    """adv_compose_solver.py:369-403 with a mask the field preserves: the n_iter steps (with their regulariser term) and the
+    score of the volume check come from the replay, the host only reads the score -- the same messages, the same results
+    as the ordinary path to the tolerance between two backward formulations."""
+    import bench
+    dims, names, n_iter = {"3d_morph": ((32, 32, 16), ["morph"], 2), "2d_full": CASES["2d_full"]}[case]
+    n_iter = 1
+    N = 2
+    model = make_model(len(dims), device=DEV)
+    mask = bench.ellipsoid(N, dims).to(DEV)
+    eager, graph = _solver(dims, names, N, False), _solver(dims, names, N, True)
+    for k in range(6):
+        data = smooth_data(N, 1, dims, 60 + k).to(DEV)
+        want, said_e = _anat_call(eager, data, model, mask, n_iter, 500 + k, 5e-4)
+        got, said_g = _anat_call(graph, data, model, mask, n_iter, 500 + k, 5e-4)
+        assert said_e == said_g and "Success" in said_g
+        _close(got, want, 1e-4)
+    st = graph.graph_stats
+    assert st["refused"] == 0 and st["captures"] >= 1 and st["replays"] >= 2 and st["recorded"] == 3 + st["violations"], st
+
+
+def test_the_anatomy_ladder_behind_a_replay_failing_check():
+    """A tolerance nothing meets: the ladder adds steps, draws new parameters at 2 n_iter and gives up at 3 n_iter with a
+    fresh draw (adv_compose_solver.py:376-395).  Behind a replay the further steps run the ordinary way: the same number of
+    steps, the same messages, the same random draws -- the parameters the call ends with are the ordinary path's, exactly."""
+    import bench
+    from advchain_amd.augmentor import ComposeAdversarialTransformSolver
+    dims, names, n_iter = (32, 32, 16), ["morph"], 2
+    N = 2
+    model = make_model(3, device=DEV)
+    mask = bench.ellipsoid(N, dims).to(DEV)
+    eager, graph = _solver(dims, names, N, False), _solver(dims, names, N, True)
+    chains = {id(s): list(s.chain_of_transforms) for s in (eager, graph)}
+    counts = {id(eager): 0, id(graph): 0}
+    inner = ComposeAdversarialTransformSolver._ascent_step
+
+    def counting(self, *a, **k):
+        if not torch.cuda.is_current_stream_capturing():
+            counts[id(self)] += 1
+        return inner(self, *a, **k)
+    ComposeAdversarialTransformSolver._ascent_step = counting
+    try:
+        for k in range(6):
+            data = smooth_data(N, 1, dims, 80 + k).to(DEV)
+            c0, st0 = dict(counts), dict(graph.graph_stats)
+            want, said_e = _anat_call(eager, data, model, mask, n_iter, 700 + k, -1.0)
+            got, said_g = _anat_call(graph, data, model, mask, n_iter, 700 + k, -1.0)
+            assert said_e == said_g and "new initialization" in said_g and "Success" not in said_g
+            assert counts[id(eager)] - c0[id(eager)] == 3 * n_iter
+            st1 = graph.graph_stats      # (a replay holds the first n_iter steps; a violated one is run again in full)
+            replayed = st1["replays"] > st0["replays"] and st1["violations"] == st0["violations"]
+            assert counts[id(graph)] - c0[id(graph)] == (2 * n_iter if replayed else 3 * n_iter), (k, counts, st1)
+            # (the reference's ladder leaves the last transform listed twice when it gives up, adv_compose_solver.py:399 -- kept;
+            # the caller who goes on with the same solver puts the chain back)
+            assert len(got) == len(want) == 4 + len(names) + 1
+            for x, y in zip(got[4:], want[4:]):
+                assert torch.equal(x, y)
+            _close(got[:4], want[:4], 1e-4)
+            for s in (eager, graph):
+                s.chain_of_transforms = list(chains[id(s)])
+    finally:
+        ComposeAdversarialTransformSolver._ascent_step = inner
+    st = graph.graph_stats
+    assert st["refused"] == 0 and st["replays"] >= 2, st
 
 
 def test_batchnorm_model_in_train_mode_is_captured():
