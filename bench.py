@@ -447,6 +447,38 @@ def run_gpu(workload, wl, steps, warmup, rank, world, device):
         finally:
             _ops_det.set_deterministic(False)
         del ds
+    if workload == "cfg2" and world == 1 and pg is None and not PROFILING_RUN:
+        # BASELINE config 2 says "bf16": the USER MODEL under torch.autocast(bfloat16) -- what a mixed-precision training loop
+        # hands the solver -- with the augmentation path in fp32 as the reference's own F.grid_sample is under autocast (it is
+        # on autocast's fp32 list).  A secondary line: the headline stays the fp32 model (the 1e-4 parity contract is fp32)
+        class _Bf16Model(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, x):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = self.inner(x)
+                return y.float()
+        bm = _Bf16Model(model)
+        bs = build_solver(wl, device, None, hip_graph=False)
+
+        def bstep():
+            with contextlib.redirect_stdout(io.StringIO()):
+                return bs.adversarial_training(data=data, model=bm, **kw)
+        try:
+            for _ in range(3):
+                bstep()
+            k_bf = max(3, min(steps, 10))
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k_bf):
+                bstep()
+            sync()
+            extras["model_bf16_autocast_ms_per_step"] = round((time.perf_counter() - t1) / k_bf * 1e3, 3)
+        except Exception as exc:        # (a secondary line must not take the headline down with it)
+            extras["model_bf16_autocast_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+        del bs, bm
     if not PROFILING_RUN and dominant and not lib.records:
         # nothing in the timed region could carry the dominant entry's events (a replayed graph makes no C-ABI call; the
         # composite DemonsCompose entries hold the chain inside one call): the same launches, enqueued entry by entry
