@@ -67,6 +67,8 @@ PROTOTYPES = {
     "advchain_consistency_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
     "advchain_consistency_fused_fwd": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _I, _I, _P]),
     "advchain_consistency_fused_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _L, _L, _I, _P, _I, _P]),
+    "advchain_consistency_fused_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _L, _L, _I, _P, _P]),
+    "advchain_consistency_fused_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _I, _P, _P]),
 }
 
 class UpdateDesc(ctypes.Structure):

@@ -580,9 +580,29 @@ using namespace advchain;
 // ---------------------------------------------------------------------------------------------
 struct Quad { float v[4]; };
 
+// Storage type of the K-channel tensors of the fused loss (round 6 experiment, advchain_consistency_fused_*_bf16): fp32 is the
+// product; Bf16 halves the bytes of pred / ref / R / grad_pred and keeps every operation in fp32 registers.
+struct Bf16 { unsigned short v; };
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const Bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned bf16_rne(float x) {          // round to nearest even; NaN stays NaN
+  const unsigned b = __float_as_uint(x);
+  return (x != x) ? 0x7fc0u : (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float e) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, e);
+}
+__device__ __forceinline__ void st4(Bf16* p, float a, float b, float c, float e) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(bf16_rne(a) | (bf16_rne(b) << 16), bf16_rne(c) | (bf16_rne(e) << 16));
+}
+
 // rows (i0 +- 1, j1) folded over z and x for the 4 voxels of this lane: zs = h along x, zd = hp along x
-template <int DIM>
-__device__ __forceinline__ void fold_row4(const float* __restrict__ p, int i0, int j1, int x, bool first, bool last,
+template <int DIM, typename ST>
+__device__ __forceinline__ void fold_row4(const ST* __restrict__ p, int i0, int j1, int x, bool first, bool last,
                                           const Dims& d, Quad& zs, Quad& zd) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) { zs.v[q] = 0.f; zd.v[q] = 0.f; }
@@ -591,7 +611,7 @@ __device__ __forceinline__ void fold_row4(const float* __restrict__ p, int i0, i
     const int j0 = i0 + a0 - 1;
     const bool in = (j0 >= 0) && (j0 < d.s0) && (j1 >= 0) && (j1 < d.s1);
     const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1);
-    float4 c = *reinterpret_cast<const float4*>(p + ((int64_t)c0 * d.s1 + c1) * d.s2 + x);
+    float4 c = ld4(p + ((int64_t)c0 * d.s1 + c1) * d.s2 + x);
     if (!in) c = make_float4(0.f, 0.f, 0.f, 0.f);
     const float pw = lane_prev_f(c.w), nx = lane_next_f(c.x);
     const float l[4] = {first ? 0.f : pw, c.x, c.y, c.z};
@@ -814,25 +834,25 @@ __device__ __forceinline__ void softmax_quads(const float (&p)[K][4], const floa
 }
 
 // the same for the 4 voxels at `o` (+ k V) of both logit maps in memory
-template <int K, bool LOGS>
-__device__ __forceinline__ void softmax_pair4(const float* __restrict__ pred, const float* __restrict__ ref, int64_t o, int V,
+template <int K, bool LOGS, typename ST>
+__device__ __forceinline__ void softmax_pair4(const ST* __restrict__ pred, const ST* __restrict__ ref, int64_t o, int V,
                                               int ref_is_prob, float (&P)[K][4], float (&T)[K][4], float (&lq)[LOGS ? K : 1][4],
                                               float (&lt)[LOGS ? K : 1][4]) {
   float p[K][4], r[K][4];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const float4 a = *reinterpret_cast<const float4*>(pred + o + (int64_t)k * V);
-    const float4 b = *reinterpret_cast<const float4*>(ref + o + (int64_t)k * V);
+    const float4 a = ld4(pred + o + (int64_t)k * V);
+    const float4 b = ld4(ref + o + (int64_t)k * V);
     p[k][0] = a.x; p[k][1] = a.y; p[k][2] = a.z; p[k][3] = a.w;
     r[k][0] = b.x; r[k][1] = b.y; r[k][2] = b.z; r[k][3] = b.w;
   }
   softmax_quads<K, LOGS>(p, r, ref_is_prob, P, T, lq, lt);
 }
 
-template <int DIM, int K, bool KL, bool EDGES>
+template <int DIM, int K, bool KL, bool EDGES, typename ST = float>
 __global__ void __launch_bounds__(kBlock)
-k_loss_fused_fwd4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ mask,
-                  float* __restrict__ R, float* __restrict__ sums, Dims d, int mlen, int ref_is_prob) {
+k_loss_fused_fwd4(const ST* __restrict__ pred, const ST* __restrict__ ref, const float* __restrict__ mask,
+                  ST* __restrict__ R, float* __restrict__ sums, Dims d, int mlen, int ref_is_prob) {
   __shared__ float smem[16];
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
@@ -858,7 +878,7 @@ k_loss_fused_fwd4(const float* __restrict__ pred, const float* __restrict__ ref,
       const int c0 = min(max(j0, 0), d.s0 - 1), c1 = min(max(j1, 0), d.s1 - 1);
       const int v = (c0 * d.s1 + c1) * d.s2 + x;
       float P[K][4], T[K][4], lq[KL ? K : 1][4], lt[KL ? K : 1][4];
-      softmax_pair4<K, KL>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, P, T, lq, lt);
+      softmax_pair4<K, KL, ST>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, P, T, lq, lt);
       if (a0 == 1 && in && ok && j1 >= y0 && j1 < y1) {
         float m[4] = {1.f, 1.f, 1.f, 1.f};
         if (mask) {
@@ -923,8 +943,8 @@ k_loss_fused_fwd4(const float* __restrict__ pred, const float* __restrict__ ref,
           rb[q] = 2.f * m[q] * m[q] * gb;
         }
         if (R && ok) {
-          *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v) = make_float4(ra[0], ra[1], ra[2], ra[3]);
-          *reinterpret_cast<float4*>(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+          st4(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V + v, ra[0], ra[1], ra[2], ra[3]);
+          st4(R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1) + 1) * V + v, rb[0], rb[1], rb[2], rb[3]);
         }
         zs[k - 1][0] = zs[k - 1][1]; zs[k - 1][1] = zs[k - 1][2];
         zd[k - 1][0] = zd[k - 1][1]; zd[k - 1][1] = zd[k - 1][2];
@@ -945,10 +965,10 @@ k_loss_fused_fwd4(const float* __restrict__ pred, const float* __restrict__ ref,
 }
 
 // backward of the fused form: k_consistency_bwd_march4 with P and D = P - T recomputed from the logits at the voxel
-template <int DIM, int K, bool KL>
+template <int DIM, int K, bool KL, typename ST = float>
 __global__ void __launch_bounds__(kBlock)
-k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref, const float* __restrict__ R,
-                  const float* __restrict__ mask, const float* __restrict__ gscale, float* __restrict__ gpred,
+k_loss_fused_bwd4(const ST* __restrict__ pred, const ST* __restrict__ ref, const ST* __restrict__ R,
+                  const float* __restrict__ mask, const float* __restrict__ gscale, ST* __restrict__ gpred,
                   float c_mse, float c_a, float c_b, Dims d, int mlen, float c_kl, int ref_is_prob) {
   const int n = blockIdx.y;
   const int V = (int)d.voxels();
@@ -958,7 +978,7 @@ k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref,
   const float gs = gscale ? gscale[0] : 1.f;
   Quad za[K - 1][3], zb[K - 1][3];
   auto fold = [&](int k, int j1, Quad& a, Quad& b) {
-    const float* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
+    const ST* Ra = R + ((int64_t)n * 2 * (K - 1) + 2 * (k - 1)) * V;
     Quad as, ad, bs, bd;
     fold_row4<DIM>(Ra, i0, j1, x, first, last, d, as, ad);
     fold_row4<DIM>(Ra + V, i0, j1, x, first, last, d, bs, bd);
@@ -985,7 +1005,7 @@ k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref,
       const float4 mm = *reinterpret_cast<const float4*>(mask + (int64_t)n * V + v);
       m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
     }
-    softmax_pair4<K, false>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, pk, tk, lq, lt);
+    softmax_pair4<K, false, ST>(pred, ref, (int64_t)n * K * V + v, V, ref_is_prob, pk, tk, lq, lt);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       if (k >= 1 && R) fold(k, i1 + 1, za[k - 1][2], zb[k - 1][2]);
@@ -1023,7 +1043,7 @@ k_loss_fused_bwd4(const float* __restrict__ pred, const float* __restrict__ ref,
           o4[q] = pk[k][q] * (gp[k][q] - dot[q]);
           if (KL) o4[q] += gs * c_kl * (pk[k][q] * klS[q] - mt[k][q]);
         }
-        *reinterpret_cast<float4*>(gpred + ((int64_t)n * K + k) * V + v) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        st4(gpred + ((int64_t)n * K + k) * V + v, o4[0], o4[1], o4[2], o4[3]);
       }
     }
   }
@@ -1645,6 +1665,50 @@ int advchain_consistency_fused_bwd(const float* pred, const float* ref, const fl
     else hipLaunchKernelGGL((k_loss_fused_bwd4<DIM_, K_, false>), g4, b4, 0, st, pred, ref, R, mask, grad_scale, grad_pred, c_mse, c_a, c_b, d, mlen, c_kl, ref_is_prob); } while (0)
   switch (K) { case 2: FUSED_BWD(2, 2); break; case 3: FUSED_BWD(2, 3); break; default: FUSED_BWD(2, 4); break; }
 #undef FUSED_BWD
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+// ---- bf16 STORAGE experiment (round 6; BASELINE config 2 says "bf16").  The 2D K = 4 fused loss with pred / ref / R /
+// grad_pred stored as bfloat16 (8 bytes per lane instead of 16) and every operation in fp32 registers: what the byte-heaviest
+// entries of a cfg-2 step gain from half the bytes.  NOT on the product path (the parity contract is fp32 at 1e-4;
+// tools/kernel_bench.py "bf16 storage" rows, tests/test_ops_gpu.py::test_bf16_storage_experiment...).  2D, K == 4, logits on both
+// sides, mse + edge terms, a one-channel fp32 mask or none; -2 for anything else.
+int advchain_consistency_fused_fwd_bf16(const void* pred, const void* ref, const float* mask, void* R, float* sums, int64_t N,
+                                        int64_t K, int ndim, const int64_t* dims, void* stream) {
+  ADVCHAIN_CHECK_ARG(pred && ref && sums, "consistency_fused_fwd_bf16: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fused_fwd_bf16: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "consistency_fused_fwd_bf16: bad N");
+  const Dims d = lmake_dims(ndim, dims);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(R);
+  if (ndim != 2 || K != 4 || d.s2 % 4 != 0 || d.s2 > 256 || (al & 7) != 0 || (reinterpret_cast<uintptr_t>(mask) & 15) != 0 ||
+      d.voxels() >= (1ll << 31))
+    return ADVCHAIN_ERR_UNSUPPORTED;
+  if (N == 0) return ADVCHAIN_OK;
+  const int mlen = march4_len(d, N);
+  hipLaunchKernelGGL((k_loss_fused_fwd4<2, 4, false, true, Bf16>), march4_grid(d, N, mlen), dim3(kBlock), 0, (hipStream_t)stream,
+                     static_cast<const Bf16*>(pred), static_cast<const Bf16*>(ref), mask, static_cast<Bf16*>(R), sums, d, mlen, 0);
+  ADVCHAIN_LAUNCH_CHECK();
+  return ADVCHAIN_OK;
+}
+
+int advchain_consistency_fused_bwd_bf16(const void* pred, const void* ref, const void* R, const float* mask,
+                                        const float* grad_scale, void* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
+                                        int64_t K, int ndim, const int64_t* dims, void* stream) {
+  ADVCHAIN_CHECK_ARG(pred && ref && R && grad_pred, "consistency_fused_bwd_bf16: null pointer");
+  ADVCHAIN_CHECK_ARG(ldims_ok(ndim, dims), "consistency_fused_bwd_bf16: bad dims");
+  ADVCHAIN_CHECK_ARG(N >= 0 && N < 65536, "consistency_fused_bwd_bf16: bad N");
+  const Dims d = lmake_dims(ndim, dims);
+  const uintptr_t al = reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(ref) | reinterpret_cast<uintptr_t>(R) |
+                       reinterpret_cast<uintptr_t>(grad_pred);
+  if (ndim != 2 || K != 4 || d.s2 % 4 != 0 || d.s2 > 256 || (al & 7) != 0 || (reinterpret_cast<uintptr_t>(mask) & 15) != 0 ||
+      d.voxels() >= (1ll << 31))
+    return ADVCHAIN_ERR_UNSUPPORTED;
+  if (N == 0) return ADVCHAIN_OK;
+  const int mlen = march4_len(d, N);
+  hipLaunchKernelGGL((k_loss_fused_bwd4<2, 4, false, Bf16>), march4_grid(d, N, mlen), dim3(kBlock), 0, (hipStream_t)stream,
+                     static_cast<const Bf16*>(pred), static_cast<const Bf16*>(ref), static_cast<const Bf16*>(R), mask, grad_scale,
+                     static_cast<Bf16*>(grad_pred), c_mse, c_a, c_b, d, mlen, 0.f, 0);
   ADVCHAIN_LAUNCH_CHECK();
   return ADVCHAIN_OK;
 }

@@ -432,6 +432,17 @@ int advchain_consistency_fused_bwd(const float* pred, const float* ref, const fl
                                    int ref_is_prob, int64_t N, int64_t K, int ndim, const int64_t* dims, int mask_channels,
                                    void* stream);
 
+/* bf16 STORAGE experiment (round 6; BASELINE config 2 names "bf16"): the 2D K = 4 fused loss above (common/loss.py:8-87,
+ * 102-220: mse + contour terms on logits) with pred / ref / R / grad_pred stored as bfloat16 (raw 16-bit words, 8-byte aligned)
+ * and all arithmetic in fp32 registers.  NOT used by the product path -- the parity contract is fp32 at 1e-4; the entries exist
+ * so that "what would half the bytes buy" is a measurement (tools/kernel_bench.py).  mask: fp32, one
+ * channel or NULL.  ADVCHAIN_ERR_UNSUPPORTED (-2) for anything but ndim == 2, K == 4, rows of 4j <= 256 pixels. */
+int advchain_consistency_fused_fwd_bf16(const void* pred, const void* ref, const float* mask, void* R, float* sums, int64_t N,
+                                        int64_t K, int ndim, const int64_t* dims, void* stream);
+int advchain_consistency_fused_bwd_bf16(const void* pred, const void* ref, const void* R, const float* mask,
+                                        const float* grad_scale, void* grad_pred, float c_mse, float c_a, float c_b, int64_t N,
+                                        int64_t K, int ndim, const int64_t* dims, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

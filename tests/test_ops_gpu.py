@@ -1301,6 +1301,47 @@ def test_consistency_loss_row_kernels(dims):
         assert maxdiff(b.grad.cpu(), a.grad) < 2e-5 * float(a.grad.abs().max()) + 1e-10
 
 
+@pytest.mark.parametrize("dims", [(64, 256), (37, 52), (5, 8)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_bf16_storage_experiment_of_the_fused_loss(dims, masked):
+    """advchain_consistency_fused_{fwd,bwd}_bf16 (round 6 experiment, NOT the product path): bf16 storage of pred / ref / R /
+    grad_pred, fp32 arithmetic.  On bf16-representable inputs the sums are the fp32 entry's (the same folds on the same values),
+    R and grad_pred are the fp32 entry's results rounded to bf16 (2^-8 relative: the storage, nothing else)."""
+    import ctypes
+    from advchain_amd import _lib, ops
+    lib = _lib.load()
+    N, K = 3, 4
+    pf = (rand((N, K) + dims, 801) * 3).to(DEV).bfloat16().float().contiguous()
+    rf = (rand((N, K) + dims, 802) * 3).to(DEV).bfloat16().float().contiguous()
+    mk = (rand((N, 1) + dims, 803) > -0.7).float().to(DEV).contiguous() if masked else None
+    pb, rb = pf.bfloat16().contiguous(), rf.bfloat16().contiguous()
+    dm = _lib.dims_array(dims)
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ops._stream()
+    Rf = torch.zeros(N, 6, *dims, device=DEV)
+    Rb = torch.zeros(N, 6, *dims, device=DEV, dtype=torch.bfloat16)
+    sf, sb = torch.zeros(4, 64, device=DEV), torch.zeros(4, 64, device=DEV)
+    _lib.check(lib.advchain_consistency_fused_fwd(P(pf), P(rf), P(mk), P(Rf), P(sf), N, K, 2, dm, 1, 0, 1, 0, st), "fwd")
+    _lib.check(lib.advchain_consistency_fused_fwd_bf16(P(pb), P(rb), P(mk), P(Rb), P(sb), N, K, 2, dm, st), "fwd16")
+    tot_f, tot_b = sf.double().sum(1), sb.double().sum(1)
+    assert float((tot_f - tot_b).abs().max()) <= 1e-5 * float(tot_f.abs().max())
+    scale = float(Rf.abs().max())
+    assert float((Rb.float() - Rf).abs().max()) <= 2.0 ** -8 * scale
+    # backward from the SAME (bf16-rounded) R on both sides
+    R16 = Rb.float().contiguous()
+    gf = torch.zeros_like(pf)
+    gb = torch.zeros(N, K, *dims, device=DEV, dtype=torch.bfloat16)
+    _lib.check(lib.advchain_consistency_fused_bwd(P(pf), P(rf), P(R16), P(mk), None, P(gf), 1.0, 0.5, 0.5, 0.0, 0, N, K, 2, dm, 1,
+                                                  st), "bwd")
+    _lib.check(lib.advchain_consistency_fused_bwd_bf16(P(pb), P(rb), P(Rb), P(mk), None, P(gb), 1.0, 0.5, 0.5, N, K, 2, dm, st),
+               "bwd16")
+    assert float((gb.float() - gf).abs().max()) <= 2.0 ** -8 * float(gf.abs().max())
+    assert torch.isfinite(gb.float()).all()
+    # what the entries do not take: 3D, K != 4
+    assert lib.advchain_consistency_fused_fwd_bf16(P(pb), P(rb), None, P(Rb), P(sb), N, 3, 2, dm, st) == -2
+    sb.zero_()
+
+
 @pytest.mark.parametrize("dims", [(40, 50, 64), (37, 33, 80), (19, 40, 128), (70, 30, 16), (2, 3, 8), (33, 15, 4)])
 @pytest.mark.parametrize("K", [2, 3, 4])
 def test_fused_loss_3d_marching_along_z(dims, K):

@@ -6,6 +6,7 @@ device copy of the same size for calibration.
     python tools/kernel_bench.py [--shape 3d|2d] [--reps 20] [--only name]
 """
 import argparse
+import ctypes
 import os
 import sys
 
@@ -205,6 +206,37 @@ def main():
         v = calc_segmentation_consistency(pr, g4, ['mse', 'contour'], [1.0, 0.5], mask=m1)
         torch.autograd.grad(v, pr)
     add("consistency loss fwd+bwd K=4", loss_fb, 4 * NV * (4 + 4 + 1 + 4))
+    if d == 2:
+        # the bf16 STORAGE experiment (include/advchain_hip.h, last section): the fused loss entries called raw, fp32 against bf16
+        # storage of pred / ref / R / grad_pred on the same (bf16-representable) values; bytes = what each form moves
+        from advchain_amd import _lib
+        lib = _lib.load()
+        dm = _lib.dims_array(dims)
+        mk = (torch.rand_like(x1) > 0.1).float()
+        pf, rf = x4.bfloat16().float().contiguous(), g4.bfloat16().float().contiguous()
+        pb, rb = pf.bfloat16().contiguous(), rf.bfloat16().contiguous()
+        Rf = torch.empty(N, 6, *dims, device=dev)
+        Rb = torch.empty(N, 6, *dims, device=dev, dtype=torch.bfloat16)
+        gf, gb = torch.empty_like(pf), torch.empty_like(pb)
+        slots = torch.zeros(4, 64, device=dev)
+        st = ops._stream()
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def f32_fwd():
+            _lib.check(lib.advchain_consistency_fused_fwd(P(pf), P(rf), P(mk), P(Rf), P(slots), N, 4, 2, dm, 1, 0, 1, 0, st), "fwd")
+
+        def f32_bwd():
+            _lib.check(lib.advchain_consistency_fused_bwd(P(pf), P(rf), P(Rf), P(mk), None, P(gf), 1.0, 0.5, 0.5, 0.0, 0, N, 4, 2, dm, 1, st), "bwd")
+
+        def b16_fwd():
+            _lib.check(lib.advchain_consistency_fused_fwd_bf16(P(pb), P(rb), P(mk), P(Rb), P(slots), N, 4, 2, dm, st), "fwd16")
+
+        def b16_bwd():
+            _lib.check(lib.advchain_consistency_fused_bwd_bf16(P(pb), P(rb), P(Rb), P(mk), None, P(gb), 1.0, 0.5, 0.5, N, 4, 2, dm, st), "bwd16")
+        add("fused loss fwd K=4 fp32 storage", f32_fwd, 4 * NV * (4 + 4 + 1 + 6))
+        add("fused loss fwd K=4 bf16 storage", b16_fwd, 2 * NV * (4 + 4 + 6) + 4 * NV)
+        add("fused loss bwd K=4 fp32 storage", f32_bwd, 4 * NV * (4 + 4 + 6 + 1 + 4))
+        add("fused loss bwd K=4 bf16 storage", b16_bwd, 2 * NV * (4 + 4 + 6 + 4) + 4 * NV)
     print("shape %s N=%d dims=%s" % (args.shape, N, dims))
     print("%-40s %10s %10s %10s" % ("kernel", "us", "GB/s(alg)", "MB(alg)"))
     for r in rows:
