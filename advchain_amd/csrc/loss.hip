@@ -19,6 +19,18 @@
 #include <stdlib.h>
 #include "common.h"
 
+// exp of a softmax argument x - max <= 0: the library expf (13 VALU instructions: extended-precision argument reduction,
+// ldexp, range selects) or v_exp_f32(x log2 e) (2; its argument product is rounded once: |x| 6e-8 relative, at most 2.2e-8
+// absolute in a probability, against the 6e-8 of a correctly rounded exp).  A/B of tools/sessions/r06_s18.sh
+#ifndef ADVCHAIN_SOFTMAX_FAST_EXP
+#define ADVCHAIN_SOFTMAX_FAST_EXP 1
+#endif
+#if ADVCHAIN_SOFTMAX_FAST_EXP
+#define ADVCHAIN_SM_EXP(x) __expf(x)
+#else
+#define ADVCHAIN_SM_EXP(x) expf(x)
+#endif
+
 namespace advchain {
 
 constexpr int kMaxK = 16;
@@ -65,14 +77,15 @@ k_softmax_diff(const float* __restrict__ pred, const float* __restrict__ ref, co
     }
     float sp = 0.f, sr = 0.f;
     for (int k = 0; k < K; ++k) {
-      sp += expf(pn[(int64_t)k * V] - mp);
-      sr += expf(rn[(int64_t)k * V] - mr);
+      sp += ADVCHAIN_SM_EXP(pn[(int64_t)k * V] - mp);
+      sr += ADVCHAIN_SM_EXP(rn[(int64_t)k * V] - mr);
     }
     const float lsp = logf(sp), lsr = logf(sr);
+    const float isp = 1.f / sp, isr = 1.f / sr;     // ONE division per voxel and side, K products (see softmax_quads)
     for (int k = 0; k < K; ++k) {
       const float zp = pn[(int64_t)k * V] - mp, zr = rn[(int64_t)k * V] - mr;
-      const float p = expf(zp) / sp;
-      const float t = ref_is_prob ? rn[(int64_t)k * V] : expf(zr) / sr;
+      const float p = mul_nc(ADVCHAIN_SM_EXP(zp), isp);
+      const float t = ref_is_prob ? rn[(int64_t)k * V] : mul_nc(ADVCHAIN_SM_EXP(zr), isr);
       const float m = mask ? mask[((int64_t)n * mask_ch + (mask_ch > 1 ? k : 0)) * V + v] : 1.f;
       const int64_t o = ((int64_t)n * K + k) * V + v;
       P[o] = p;
@@ -122,13 +135,14 @@ k_softmax_diff_v4(const float* __restrict__ pred, const float* __restrict__ ref,
       for (int k = 0; k < K; ++k) { mp = fmaxf(mp, p[k][q]); mr = fmaxf(mr, r[k][q]); }
       float sp = 0.f, sr = 0.f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) { sp += expf(p[k][q] - mp); sr += expf(r[k][q] - mr); }
+      for (int k = 0; k < K; ++k) { sp += ADVCHAIN_SM_EXP(p[k][q] - mp); sr += ADVCHAIN_SM_EXP(r[k][q] - mr); }
       const float lsp = want_kl ? logf(sp) : 0.f, lsr = want_kl ? logf(sr) : 0.f;
+      const float isp = 1.f / sp, isr = 1.f / sr;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const float zp = p[k][q] - mp, zr = r[k][q] - mr;
-        const float pp = expf(zp) / sp;
-        const float tt = ref_is_prob ? r[k][q] : expf(zr) / sr;
+        const float pp = mul_nc(ADVCHAIN_SM_EXP(zp), isp);
+        const float tt = ref_is_prob ? r[k][q] : mul_nc(ADVCHAIN_SM_EXP(zr), isr);
         p[k][q] = pp;
         r[k][q] = pp - tt;          // D
         const float tq = tt;
@@ -821,13 +835,20 @@ __device__ __forceinline__ void softmax_quads(const float (&p)[K][4], const floa
     for (int k = 0; k < K; ++k) { mp = fmaxf(mp, p[k][q]); mr = fmaxf(mr, r[k][q]); }
     float sp = 0.f, sr = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) { sp += expf(p[k][q] - mp); sr += expf(r[k][q] - mr); }
+    for (int k = 0; k < K; ++k) { sp += ADVCHAIN_SM_EXP(p[k][q] - mp); sr += ADVCHAIN_SM_EXP(r[k][q] - mr); }
     const float lsp = LOGS ? logf(sp) : 0.f, lsr = LOGS ? logf(sr) : 0.f;
+    // ONE correctly rounded division per voxel and side and K products instead of K divisions (round 6: a division is ten
+    // VALU instructions, and 41 % of the marching loop's were divisions): P differs from exp / sum by at most one ulp.
+    // mul_nc (common.h; __fmul_rn is a plain `*` on this toolchain): the product must be ROUNDED before anything uses it -- contracted into a consumer's fma, `P - (P - T)` of
+    // the backward's 'kl' term (kl_prob) is the product's rounding error instead of T = 0 (caught by
+    // test_fused_loss_3d_marching_along_z[2-dims0]).  The hardware reciprocal (v_rcp_f32, one ulp) instead of the division
+    // measured another 1-4 us per launch and nothing per call (profiles/r06/softmax_rcp/): not taken.
+    const float isp = 1.f / sp, isr = 1.f / sr;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float zp = p[k][q] - mp, zr = r[k][q] - mr;
-      P[k][q] = expf(zp) / sp;
-      T[k][q] = ref_is_prob ? r[k][q] : expf(zr) / sr;
+      P[k][q] = mul_nc(ADVCHAIN_SM_EXP(zp), isp);
+      T[k][q] = ref_is_prob ? r[k][q] : mul_nc(ADVCHAIN_SM_EXP(zr), isr);
       if (LOGS) { lq[k][q] = zp - lsp; lt[k][q] = zr - lsr; }
     }
   }
