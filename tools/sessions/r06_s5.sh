@@ -2,7 +2,7 @@
 # round 6, GPU session 5: the whole GPU suite on the final state, then everything profiles/r06 holds (tools/profile_all.sh) and the
 # default bench line
 set -u
-tag=r06r
+tag=r06v
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/$tag
 mkdir -p "$out"
